@@ -1,0 +1,157 @@
+"""Synthetic, reproducible checkpoints, frames and crowd heads (no dataset, no network).
+
+* ``make_state_dict``  -- a state_dict with the reference's names/shapes (arch.param_spec),
+  conv weights ~ kaiming-normal(a=0.1, fan_in) as in model.py:97-102 but drawn from the
+  integer PRNG, BN affine slightly randomised so the scale/shift paths are exercised.
+* ``planted_crowd_head`` -- SURVEY.md 8d config 5: a head tensor with planted people
+  following the target-encoder rules of dataset.py:108-152, used for the decode stress.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import numpy as np
+
+from . import arch as A
+from . import config as cfg
+from . import prng
+
+
+def _name_stream(seed: int, name: str) -> int:
+    h = 0xCBF29CE484222325
+    for b in name.encode():
+        h = ((h ^ b) * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
+    return prng.stream_seed(seed, h & 0x7FFFFFFF)
+
+
+def make_state_dict(arch: str = "drn_d_22", seed: int = 0, bn_stats: Optional[Dict[str, np.ndarray]] = None,
+                    head_channels: Optional[int] = None) -> Dict[str, np.ndarray]:
+    sd: Dict[str, np.ndarray] = {}
+    for name, shape in A.param_spec(arch, head_channels):
+        s = _name_stream(seed, name)
+        n = int(np.prod(shape)) if shape else 1
+        if name.endswith("num_batches_tracked"):
+            sd[name] = np.array(1, dtype=np.int64)
+        elif name.endswith("running_mean"):
+            sd[name] = np.zeros(shape, np.float32)
+        elif name.endswith("running_var"):
+            sd[name] = np.ones(shape, np.float32)
+        elif len(shape) == 4:                                   # conv weight
+            fan_in = shape[1] * shape[2] * shape[3]
+            std = math.sqrt(2.0 / (1.0 + 0.1 * 0.1)) / math.sqrt(fan_in)
+            sd[name] = (prng.normalish(s, n) * np.float32(std)).reshape(shape)
+        elif name in ("conv2.bias", "conv3.bias"):              # nn.Conv2d default bias init range
+            bound = 1.0 / math.sqrt(512 * (9 if name == "conv2.bias" else 1))
+            sd[name] = prng.uniform(s, n, -bound, bound).reshape(shape)
+        elif name.endswith(".weight"):                          # BN gamma
+            sd[name] = prng.uniform(s, n, 0.7, 1.3).reshape(shape)
+        else:                                                   # BN beta
+            sd[name] = prng.uniform(s, n, -0.2, 0.2).reshape(shape)
+    if bn_stats:
+        for k, v in bn_stats.items():
+            assert k in sd and sd[k].shape == v.shape, k
+            sd[k] = v.astype(np.float32)
+    return sd
+
+
+def normalized_frames(frames_u8: np.ndarray) -> np.ndarray:
+    """u8[B,H,W,3] -> f32[B,3,H,W] with the reference's (x-mean)/std, no /255 (aug.py:149-153)."""
+    x = frames_u8.astype(np.float32).transpose(0, 3, 1, 2)
+    mean = np.array(cfg.MEAN, np.float32).reshape(1, 3, 1, 1)
+    std = np.array(cfg.STD, np.float32).reshape(1, 3, 1, 1)
+    return ((x - mean) / std).astype(np.float32)
+
+
+def planted_crowd_head(seed: int, n_people: int = 16, n_decoys: int = 4, out_hw=(24, 24),
+                       local_grid=(21, 21)) -> np.ndarray:
+    """One head tensor f32[6K+E*sH*sW, H, W] with a planted crowd.
+
+    Background: resp,conf ~ U(0,0.3) (delta < 0.09), x,y ~ U(0,1), w,h ~ U(0.02,0.1),
+    e ~ U(0,0.5).  Each planted person gets a distinct root cell with resp=conf in
+    U(0.8,1), an instance box of 0.15..0.4 of the frame, and for every limb of the
+    skeleton tree an offset |dh|,|dw| <= 10 whose e-channel is raised to U(0.9,1)
+    (te[ei, dh+10, dw+10, h, w] = 1 in dataset.py:136-152).  Some limbs are truncated
+    (target delta < 0.15) or point outside the grid to exercise both `break`s of
+    datatest.py:118-122; decoy roots have no limbs or heavily overlap a planted root.
+    All values come from the integer PRNG; candidate scores are distinct by construction
+    with overwhelming probability (24-bit uniforms) and the generator re-draws on a tie.
+    """
+    H, W = out_hw
+    sW, sH = local_grid
+    K, E = cfg.K, cfg.E
+    C = 6 * K + E * sH * sW
+    n = C * H * W
+    st = lambda i: prng.stream_seed(seed, i)
+    head = np.empty((C, H, W), np.float32)
+    head[0:2 * K] = prng.uniform(st(1), 2 * K * H * W, 0.0, 0.3).reshape(2 * K, H, W)
+    head[2 * K:4 * K] = prng.uniform01(st(2), 2 * K * H * W).reshape(2 * K, H, W)
+    head[4 * K:6 * K] = prng.uniform(st(3), 2 * K * H * W, 0.02, 0.1).reshape(2 * K, H, W)
+    head[6 * K:] = prng.uniform(st(4), E * sH * sW * H * W, 0.0, 0.5).reshape(E * sH * sW, H, W)
+
+    r = prng.raw_u64(st(5), 4096)
+    ri = [0]
+
+    def rnd():                      # float in [0,1)
+        v = float(r[ri[0]] >> np.uint64(40)) / 16777216.0
+        ri[0] += 1
+        return v
+
+    def rint(lo, hi):               # integer in [lo, hi]
+        return lo + int(rnd() * (hi - lo + 1))
+
+    src, dst, order = cfg.tree_tables()
+    cells = set()
+    used_scores = set()
+
+    def put_kp(k, h, w, strong=True):
+        while True:
+            a = 0.8 + 0.2 * rnd() if strong else 0.2 * rnd()
+            val = np.float32(a)
+            prod = float(val * val)
+            if prod not in used_scores:
+                used_scores.add(prod)
+                break
+        head[k, h, w] = val
+        head[K + k, h, w] = val
+
+    people = 0
+    tries = 0
+    while people < n_people + n_decoys and tries < 10000:
+        tries += 1
+        h0, w0 = rint(0, H - 1), rint(0, W - 1)
+        if (h0, w0) in cells:
+            continue
+        cells.add((h0, w0))
+        decoy = people >= n_people
+        put_kp(0, h0, w0)
+        head[4 * K, h0, w0] = np.float32(0.15 + 0.25 * rnd())
+        head[5 * K, h0, w0] = np.float32(0.15 + 0.25 * rnd())
+        people += 1
+        if decoy and rnd() < 0.5:
+            continue                                  # decoy without limbs -> dropped (datatest.py:129)
+        pos = {0: (h0, w0)}
+        for e in order:
+            s, d = src[e], dst[e]
+            if s not in pos:
+                continue
+            ph, pw = pos[s]
+            mode = rnd()
+            dh, dw = rint(-3, 3), rint(-3, 3)
+            if mode < 0.06:                           # limb pointing out of the grid
+                dh = -10 if ph < 10 else 10
+                if 0 <= ph + dh < H:
+                    dh = -ph - 1 if ph < 10 else H - ph
+                    dh = max(-10, min(10, dh))
+            jh, jw = ph + dh, pw + dw
+            ch = 6 * K + e * sH * sW + (dh + sH // 2) * sW + (dw + sW // 2)
+            head[ch, ph, pw] = np.float32(0.9 + 0.1 * rnd())
+            if not (0 <= jh < H and 0 <= jw < W):
+                continue
+            if mode > 0.92:                           # truncated limb: target delta stays < 0.15
+                continue
+            put_kp(d, jh, jw)
+            head[4 * K + d, jh, jw] = np.float32(0.02 + 0.08 * rnd())
+            head[5 * K + d, jh, jw] = np.float32(0.02 + 0.08 * rnd())
+            pos[d] = (jh, jw)
+    return head

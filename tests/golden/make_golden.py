@@ -1,0 +1,250 @@
+"""Generate the golden fixtures by running the REFERENCE itself (this container only).
+
+Usage:  python tests/golden/make_golden.py [--only forward|decode|nms]
+
+The reference (/root/reference, read-only, never copied) is imported with stub modules for
+its absent optional dependencies (recipe: SURVEY.md Appendix B).  For every fixture the
+script (1) builds inputs from the repo's integer PRNG, (2) runs the reference's own code
+(model.PoseProposalNet / datatest.get_humans_by_feature / datatest.non_maximum_suppression),
+(3) checks the repo's CPU oracle (oracle/*.py) against it, and (4) writes inputs' seeds and
+expected outputs as small .npz files next to this script.  Fixtures are data only.
+
+The GPU box never sees /root/reference: tests replay the fixtures from seeds.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import types
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+REF = "/root/reference"
+
+
+def import_reference():
+    sys.path.insert(0, REF)
+    sys.argv = ["main.py"]
+    import matplotlib
+    matplotlib.use("Agg")
+
+    def stub(name, **a):
+        m = types.ModuleType(name)
+        m.__dict__.update(a)
+        sys.modules[name] = m
+        return m
+
+    stub("torchsummary", summary=lambda *a, **k: None)
+    stub("gelu", GELU=object)
+    tv = stub("torchvision")
+    for s in ("transforms", "utils", "datasets", "models"):
+        setattr(tv, s, stub("torchvision." + s))
+    sk = stub("skimage")
+    sk.io = stub("skimage.io")
+    sk.transform = stub("skimage.transform")
+    stub("skimage.color", gray2rgb=None)
+    stub("cv2")
+    ia = stub("imgaug")
+    ia.augmenters = stub("imgaug.augmenters")
+    sh = stub("shapely")
+    sh.geometry = stub("shapely.geometry")
+    import drn, model, datatest  # noqa: E401
+    return drn, model, datatest
+
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from pytorch_pose_proposal_network_amd import arch as A, config as cfg, prng, synth  # noqa: E402
+from oracle import decode_ref as D, forward_ref as Fr  # noqa: E402
+
+
+def build_ref_model(drn, model, arch_name, sd_np):
+    import torch.nn as nn
+    bb = getattr(drn, arch_name)()
+    net = model.PoseProposalNet(nn.Sequential(*list(bb.children())[:-2]), local_grid_size=(21, 21))
+    sd = {k: torch.from_numpy(np.asarray(v)).clone() for k, v in sd_np.items()}
+    missing = net.load_state_dict(sd, strict=True)
+    return net
+
+
+def calibrate(net, frames):
+    """One train-mode pass with momentum 1.0 -> running stats = batch stats."""
+    import torch.nn as nn
+    for m in net.modules():
+        if isinstance(m, nn.BatchNorm2d):
+            m.momentum = 1.0
+    net.train()
+    with torch.no_grad():
+        net(frames)
+    net.eval()
+    return {k: v.detach().numpy().copy() for k, v in net.state_dict().items()
+            if k.endswith("running_mean") or k.endswith("running_var")}
+
+
+def make_forward(drn, model):
+    cases = [  # (fixture name, arch, size, batch, full head?)
+        ("forward_d22_96", "drn_d_22", 96, 2, True),
+        ("forward_d22_384", "drn_d_22", 384, 2, False),
+        ("forward_d54_96", "drn_d_54", 96, 1, True),
+        ("forward_d38_96", "drn_d_38", 96, 1, True),
+    ]
+    for name, arch_name, size, batch, full in cases:
+        seed_w, seed_cal, seed_in = 0, 1, 1234
+        sd = synth.make_state_dict(arch_name, seed_w)
+        # the reference's own state_dict must have exactly our names/shapes
+        net = build_ref_model(drn, model, arch_name, sd)
+        ref_keys = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+        spec = dict(A.param_spec(arch_name))
+        assert ref_keys == {k: tuple(s) for k, s in spec.items()}, "param_spec mismatch with reference"
+        cal = Fr.normalize_u8(prng.u8_frames(seed_cal, 4, (size, size)))
+        stats = calibrate(net, cal)
+        x_u8 = prng.u8_frames(seed_in, batch, (size, size))
+        x = Fr.normalize_u8(x_u8)
+        with torch.no_grad():
+            ref = net(x).numpy()
+        # oracle vs reference (same torch build -> expect ~bit equality)
+        sd_cal = synth.make_state_dict(arch_name, seed_w, bn_stats=stats)
+        taps = {}
+        mine = Fr.forward_ref(sd_cal, x, arch_name, taps=taps).numpy()
+        err = float(np.abs(mine - ref).max())
+        sat = float(((ref == 0) | (ref == 1)).mean())
+        print(f"{name}: oracle-vs-reference max|diff| = {err:.3e}; saturated frac {sat:.4f}; "
+              f"head mean {ref.mean():.4f}")
+        assert err <= 1e-6, err
+        # calibration by the oracle's own train-mode BN must reproduce the reference's stats
+        sd2 = synth.make_state_dict(arch_name, seed_w)
+        Fr.forward_ref(sd2, cal, arch_name, train_bn=True, momentum=1.0)
+        for k, v in stats.items():
+            np.testing.assert_allclose(sd2[k], v, rtol=1e-4, atol=1e-5)
+        out = {"seed_w": seed_w, "seed_cal": seed_cal, "seed_in": seed_in, "size": size, "batch": batch,
+               "arch": arch_name}
+        for k, v in stats.items():
+            out["bn/" + k] = v
+        for k, v in taps.items():
+            t = v.numpy().astype(np.float64)
+            out["tap/" + k] = np.array([t.mean(), np.abs(t).mean(), t.std()])
+        if full:
+            out["head"] = ref
+        else:
+            n = 40000
+            idx = (prng.raw_u64(prng.stream_seed(99, 0), n) % np.uint64(ref.size)).astype(np.int64)
+            out["head_idx"] = idx
+            out["head_val"] = ref.reshape(-1)[idx]
+            out["head_chan_sum"] = ref.astype(np.float64).sum(axis=(2, 3))
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+        if size == 384:
+            # the calibrated BN statistics double as the synthetic "checkpoint" of bench.py
+            d = os.path.join(ROOT, "pytorch_pose_proposal_network_amd", "data")
+            os.makedirs(d, exist_ok=True)
+            np.savez_compressed(os.path.join(d, f"bn_calib_{arch_name}_seed{seed_w}.npz"), **stats)
+    # D-54 calibrated at 384 for the config-5 end-to-end run (stats only)
+    sd = synth.make_state_dict("drn_d_54", 0)
+    net = build_ref_model(drn, model, "drn_d_54", sd)
+    stats = calibrate(net, Fr.normalize_u8(prng.u8_frames(1, 2, (384, 384))))
+    d = os.path.join(ROOT, "pytorch_pose_proposal_network_amd", "data")
+    np.savez_compressed(os.path.join(d, "bn_calib_drn_d_54_seed0.npz"), **stats)
+
+
+def compare_humans(ref_h, ref_s, res):
+    humans, scores = D.humans_from_compact(res)
+    assert len(humans) == len(ref_h), (len(humans), len(ref_h))
+    for a, b, sa, sb in zip(humans, ref_h, scores, ref_s):
+        assert sorted(a.keys()) == sorted(b.keys()), (sorted(a.keys()), sorted(b.keys()))
+        for k in a:
+            assert np.array_equal(a[k], b[k]), (k, a[k], b[k])
+            assert sa[k] == sb[k]
+
+
+def make_decode(datatest):
+    heads = []
+    for seed in range(7, 7 + 12):
+        heads.append(("crowd", seed, synth.planted_crowd_head(seed)))
+    for seed in range(100, 104):               # unstructured heads: many candidates, NMS heavy
+        C = cfg.lastsize()
+        h = prng.uniform01(prng.stream_seed(seed, 0), C * 576).reshape(C, 24, 24)
+        h[0:36] = prng.uniform(prng.stream_seed(seed, 1), 36 * 576, 0.2, 1.0).reshape(36, 24, 24)
+        h[72:108] = prng.uniform(prng.stream_seed(seed, 2), 36 * 576, 0.05, 0.3).reshape(36, 24, 24)
+        heads.append(("random", seed, h.astype(np.float32)))
+    out = {}
+    for i, (kind, seed, head) in enumerate(heads):
+        delta, x, y, w, h, e = D.split_head(head)
+        ref_h, ref_s = datatest.get_humans_by_feature(delta, x, y, w, h, e, detection_thresh=0.15)
+        res = D.decode_ref(head)
+        compare_humans(ref_h, ref_s, res)
+        sc = delta[0][delta[0] > np.float32(0.15)]
+        assert len(np.unique(sc)) == len(sc), "fixture must have distinct candidate scores"
+        print(f"decode {kind} seed {seed}: {len(res['cand'])} candidates, {len(res['selected'])} after NMS, "
+              f"{res['n']} humans, {int((res['kp_cell'] >= 0).sum())} keypoints")
+        out[f"{i}/kind"] = kind
+        out[f"{i}/seed"] = seed
+        for k in ("n", "root_cell", "kp_cell", "limb_arg", "bbox", "score", "cand", "selected"):
+            out[f"{i}/{k}"] = res[k]
+    out["count"] = len(heads)
+    np.savez_compressed(os.path.join(HERE, "decode_heads.npz"), **out)
+
+
+def make_nms(datatest):
+    out = {}
+    cases = []
+    # hand-made boxes: disjoint, nested, identical, touching edges, and IoU straddling 0.3
+    base = np.array([[10, 10, 50, 50], [12, 12, 52, 52], [100, 100, 140, 160], [10, 50, 50, 90],
+                     [20, 20, 40, 40], [100, 100, 140, 160], [0, 0, 384, 384]], np.float32)
+    cases.append((base, np.array([0.9, 0.8, 0.7, 0.6, 0.95, 0.65, 0.5], np.float32)))
+    # pairs whose IoU is swept across the 0.3 knife edge in 1-ulp steps of one coordinate
+    a = np.array([0, 0, 100, 100], np.float32)
+    xs = []
+    x = np.float32(53.846153)          # shift giving IoU ~ 0.3 for two 100x100 boxes
+    for _ in range(8):
+        x = np.nextafter(x, np.float32(0))
+    for _ in range(16):
+        xs.append(x)
+        x = np.nextafter(x, np.float32(1000))
+    for x in xs:
+        b = np.array([0, x, 100, x + np.float32(100)], np.float32)
+        cases.append((np.stack([a, b]), np.array([0.9, 0.8], np.float32)))
+    # random crowds
+    for seed in range(5):
+        n = 40 + 30 * seed
+        u = prng.uniform01(prng.stream_seed(500 + seed, 0), n * 5).reshape(n, 5)
+        cy, cx = u[:, 0] * 384, u[:, 1] * 384
+        hh, ww = 20 + u[:, 2] * 150, 20 + u[:, 3] * 150
+        bb = np.stack([cy - hh / 2, cx - ww / 2, cy + hh / 2, cx + ww / 2], 1).astype(np.float32)
+        cases.append((bb, u[:, 4].astype(np.float32)))
+    for i, (bb, sc) in enumerate(cases):
+        ref = datatest.non_maximum_suppression(bb, 0.3, sc)
+        mine = D.nms_ref(bb, 0.3, sc)
+        assert np.array_equal(ref, mine), (i, ref, mine)
+        out[f"{i}/bbox"], out[f"{i}/score"], out[f"{i}/sel"] = bb, sc, ref
+        if i < 20:
+            ref_l = datatest.non_maximum_suppression(bb, 0.3, sc, limit=1)
+            assert np.array_equal(ref_l, D.nms_ref(bb, 0.3, sc, limit=1))
+    # score=None path (input order)
+    ref = datatest.non_maximum_suppression(base, 0.3)
+    assert np.array_equal(ref, D.nms_ref(base, 0.3))
+    out["noscore/bbox"], out["noscore/sel"] = base, ref
+    out["count"] = len(cases)
+    print(f"nms: {len(cases)} cases; knife-edge selections:",
+          [len(out[f'{i}/sel']) for i in range(1, 17)])
+    np.savez_compressed(os.path.join(HERE, "nms_cases.npz"), **out)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    args = ap.parse_args()
+    drn, model, datatest = import_reference()
+    torch.set_num_threads(8)
+    if args.only in (None, "nms"):
+        make_nms(datatest)
+    if args.only in (None, "decode"):
+        make_decode(datatest)
+    if args.only in (None, "forward"):
+        make_forward(drn, model)
+
+
+if __name__ == "__main__":
+    main()
