@@ -1,0 +1,164 @@
+/*
+ * libppn -- MI355X (gfx950) native Pose Proposal Network hot path, C ABI.
+ *
+ * The reference (noirmist/Pytorch_Pose_Proposal_Network) is 100 % Python and has no FFI;
+ * its call surface for this path is
+ *     PoseProposalNet.forward            model.py:104-136   (conv/BN/act stack)
+ *     rt_test.inference                  rt_test.py:87-147  (normalise, forward, slice, decode)
+ *     datatest.get_humans_by_feature     datatest.py:74-132 (decode + root NMS + limb parse)
+ *     datatest.non_maximum_suppression   datatest.py:134-160
+ * The entry points below are what a ctypes binding for those functions binds
+ * (INTEGRATION.md shows the stub).  Conventions:
+ *   - every function returns 0 on success, a negative PPN_E_* code on error;
+ *     ppn_last_error() returns a thread-local message.  No C++ exception crosses the ABI.
+ *   - all tensor arguments are BORROWED raw device pointers (PyTorch-ROCm owns the memory);
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
+ *     every launch is asynchronous on that stream; nothing here synchronises or allocates,
+ *     except ppn_plan_create/ppn_plan_destroy (host memory, optional hipGraph).
+ *   - not thread-safe per handle (the reference is single-threaded).
+ */
+#ifndef PPN_H
+#define PPN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PPN_OK 0
+#define PPN_E_INVALID (-1)   /* bad argument / unsupported shape */
+#define PPN_E_HIP (-2)       /* a HIP runtime call failed */
+#define PPN_E_UNSUPPORTED (-3)
+
+#define PPN_MAX_EDGES 32
+#define PPN_MAX_KP 32
+
+const char* ppn_last_error(void);
+int ppn_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Decode: grid-cell decode + root-box NMS + greedy limb parse on the DEVICE head tensor.
+ * Replaces datatest.py:74-132 (get_humans_by_feature) incl. the head slicing and
+ * delta = resp*conf of rt_test.py:106-130; bit-exact on every index it returns.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct ppn_decode_cfg {
+    int32_t K, E;                 /* keypoints (18), edges (17)                config.py:64-65   */
+    int32_t sH, sW;               /* local limb window (21,21)                 rt_test.py:58     */
+    int32_t H, W;                 /* output grid (24,24)                       datatest.py:54    */
+    int32_t inH, inW;             /* network input size (384,384)              datatest.py:53    */
+    float det_thr;                /* 0.15  rt_test.py:133                                        */
+    float nms_thr;                /* 0.3   datatest.py:94                                        */
+    int32_t min_kp;               /* 1     datatest.py:74                                        */
+    int32_t max_humans;           /* rows per image in the output buffers (<= H*W)               */
+    int32_t edge_src[PPN_MAX_EDGES];   /* EDGES[e][0]                          config.py:65      */
+    int32_t edge_dst[PPN_MAX_EDGES];   /* EDGES[e][1]                                            */
+    int32_t edge_order[PPN_MAX_EDGES]; /* edges parent-before-child (tree form of DIRECTED_GRAPHS,
+                                          config.py:67-80)                                      */
+} ppn_decode_cfg;
+
+/* Bytes of device scratch ppn_decode needs for `batch` images (limb arg-max map). */
+size_t ppn_decode_workspace_bytes(const ppn_decode_cfg* cfg, int32_t batch);
+
+/*
+ * head       f32 [batch, 6K + E*sH*sW, H, W]  sigmoid outputs, NCHW contiguous (model.py:136)
+ * workspace  >= ppn_decode_workspace_bytes()
+ * out_count  i32 [batch]                          humans kept per image (before max_humans clamp)
+ * out_kp_cell  i32 [batch, max_humans, K]         row-major cell h*W+w of each accepted keypoint, -1 absent
+ * out_limb_arg i32 [batch, max_humans, E]         arg-max index sh*sW+sw of each evaluated limb, -1 otherwise
+ * out_bbox   f32 [batch, max_humans, K, 4]        (ymin,xmin,ymax,xmax)  datatest.py:80-86
+ * out_score  f32 [batch, max_humans, K]           delta = resp*conf of accepted keypoints
+ * Humans are ordered by descending root score (datatest.py:103,139); equal scores by ascending cell.
+ */
+int ppn_decode(const ppn_decode_cfg* cfg, const float* head, int32_t batch, void* workspace,
+               int32_t* out_count, int32_t* out_kp_cell, int32_t* out_limb_arg, float* out_bbox,
+               float* out_score, void* stream);
+
+/* First half of ppn_decode on its own (the HBM-bound kernel): dense first-index arg-max over the
+ * sH*sW limb window for every (image, edge, cell).  out_arg i32 [batch, E, H, W]. */
+int ppn_limb_argmax(const ppn_decode_cfg* cfg, const float* head, int32_t batch, int32_t* out_arg,
+                    void* stream);
+
+/*
+ * datatest.py:134-160 non_maximum_suppression.  bbox f32 [n,4] (ymin,xmin,ymax,xmax) on device,
+ * score f32 [n] or NULL, limit <= 0 means None.  out_sel i32 [n] receives the selected indices in the
+ * reference's order (descending score when score is given), out_count i32 [1].  n <= 1024.
+ */
+int ppn_nms(const float* bbox, const float* score, int32_t n, float thresh, int32_t limit, int32_t* out_sel,
+            int32_t* out_count, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Convolution stack: one fused launch per convolution of PoseProposalNet.forward
+ * (model.py:104-136, drn.py:42-57,77-97,192-202).
+ *   acc  = conv(src, weight)                        implicit GEMM on MFMA, NHWC activations
+ *   v    = act1(acc * scale1 + shift1)              folded conv-bias / eval-mode BN + ReLU/LReLU/sigmoid
+ *   v   += residual                                 (optional)
+ *   out_raw = v                                     (optional)
+ *   out_act = act2(v * scale2 + shift2)             (optional) pre-activation of the consumer block
+ * ---------------------------------------------------------------------------------------- */
+enum { PPN_ACT_NONE = 0, PPN_ACT_RELU = 1, PPN_ACT_LRELU = 2, PPN_ACT_SIGMOID = 3 };
+enum { PPN_F32 = 0, PPN_BF16 = 1 };
+
+typedef struct ppn_conv_desc {
+    int32_t dtype;               /* PPN_F32 (exact-f32 MFMA, parity mode) or PPN_BF16 (bf16 MFMA, f32 accumulate) */
+    int32_t batch, in_h, in_w, cin;
+    int32_t out_h, out_w, cout;
+    int32_t ksize, stride, dilation, pad;
+    int32_t k_total;             /* padded GEMM depth of the packed weight rows (multiple of the K step) */
+    int32_t cout_pad;            /* rows in the packed weight matrix (multiple of the channel tile)  */
+    int32_t act1, act2;
+    int32_t out_nchw_f32;        /* 1: out_raw is f32 NCHW [B,cout,H,W] (the head, model.py:136)     */
+    const void* src;             /* NHWC [B,in_h,in_w,cin] dtype                                      */
+    const void* weight;          /* packed [cout_pad][k_total] dtype, k = (ky*ksize+kx)*cin + ci      */
+    const float* scale1;         /* [cout] or NULL (=1)                                               */
+    const float* shift1;         /* [cout] or NULL (=0)                                               */
+    const void* residual;        /* NHWC [B,out_h,out_w,cout] dtype or NULL                           */
+    void* out_raw;               /* NHWC dtype (or NCHW f32) or NULL                                  */
+    const float* scale2;         /* [cout] or NULL                                                    */
+    const float* shift2;         /* [cout] or NULL                                                    */
+    void* out_act;               /* NHWC dtype or NULL                                                */
+    const void* zero_page;       /* >= 256 B of zeros on device (padding source)                      */
+} ppn_conv_desc;
+
+/* GEMM-depth step / channel tile the packer must pad to for a conv of this shape and dtype. */
+int ppn_conv_tiling(int32_t dtype, int32_t cin, int32_t cout, int32_t ksize, int32_t* k_step, int32_t* cout_tile);
+
+int ppn_conv2d_fused(const ppn_conv_desc* d, void* stream);
+
+/*
+ * First layer (drn.py:123-128 layer0: 7x7 conv 3->16, BN, ReLU) with the input normalisation of
+ * rt_test.py:97-101 / aug.py:149-153 fused into the load.
+ *   src_u8   u8  [B,H,W,3]  RGB frame (src_is_u8=1)  -> (x-mean_c)/std_c applied on the fly, or
+ *   src_f32  f32 [B,3,H,W]  already normalised NCHW input, the model.forward() argument (src_is_u8=0)
+ *   weight   f32 [16,3,7,7] (reference layout), scale/shift f32[16] folded BN
+ *   out      NHWC [B,H,W,16] dtype
+ */
+int ppn_stem7x7(int32_t dtype, int32_t src_is_u8, const void* src, int32_t batch, int32_t h, int32_t w,
+                const float* weight, const float* scale, const float* shift, const float* mean, const float* std_,
+                const float* scale2, const float* shift2, int32_t act2, void* out_raw, void* out_act, void* stream);
+
+/* A recorded sequence of launches (one forward pass): replayed in order on `stream`. */
+typedef struct ppn_plan ppn_plan;
+int ppn_plan_create(ppn_plan** out);
+int ppn_plan_add_conv(ppn_plan* p, const ppn_conv_desc* d);
+int ppn_plan_add_stem(ppn_plan* p, int32_t dtype, int32_t src_is_u8, const void* src, int32_t batch, int32_t h,
+                      int32_t w, const float* weight, const float* scale, const float* shift, const float* mean,
+                      const float* std_, const float* scale2, const float* shift2, int32_t act2, void* out_raw,
+                      void* out_act);
+int ppn_plan_run(ppn_plan* p, void* stream);
+/* Same as ppn_plan_run but brackets every launch with HIP events on `stream`; ms[i] = duration of launch i. */
+int ppn_plan_run_timed(ppn_plan* p, void* stream, float* ms, int32_t n_ms);
+int ppn_plan_size(const ppn_plan* p);
+/* Name of the kernel launch i dispatches (as it appears in rocprofv3 --kernel-trace). */
+const char* ppn_plan_kernel_name(const ppn_plan* p, int32_t i);
+int ppn_plan_destroy(ppn_plan* p);
+
+/* Weight packing: reference layout f32 [cout,cin,k,k] -> [cout_pad][k_total] dtype, zero padded. */
+int ppn_pack_weight(int32_t dtype, const float* w, int32_t cout, int32_t cin, int32_t ksize, int32_t cout_pad,
+                    int32_t k_total, void* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PPN_H */

@@ -1,0 +1,32 @@
+// Shared host-side helpers of libppn (error reporting, launch checks).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+
+#include "../../include/ppn.h"
+
+namespace ppn {
+
+char* error_buffer();  // thread-local, 512 bytes
+
+inline int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(error_buffer(), 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define PPN_HIP_CHECK(expr)                                                                      \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return ::ppn::fail(PPN_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                               __FILE__, __LINE__);                                              \
+    } while (0)
+
+#define PPN_LAUNCH_CHECK() PPN_HIP_CHECK(hipGetLastError())
+
+}  // namespace ppn

@@ -1,0 +1,479 @@
+// Decode + root-box NMS + greedy limb parse on the device head tensor (gfx950, wave64).
+//
+// Replaces the NumPy/Python of the reference:
+//   head slicing, delta = resp*conf ............ rt_test.py:106-130
+//   restore_xy / restore_size / bbox ........... datatest.py:63-86
+//   candidates, non_maximum_suppression ........ datatest.py:87-95, 134-160
+//   limb parse over DIRECTED_GRAPHS ............ datatest.py:98-132, config.py:67-80
+//
+// Two kernels per batch:
+//   limb_argmax_kernel  HBM-bound: streams the whole e block (E*sH*sW channels x H*W cells) of
+//                       every image exactly once with 16-byte coalesced loads and keeps the
+//                       FIRST maximum per (edge, cell) -- np.argmax semantics (datatest.py:113).
+//   parse_kernel        one workgroup per image: ballot-compaction of root candidates, rank sort,
+//                       pairwise-IoU bit matrix, a one-wave greedy resolve, and one lane per
+//                       surviving root walking the skeleton tree through the arg-max map.
+//
+// All floating-point arithmetic follows the reference's fp32 operation order; this file is
+// compiled with -ffp-contract=off so no multiply-add is fused (the IoU >= 0.3 and
+// delta < 0.15 tests are knife edges).
+#include "common.h"
+
+namespace {
+
+constexpr int kWave = 64;
+
+struct DecodeParams {
+    ppn_decode_cfg c;
+    int C;       // channels per image = 6K + E*sH*sW
+    int ncell;   // H*W
+    int S;       // sH*sW
+};
+
+// ------------------------------------------------------------------------------------------
+// Kernel 1: dense limb arg-max.  grid = (E, batch); thread t -> (column group q, row slice r).
+// ------------------------------------------------------------------------------------------
+template <int V>
+struct VecT;
+template <>
+struct VecT<4> {
+    using type = float4;
+};
+template <>
+struct VecT<1> {
+    using type = float;
+};
+
+template <int V>
+__device__ __forceinline__ void vec_to_arr(const typename VecT<V>::type& v, float* a);
+template <>
+__device__ __forceinline__ void vec_to_arr<4>(const float4& v, float* a) {
+    a[0] = v.x; a[1] = v.y; a[2] = v.z; a[3] = v.w;
+}
+template <>
+__device__ __forceinline__ void vec_to_arr<1>(const float& v, float* a) {
+    a[0] = v;
+}
+
+template <int V>
+__global__ void __launch_bounds__(1024)
+limb_argmax_kernel(const float* __restrict__ head, int* __restrict__ out_arg, int C, int e_chan0, int S,
+                   int ncell, int Q, int NS, int E) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* s_val = reinterpret_cast<float*>(smem);                 // [NS][ncell]
+    int* s_idx = reinterpret_cast<int*>(smem + sizeof(float) * NS * ncell);
+
+    const int edge = blockIdx.x, b = blockIdx.y;
+    const int t = threadIdx.x;
+    const int q = t % Q, r = t / Q;
+    const float* base = head + ((size_t)b * C + e_chan0 + (size_t)edge * S) * ncell;
+    using vec = typename VecT<V>::type;
+
+    if (r < NS) {
+        float best[V];
+        int bidx[V];
+#pragma unroll
+        for (int i = 0; i < V; ++i) { best[i] = -INFINITY; bidx[i] = 0x7fffffff; }
+        if (r < S) {
+            float a[V];
+            vec_to_arr<V>(*reinterpret_cast<const vec*>(base + (size_t)r * ncell + V * q), a);
+#pragma unroll
+            for (int i = 0; i < V; ++i) { best[i] = a[i]; bidx[i] = r; }
+        }
+#pragma unroll 8
+        for (int s = r + NS; s < S; s += NS) {
+            float a[V];
+            vec_to_arr<V>(*reinterpret_cast<const vec*>(base + (size_t)s * ncell + V * q), a);
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+                if (a[i] > best[i]) { best[i] = a[i]; bidx[i] = s; }   // strict: first max within a slice
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            s_val[r * ncell + V * q + i] = best[i];
+            s_idx[r * ncell + V * q + i] = bidx[i];
+        }
+    }
+    __syncthreads();
+    for (int cell = t; cell < ncell; cell += blockDim.x) {
+        float bv = s_val[cell];
+        int bi = s_idx[cell];
+        for (int rr = 1; rr < NS; ++rr) {
+            float v = s_val[rr * ncell + cell];
+            int i = s_idx[rr * ncell + cell];
+            if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }     // lowest s wins ties
+        }
+        out_arg[((size_t)b * E + edge) * ncell + cell] = bi;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Shared pieces of the per-image parse and the standalone NMS.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float box_area(const float4& b) {       // (ymin,xmin,ymax,xmax)
+    return (b.z - b.x) * (b.w - b.y);                               // datatest.py:141
+}
+
+// iou(b_i, b_j) >= thr with the reference's operation order (datatest.py:145-150).
+__device__ __forceinline__ bool iou_ge(const float4& bi, float ai, const float4& bj, float aj, float thr) {
+    float tl0 = fmaxf(bi.x, bj.x), tl1 = fmaxf(bi.y, bj.y);
+    float br0 = fminf(bi.z, bj.z), br1 = fminf(bi.w, bj.w);
+    float inter = ((br0 - tl0) * (br1 - tl1)) * ((tl0 < br0 && tl1 < br1) ? 1.0f : 0.0f);
+    float iou = inter / ((ai + aj) - inter);
+    return iou >= thr;
+}
+
+// Block-wide exclusive prefix of a per-thread flag (threads in row-major order). Returns the
+// position of this thread among the flagged ones and writes the total to *total (LDS).
+__device__ __forceinline__ int block_compact(bool flag, int* s_wave_cnt, int* total) {
+    const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave, nw = blockDim.x / kWave;
+    unsigned long long m = __ballot(flag);
+    int prefix = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) s_wave_cnt[wid] = __popcll(m);
+    __syncthreads();
+    int off = 0, tot = 0;
+    for (int w = 0; w < nw; ++w) {
+        int c = s_wave_cnt[w];
+        if (w < wid) off += c;
+        tot += c;
+    }
+    if (threadIdx.x == 0) *total = tot;
+    __syncthreads();
+    return off + prefix;
+}
+
+// Steps shared by parse and nms, operating on n boxes already in sorted (priority) order.
+//   s_box/s_area [n], s_mask [n][nw] scratch, s_sel [n] out (sorted positions kept, in order), *s_nsel out.
+__device__ __forceinline__ void greedy_nms(int n, int nwords, const float4* s_box, const float* s_area,
+                                           unsigned long long* s_mask, int* s_sel, int* s_nsel, float thr,
+                                           int limit) {
+    const int t = threadIdx.x;
+    // pairwise suppression bits: row i holds, for every higher-priority j < i, [iou(i,j) >= thr]
+    for (int i = t; i < n; i += blockDim.x) {
+        const float4 bi = s_box[i];
+        const float ai = s_area[i];
+        for (int w = 0; w < nwords; ++w) {
+            unsigned long long bits = 0ull;
+            const int j0 = w * 64;
+            const int j1 = min(j0 + 64, i);
+            for (int j = j0; j < j1; ++j) {
+                if (iou_ge(bi, ai, s_box[j], s_area[j], thr)) bits |= (1ull << (j - j0));
+            }
+            s_mask[(size_t)i * nwords + w] = bits;
+        }
+    }
+    __syncthreads();
+    // one wave resolves the greedy order: lane w owns keep-word w
+    if (t < kWave) {
+        unsigned long long keep = 0ull;
+        int nsel = 0;
+        for (int i = 0; i < n; ++i) {
+            unsigned long long m = (t < nwords) ? (s_mask[(size_t)i * nwords + t] & keep) : 0ull;
+            if (__ballot(m != 0ull) == 0ull) {
+                if (t == (i >> 6)) keep |= (1ull << (i & 63));
+                if (t == 0) s_sel[nsel] = i;
+                ++nsel;
+                if (limit > 0 && nsel >= limit) break;
+            }
+        }
+        if (t == 0) *s_nsel = nsel;
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------
+// Kernel 2: per-image parse.  One workgroup per image, blockDim = 64*ceil(ncell/64).
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024)
+parse_kernel(DecodeParams p, const float* __restrict__ head, const int* __restrict__ argmap,
+             int* __restrict__ out_count, int* __restrict__ out_kp_cell, int* __restrict__ out_limb_arg,
+             float* __restrict__ out_bbox, float* __restrict__ out_score) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const ppn_decode_cfg& c = p.c;
+    const int ncell = p.ncell, K = c.K, E = c.E, W = c.W, H = c.H;
+    const int nwords = blockDim.x / kWave;
+    const int t = threadIdx.x, b = blockIdx.x;
+
+    // LDS carve (all offsets multiples of 16)
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { char* ptr = smem + off; off += (bytes + 15) & ~size_t(15); return ptr; };
+    float4* s_box = reinterpret_cast<float4*>(carve(sizeof(float4) * ncell));
+    unsigned long long* s_key = reinterpret_cast<unsigned long long*>(carve(8 * ncell));
+    unsigned long long* s_mask = reinterpret_cast<unsigned long long*>(carve(8 * (size_t)ncell * nwords));
+    float* s_area = reinterpret_cast<float*>(carve(4 * ncell));
+    int* s_cell = reinterpret_cast<int*>(carve(4 * ncell));          // sorted position -> cell
+    int* s_sel = reinterpret_cast<int*>(carve(4 * ncell));
+    unsigned short* s_kp = reinterpret_cast<unsigned short*>(carve(2 * (size_t)ncell * K));
+    unsigned short* s_la = reinterpret_cast<unsigned short*>(carve(2 * (size_t)ncell * E));
+    int* s_misc = reinterpret_cast<int*>(carve(4 * (32 + 4)));      // wave counts [32], n, nsel, nkept
+
+    const float* img = head + (size_t)b * p.C * ncell;
+    const float gridW = (float)(c.inW / W), gridH = (float)(c.inH / H);
+    const float inW = (float)c.inW, inH = (float)c.inH;
+
+    auto delta_at = [&](int k, int cell) -> float {                   // rt_test.py:130
+        return img[(size_t)k * ncell + cell] * img[(size_t)(K + k) * ncell + cell];
+    };
+    auto bbox_at = [&](int k, int cell) -> float4 {                   // datatest.py:63-84
+        const float x = img[(size_t)(2 * K + k) * ncell + cell], y = img[(size_t)(3 * K + k) * ncell + cell];
+        const float w = img[(size_t)(4 * K + k) * ncell + cell], h = img[(size_t)(5 * K + k) * ncell + cell];
+        const float X = (float)(cell % W), Y = (float)(cell / W);
+        const float rx = (x + X) * gridW, ry = (y + Y) * gridH;
+        const float rw = inW * w, rh = inH * h;
+        float4 r;
+        r.x = ry - rh / 2.0f;   // ymin
+        r.y = rx - rw / 2.0f;   // xmin
+        r.z = ry + rh / 2.0f;   // ymax
+        r.w = rx + rw / 2.0f;   // xmax
+        return r;
+    };
+
+    // 1. candidates: delta[0] > thr, row-major (datatest.py:89)
+    float d0 = 0.0f;
+    bool is_c = false;
+    if (t < ncell) {
+        d0 = delta_at(0, t);
+        is_c = d0 > c.det_thr;
+    }
+    const int pos = block_compact(is_c, s_misc, s_misc + 32);
+    const int n = s_misc[32];
+    if (is_c) {
+        // ascending key == descending score, ties by ascending cell (documented tie rule)
+        s_key[pos] = ((unsigned long long)(~__float_as_uint(d0)) << 32) | (unsigned)t;
+    }
+    __syncthreads();
+    // 2. rank sort; boxes/areas stored in priority order
+    if (is_c) {
+        const unsigned long long my = s_key[pos];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) rank += (s_key[j] < my) ? 1 : 0;
+        const float4 bb = bbox_at(0, t);
+        s_box[rank] = bb;
+        s_area[rank] = box_area(bb);
+        s_cell[rank] = t;
+    }
+    __syncthreads();
+    // 3./4. greedy NMS on the root boxes (datatest.py:134-160)
+    greedy_nms(n, nwords, s_box, s_area, s_mask, s_sel, s_misc + 33, c.nms_thr, 0);
+    const int nsel = s_misc[33];
+
+    // 5. one lane per surviving root: tree walk through the arg-max map (datatest.py:103-127)
+    bool keep_h = false;
+    const unsigned short NONE = 0xFFFFu;
+    if (t < nsel) {
+        unsigned short* kp = s_kp + (size_t)t * K;
+        unsigned short* la = s_la + (size_t)t * E;
+        for (int k = 0; k < K; ++k) kp[k] = NONE;
+        for (int e = 0; e < E; ++e) la[e] = NONE;
+        kp[0] = (unsigned short)s_cell[s_sel[t]];
+        int found = 0;
+        for (int oi = 0; oi < E; ++oi) {
+            const int e = c.edge_order[oi];
+            const int s = c.edge_src[e], d = c.edge_dst[e];
+            const unsigned short cs = kp[s];
+            if (cs == NONE) continue;                                 // parent chain broke earlier
+            const int am = argmap[((size_t)b * E + e) * ncell + cs];
+            la[e] = (unsigned short)am;
+            const int jh = (int)cs / W + am / c.sW - c.sH / 2;
+            const int jw = (int)cs % W + am % c.sW - c.sW / 2;
+            if (jh < 0 || jw < 0 || jh >= H || jw >= W) continue;     // datatest.py:118
+            const int cd = jh * W + jw;
+            if (delta_at(d, cd) < c.det_thr) continue;                // datatest.py:121 (== passes)
+            kp[d] = (unsigned short)cd;
+            ++found;
+        }
+        keep_h = c.min_kp <= found;                                   // datatest.py:129
+    }
+    const int opos = block_compact(keep_h, s_misc, s_misc + 34);
+    const int nkept = s_misc[34];
+    if (t == 0) out_count[b] = nkept;
+    // 6. compact output rows
+    if (keep_h && opos < c.max_humans) {
+        const unsigned short* kp = s_kp + (size_t)t * K;
+        const unsigned short* la = s_la + (size_t)t * E;
+        const size_t row = (size_t)b * c.max_humans + opos;
+        for (int k = 0; k < K; ++k) {
+            const unsigned short cell = kp[k];
+            float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
+            float sc = 0.f;
+            if (cell != NONE) {
+                bb = bbox_at(k, cell);
+                sc = delta_at(k, cell);
+            }
+            out_kp_cell[row * K + k] = (cell == NONE) ? -1 : (int)cell;
+            reinterpret_cast<float4*>(out_bbox)[row * K + k] = bb;
+            out_score[row * K + k] = sc;
+        }
+        for (int e = 0; e < E; ++e) out_limb_arg[row * E + e] = (la[e] == NONE) ? -1 : (int)la[e];
+    }
+}
+
+size_t parse_lds_bytes(int ncell, int K, int E) {
+    const int nwords = (ncell + 63) / 64;
+    auto r16 = [](size_t x) { return (x + 15) & ~size_t(15); };
+    return r16(16 * (size_t)ncell) + r16(8 * (size_t)ncell) + r16(8 * (size_t)ncell * nwords) +
+           r16(4 * (size_t)ncell) * 3 + r16(2 * (size_t)ncell * K) + r16(2 * (size_t)ncell * E) + r16(4 * 36);
+}
+
+// ------------------------------------------------------------------------------------------
+// Standalone NMS (datatest.py:134-160) -- one workgroup.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024)
+nms_kernel(const float* __restrict__ bbox, const float* __restrict__ score, int n, float thr, int limit,
+           int* __restrict__ out_sel, int* __restrict__ out_count) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nwords = (n + 63) / 64;
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { char* ptr = smem + off; off += (bytes + 15) & ~size_t(15); return ptr; };
+    float4* s_box = reinterpret_cast<float4*>(carve(sizeof(float4) * n));
+    unsigned long long* s_key = reinterpret_cast<unsigned long long*>(carve(8 * n));
+    unsigned long long* s_mask = reinterpret_cast<unsigned long long*>(carve(8 * (size_t)n * nwords));
+    float* s_area = reinterpret_cast<float*>(carve(4 * n));
+    int* s_orig = reinterpret_cast<int*>(carve(4 * n));
+    int* s_sel = reinterpret_cast<int*>(carve(4 * n));
+    int* s_misc = reinterpret_cast<int*>(carve(16));
+    const int t = threadIdx.x;
+    if (t < n) {
+        // order = score.argsort()[::-1] (descending; ties by ascending index); input order without score
+        // monotonic float->uint map so that an ascending key means a descending float value
+        unsigned k = 0u;
+        if (score) {
+            const unsigned u = __float_as_uint(score[t]);
+            const unsigned mono = (u & 0x80000000u) ? ~u : (u | 0x80000000u);   // monotonic float->uint
+            k = ~mono;
+        }
+        s_key[t] = ((unsigned long long)k << 32) | (unsigned)t;
+    }
+    __syncthreads();
+    if (t < n) {
+        const unsigned long long my = s_key[t];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) rank += (s_key[j] < my) ? 1 : 0;
+        const float4 bb = reinterpret_cast<const float4*>(bbox)[t];
+        s_box[rank] = bb;
+        s_area[rank] = box_area(bb);
+        s_orig[rank] = t;
+    }
+    __syncthreads();
+    greedy_nms(n, nwords, s_box, s_area, s_mask, s_sel, s_misc, thr, limit);
+    const int nsel = s_misc[0];
+    if (t == 0) *out_count = nsel;
+    if (t < nsel) out_sel[t] = s_orig[s_sel[t]];
+}
+
+size_t nms_lds_bytes(int n) {
+    const int nwords = (n + 63) / 64;
+    auto r16 = [](size_t x) { return (x + 15) & ~size_t(15); };
+    return r16(16 * (size_t)n) + r16(8 * (size_t)n) + r16(8 * (size_t)n * nwords) + r16(4 * (size_t)n) * 3 + 16;
+}
+
+int check_cfg(const ppn_decode_cfg* c) {
+    if (!c) return ppn::fail(PPN_E_INVALID, "decode cfg is NULL");
+    if (c->K < 1 || c->K > PPN_MAX_KP || c->E < 0 || c->E > PPN_MAX_EDGES)
+        return ppn::fail(PPN_E_INVALID, "K=%d / E=%d out of range", c->K, c->E);
+    if (c->H < 1 || c->W < 1 || c->sH < 1 || c->sW < 1 || c->inH < c->H || c->inW < c->W)
+        return ppn::fail(PPN_E_INVALID, "bad grid geometry H=%d W=%d sH=%d sW=%d", c->H, c->W, c->sH, c->sW);
+    if (c->H * c->W > 0xFFFE) return ppn::fail(PPN_E_UNSUPPORTED, "grid of %d cells is too large", c->H * c->W);
+    for (int e = 0; e < c->E; ++e) {
+        if (c->edge_src[e] < 0 || c->edge_src[e] >= c->K || c->edge_dst[e] < 0 || c->edge_dst[e] >= c->K ||
+            c->edge_order[e] < 0 || c->edge_order[e] >= c->E)
+            return ppn::fail(PPN_E_INVALID, "skeleton table entry %d out of range", e);
+    }
+    return PPN_OK;
+}
+
+}  // namespace
+
+extern "C" size_t ppn_decode_workspace_bytes(const ppn_decode_cfg* cfg, int32_t batch) {
+    if (!cfg || batch < 0) return 0;
+    return (size_t)batch * cfg->E * cfg->H * cfg->W * sizeof(int32_t);
+}
+
+extern "C" int ppn_limb_argmax(const ppn_decode_cfg* cfg, const float* head, int32_t batch, int32_t* out_arg,
+                               void* stream) {
+    if (int rc = check_cfg(cfg)) return rc;
+    if (batch == 0 || cfg->E == 0) return PPN_OK;
+    if (!head || !out_arg || batch < 0) return ppn::fail(PPN_E_INVALID, "ppn_limb_argmax: NULL pointer or batch<0");
+    const int ncell = cfg->H * cfg->W, S = cfg->sH * cfg->sW;
+    const int C = 6 * cfg->K + cfg->E * S;
+    const int V = (ncell % 4 == 0 && (reinterpret_cast<uintptr_t>(head) % 16 == 0)) ? 4 : 1;
+    const int Q = ncell / V;
+    if (Q > 1024) return ppn::fail(PPN_E_UNSUPPORTED, "grid of %d cells is too large for ppn_limb_argmax", ncell);
+    int NS = 576 / Q;
+    if (NS < 1) NS = 1;
+    if (NS > 32) NS = 32;
+    if (NS > S) NS = S;
+    int threads = ((NS * Q + 63) / 64) * 64;
+    if (threads > 1024) { NS = 1024 / Q; threads = ((NS * Q + 63) / 64) * 64; }
+    const size_t lds = (size_t)NS * ncell * 8;
+    if (lds > 160 * 1024) return ppn::fail(PPN_E_UNSUPPORTED, "limb_argmax LDS %zu too large", lds);
+    dim3 grid(cfg->E, batch);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (V == 4) {
+        PPN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(limb_argmax_kernel<4>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(limb_argmax_kernel<4>, grid, dim3(threads), lds, st, head, out_arg, C, 6 * cfg->K, S,
+                           ncell, Q, NS, cfg->E);
+    } else {
+        PPN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(limb_argmax_kernel<1>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(limb_argmax_kernel<1>, grid, dim3(threads), lds, st, head, out_arg, C, 6 * cfg->K, S,
+                           ncell, Q, NS, cfg->E);
+    }
+    PPN_LAUNCH_CHECK();
+    return PPN_OK;
+}
+
+extern "C" int ppn_decode(const ppn_decode_cfg* cfg, const float* head, int32_t batch, void* workspace,
+                          int32_t* out_count, int32_t* out_kp_cell, int32_t* out_limb_arg, float* out_bbox,
+                          float* out_score, void* stream) {
+    if (int rc = check_cfg(cfg)) return rc;
+    if (batch < 0) return ppn::fail(PPN_E_INVALID, "ppn_decode: batch < 0");
+    if (batch == 0) return PPN_OK;
+    if (!head || !workspace || !out_count || !out_kp_cell || !out_limb_arg || !out_bbox || !out_score)
+        return ppn::fail(PPN_E_INVALID, "ppn_decode: NULL pointer");
+    if (cfg->max_humans < 1) return ppn::fail(PPN_E_INVALID, "ppn_decode: max_humans < 1");
+    if (reinterpret_cast<uintptr_t>(out_bbox) % 16 != 0)
+        return ppn::fail(PPN_E_INVALID, "ppn_decode: out_bbox must be 16-byte aligned");
+    const int ncell = cfg->H * cfg->W;
+    const size_t lds = parse_lds_bytes(ncell, cfg->K, cfg->E);
+    if (ncell > 1024 || lds > 160 * 1024)
+        return ppn::fail(PPN_E_UNSUPPORTED, "grid of %d cells needs %zu B of LDS (max 163840)", ncell, lds);
+    int32_t* argmap = static_cast<int32_t*>(workspace);
+    if (int rc = ppn_limb_argmax(cfg, head, batch, argmap, stream)) return rc;
+    DecodeParams p;
+    p.c = *cfg;
+    p.ncell = ncell;
+    p.S = cfg->sH * cfg->sW;
+    p.C = 6 * cfg->K + cfg->E * p.S;
+    const int threads = ((ncell + 63) / 64) * 64;
+    PPN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(parse_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(parse_kernel, dim3(batch), dim3(threads), lds, static_cast<hipStream_t>(stream), p, head,
+                       argmap, out_count, out_kp_cell, out_limb_arg, out_bbox, out_score);
+    PPN_LAUNCH_CHECK();
+    return PPN_OK;
+}
+
+extern "C" int ppn_nms(const float* bbox, const float* score, int32_t n, float thresh, int32_t limit,
+                       int32_t* out_sel, int32_t* out_count, void* stream) {
+    if (n < 0 || !out_count) return ppn::fail(PPN_E_INVALID, "ppn_nms: bad arguments");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (n == 0) {                                                     // datatest.py:135-136
+        PPN_HIP_CHECK(hipMemsetAsync(out_count, 0, sizeof(int32_t), st));
+        return PPN_OK;
+    }
+    if (!bbox || !out_sel) return ppn::fail(PPN_E_INVALID, "ppn_nms: NULL pointer");
+    if (reinterpret_cast<uintptr_t>(bbox) % 16 != 0) return ppn::fail(PPN_E_INVALID, "ppn_nms: bbox must be 16-byte aligned");
+    const size_t lds = nms_lds_bytes(n);
+    if (n > 1024 || lds > 160 * 1024)
+        return ppn::fail(PPN_E_UNSUPPORTED, "ppn_nms: n=%d needs %zu B of LDS (max 163840)", n, lds);
+    const int threads = ((n + 63) / 64) * 64;
+    PPN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(nms_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(nms_kernel, dim3(1), dim3(threads), lds, st, bbox, score, n, thresh, limit, out_sel,
+                       out_count);
+    PPN_LAUNCH_CHECK();
+    return PPN_OK;
+}

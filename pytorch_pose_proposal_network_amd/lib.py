@@ -1,0 +1,107 @@
+"""ctypes binding of libppn.so (include/ppn.h).  Fails loudly when the library is missing:
+there is no CPU fallback on the product path."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libppn.so")
+
+PPN_MAX_EDGES = 32
+PPN_MAX_KP = 32
+PPN_F32, PPN_BF16 = 0, 1
+
+
+class DecodeCfg(C.Structure):
+    _fields_ = [
+        ("K", C.c_int32), ("E", C.c_int32), ("sH", C.c_int32), ("sW", C.c_int32),
+        ("H", C.c_int32), ("W", C.c_int32), ("inH", C.c_int32), ("inW", C.c_int32),
+        ("det_thr", C.c_float), ("nms_thr", C.c_float), ("min_kp", C.c_int32), ("max_humans", C.c_int32),
+        ("edge_src", C.c_int32 * PPN_MAX_EDGES), ("edge_dst", C.c_int32 * PPN_MAX_EDGES),
+        ("edge_order", C.c_int32 * PPN_MAX_EDGES),
+    ]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [
+        ("dtype", C.c_int32), ("batch", C.c_int32), ("in_h", C.c_int32), ("in_w", C.c_int32), ("cin", C.c_int32),
+        ("out_h", C.c_int32), ("out_w", C.c_int32), ("cout", C.c_int32),
+        ("ksize", C.c_int32), ("stride", C.c_int32), ("dilation", C.c_int32), ("pad", C.c_int32),
+        ("k_total", C.c_int32), ("cout_pad", C.c_int32), ("act1", C.c_int32), ("act2", C.c_int32),
+        ("out_nchw_f32", C.c_int32),
+        ("src", C.c_void_p), ("weight", C.c_void_p), ("scale1", C.c_void_p), ("shift1", C.c_void_p),
+        ("residual", C.c_void_p), ("out_raw", C.c_void_p), ("scale2", C.c_void_p), ("shift2", C.c_void_p),
+        ("out_act", C.c_void_p), ("zero_page", C.c_void_p),
+    ]
+
+
+class PPNError(RuntimeError):
+    pass
+
+
+_lib = None
+
+_SIGNATURES = {
+    "ppn_last_error": (C.c_char_p, []),
+    "ppn_version": (C.c_int, []),
+    "ppn_decode_workspace_bytes": (C.c_size_t, [C.POINTER(DecodeCfg), C.c_int32]),
+    "ppn_decode": (C.c_int, [C.POINTER(DecodeCfg), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ppn_limb_argmax": (C.c_int, [C.POINTER(DecodeCfg), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "ppn_nms": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_int32, C.c_void_p, C.c_void_p,
+                          C.c_void_p]),
+    "ppn_conv_tiling": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32),
+                                  C.POINTER(C.c_int32)]),
+    "ppn_conv2d_fused": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
+    "ppn_stem7x7": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32] +
+                    [C.c_void_p] * 7 + [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ppn_plan_create": (C.c_int, [C.POINTER(C.c_void_p)]),
+    "ppn_plan_add_conv": (C.c_int, [C.c_void_p, C.POINTER(ConvDesc)]),
+    "ppn_plan_add_stem": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32] +
+                          [C.c_void_p] * 7 + [C.c_int32, C.c_void_p, C.c_void_p]),
+    "ppn_plan_run": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ppn_plan_run_timed": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.c_int32]),
+    "ppn_plan_size": (C.c_int, [C.c_void_p]),
+    "ppn_plan_kernel_name": (C.c_char_p, [C.c_void_p, C.c_int32]),
+    "ppn_plan_destroy": (C.c_int, [C.c_void_p]),
+    "ppn_pack_weight": (C.c_int, [C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                  C.c_void_p, C.c_void_p]),
+}
+
+EXPORTS = tuple(_SIGNATURES)
+
+
+def load():
+    """Load libppn.so (built by pytorch_pose_proposal_network_amd.build); raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PPNError(
+            f"{LIB_PATH} is missing: build it with `python -m pytorch_pose_proposal_network_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    missing = []
+    for name, (res, args) in _SIGNATURES.items():
+        if not hasattr(lib, name):
+            missing.append(name)
+            continue
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if missing and not os.environ.get("PPN_ALLOW_PARTIAL"):
+        raise PPNError(f"{LIB_PATH} is stale, missing symbols {missing}: rebuild it")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().ppn_last_error()
+        raise PPNError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+
+def current_stream_ptr() -> int:
+    import torch
+    return torch.cuda.current_stream().cuda_stream
