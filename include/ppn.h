@@ -129,14 +129,15 @@ int ppn_conv2d_fused(const ppn_conv_desc* d, void* stream);
 /*
  * First layer (drn.py:123-128 layer0: 7x7 conv 3->16, BN, ReLU) with the input normalisation of
  * rt_test.py:97-101 / aug.py:149-153 fused into the load.
- *   src_u8   u8  [B,H,W,3]  RGB frame (src_is_u8=1)  -> (x-mean_c)/std_c applied on the fly, or
- *   src_f32  f32 [B,3,H,W]  already normalised NCHW input, the model.forward() argument (src_is_u8=0)
- *   weight   f32 [16,3,7,7] (reference layout), scale/shift f32[16] folded BN
+ *   src      u8  [B,H,W,3]  RGB frame (src_is_u8=1): (x-mean_c)/std_c applied on the fly, or
+ *            f32 [B,3,H,W]  already normalised NCHW input, the model.forward() argument (src_is_u8=0)
+ *   weight   f32 [16,3,7,7] (reference layout, device), scale/shift f32[16] folded BN (device)
+ *   mean,std_ HOST pointers to 3 floats (read at call time; may be NULL when src_is_u8=0)
  *   out      NHWC [B,H,W,16] dtype
  */
 int ppn_stem7x7(int32_t dtype, int32_t src_is_u8, const void* src, int32_t batch, int32_t h, int32_t w,
                 const float* weight, const float* scale, const float* shift, const float* mean, const float* std_,
-                const float* scale2, const float* shift2, int32_t act2, void* out_raw, void* out_act, void* stream);
+                void* out, void* stream);
 
 /* A recorded sequence of launches (one forward pass): replayed in order on `stream`. */
 typedef struct ppn_plan ppn_plan;
@@ -144,8 +145,9 @@ int ppn_plan_create(ppn_plan** out);
 int ppn_plan_add_conv(ppn_plan* p, const ppn_conv_desc* d);
 int ppn_plan_add_stem(ppn_plan* p, int32_t dtype, int32_t src_is_u8, const void* src, int32_t batch, int32_t h,
                       int32_t w, const float* weight, const float* scale, const float* shift, const float* mean,
-                      const float* std_, const float* scale2, const float* shift2, int32_t act2, void* out_raw,
-                      void* out_act);
+                      const float* std_, void* out);
+/* Re-point the first layer's input (same shape/dtype as at ppn_plan_add_stem) before a run. */
+int ppn_plan_set_input(ppn_plan* p, const void* src);
 int ppn_plan_run(ppn_plan* p, void* stream);
 /* Same as ppn_plan_run but brackets every launch with HIP events on `stream`; ms[i] = duration of launch i. */
 int ppn_plan_run_timed(ppn_plan* p, void* stream, float* ms, int32_t n_ms);

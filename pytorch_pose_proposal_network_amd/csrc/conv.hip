@@ -1,0 +1,521 @@
+// Fused implicit-GEMM convolution for gfx950 (CDNA4, wave64, MFMA) -- the conv/BN/activation stack of
+// PoseProposalNet.forward (model.py:104-136; drn.py:42-57, 77-97, 192-202).
+//
+// GEMM view (per launch):   D[channel][pixel] = sum_k  Wp[channel][k] * X[pixel][k]
+//   k = (ky*ksize + kx)*Cin + ci,   pixel = (b*Ho + oy)*Wo + ox,   activations NHWC, weights packed
+//   [cout_pad][k_total] so BOTH operands are K-contiguous 128-byte rows.
+//
+// Data movement: every K step a workgroup stages a BC x 128 B weight tile and a BP x 128 B activation
+// tile into LDS with direct-to-LDS loads (global_load_lds_dwordx4; the per-lane SOURCE address does the
+// im2col gather; padded taps read a device zero page), double buffered, one barrier per step.  LDS rows
+// are XOR-swizzled on the source side (chunk ^= (row>>1)&7) so the ds_read_b128 fragment reads are
+// bank-conflict free.  MFMA: v_mfma_f32_16x16x32_bf16 (bf16 mode) or v_mfma_f32_16x16x4_f32 (exact
+// f32 mode used for the 1e-4 parity gate).  A = weights (rows = channels), B = activations (cols =
+// pixels), so each lane ends with 4 consecutive channels of one pixel.
+//
+// Epilogue (through an LDS f32 tile so that global stores are 16 B per lane and coalesced):
+//   v = act1(acc*scale1 + shift1) (+ residual);  out_raw = v;  out_act = act2(v*scale2 + shift2)
+// which covers conv->BN->ReLU (drn.py:192-202), the pre-activation BasicBlock (drn.py:42-57: the
+// second output is the NEXT block's relu(bn1(x)), so zero padding happens after BN/ReLU as in the
+// reference), Bottleneck (drn.py:77-97) and the PPN neck/head incl. bias + sigmoid (model.py:113-134).
+#include <hip/hip_bf16.h>
+
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+
+struct ConvKArgs {
+    const char* src;
+    const char* wgt;
+    const float* scale1;
+    const float* shift1;
+    const char* residual;
+    char* out_raw;
+    const float* scale2;
+    const float* shift2;
+    char* out_act;
+    const char* zero;
+    int B, H, W, Cin, Ho, Wo, Cout, ks, stride, dil, pad;
+    int Ktot;      // padded GEMM depth (multiple of BK)
+    int M;         // B*Ho*Wo
+    int HoWo;
+    int act1, act2, nchw;
+    int log2Cin;
+    int n_ctiles, n_ptiles;
+};
+
+template <typename T>
+struct Elem;
+template <>
+struct Elem<float> {
+    static constexpr int EPC = 4;  // elements per 16-byte chunk
+};
+template <>
+struct Elem<__bf16> {
+    static constexpr int EPC = 8;
+};
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    switch (act) {
+        case PPN_ACT_RELU: return v > 0.f ? v : 0.f;
+        case PPN_ACT_LRELU: return v > 0.f ? v : v * 0.1f;      // nn.LeakyReLU(0.1), model.py:88
+        case PPN_ACT_SIGMOID: return 1.0f / (1.0f + __expf(-v));
+        default: return v;
+    }
+}
+
+__device__ __forceinline__ void glds16(const char* gptr, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)gptr,
+                                     (void __attribute__((address_space(3)))*)lds_wave_base, 16, 0, 0);
+}
+
+// One K-substep (4 chunks = 128 B/4 of a row): acc += Wfrag x Xfrag
+__device__ __forceinline__ void mma_step(f32x4& acc, const f32x4& wf, const f32x4& xf, float*) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf.x, xf.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf.y, xf.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf.z, xf.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf.w, xf.w, acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma_step(f32x4& acc, const f32x4& wf, const f32x4& xf, __bf16*) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf), __builtin_bit_cast(bf16x8, xf),
+                                                  acc, 0, 0, 0);
+}
+
+template <typename T>
+__device__ __forceinline__ void load8(const char* p, float* v);
+template <>
+__device__ __forceinline__ void load8<float>(const char* p, float* v) {
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 16);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+template <>
+__device__ __forceinline__ void load8<__bf16>(const char* p, float* v) {
+    const uint4 a = *reinterpret_cast<const uint4*>(p);
+    const unsigned u[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        v[2 * i] = __uint_as_float(u[i] << 16);
+        v[2 * i + 1] = __uint_as_float(u[i] & 0xffff0000u);
+    }
+}
+template <typename T>
+__device__ __forceinline__ void store8(char* p, const float* v);
+template <>
+__device__ __forceinline__ void store8<float>(char* p, const float* v) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(p + 16) = make_float4(v[4], v[5], v[6], v[7]);
+}
+template <>
+__device__ __forceinline__ void store8<__bf16>(char* p, const float* v) {
+    bf16x8 o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (__bf16)v[i];                 // RNE, v_cvt_pk_bf16_f32
+    *reinterpret_cast<bf16x8*>(p) = o;
+}
+
+// BP x BC output tile per 256-thread workgroup; WP x WC waves; SMALLC: Cin < BK (several taps per K step).
+template <typename T, int BP, int BC, int WP, int WC, bool SMALLC>
+__global__ void __launch_bounds__(256) conv_igemm_kernel(ConvKArgs a) {
+    constexpr int EPC = Elem<T>::EPC;
+    constexpr int BK = 8 * EPC;                    // 128-byte rows
+    constexpr int ES = sizeof(T);
+    constexpr int NXI = BP / 32;                   // activation-tile load instructions per thread
+    constexpr int NWI = (BC + 31) / 32;            // weight-tile load instructions per thread (some waves idle if BC<32)
+    constexpr int TP = BP / WP / 16, TC = BC / WC / 16;
+    constexpr int STAGE = (BP + BC) * 128;         // bytes per stage buffer
+    static_assert(WP * WC == 4, "4 waves");
+    static_assert(TP >= 1 && TC >= 1, "tile too small");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wp = wave / WC, wc = wave % WC;
+
+    // XCD-aware tile order: consecutive logical tiles (same pixel tile, neighbouring pixel tiles) share an L2
+    int ptile, ctile;
+    {
+        const int nb = gridDim.x, id = blockIdx.x;
+        const int xcd = id & 7, loc = id >> 3, q = nb >> 3, r = nb & 7;
+        const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+        ptile = logical / a.n_ctiles;
+        ctile = logical - ptile * a.n_ctiles;
+    }
+    const int m0 = ptile * BP, c0 = ctile * BC;
+
+    // ---- per-lane loader state -------------------------------------------------------------
+    // LDS slot (row, s) holds global chunk s ^ ((row>>1)&7); for this lane the xor term is constant
+    const int lrow = lane >> 3;                                      // row inside an 8-row wave-instruction
+    const int chunk = (lane & 7) ^ (((lane >> 4) & 3) | ((wave & 1) << 2));
+    const int ntaps = a.ks * a.ks;
+    int xbase[NXI];
+    unsigned xmask[NXI];
+#pragma unroll
+    for (int j = 0; j < NXI; ++j) {
+        const int row = (j * 4 + wave) * 8 + lrow;
+        const int m = m0 + row;
+        const bool vm = m < a.M;
+        const int mm = vm ? m : 0;
+        const int b = mm / a.HoWo, rem = mm - b * a.HoWo;
+        const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+        const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
+        xbase[j] = ((b * a.H + iy0) * a.W + ix0) * a.Cin;
+        unsigned mk = 0;
+        for (int t = 0; t < ntaps; ++t) {
+            const int dy = t / a.ks, dx = t - dy * a.ks;
+            const int iy = iy0 + dy * a.dil, ix = ix0 + dx * a.dil;
+            if (vm && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) mk |= (1u << t);
+        }
+        xmask[j] = mk;
+    }
+    const char* wptr[NWI];
+#pragma unroll
+    for (int j = 0; j < NWI; ++j) {
+        const int row = (j * 4 + wave) * 8 + lrow;
+        wptr[j] = a.wgt + ((size_t)(c0 + row) * a.Ktot + chunk * EPC) * ES;
+    }
+    int* s_tapoff = reinterpret_cast<int*>(smem + 2 * STAGE);        // SMALLC only: [32]
+    if (SMALLC) {
+        if (tid < 32) {
+            const int dy = tid / a.ks, dx = tid - dy * a.ks;
+            s_tapoff[tid] = (dy * a.dil * a.W + dx * a.dil) * a.Cin;
+        }
+        __syncthreads();
+    }
+
+    const int nsteps = a.Ktot / BK;
+    // uniform-tap iteration state (Cin % BK == 0): the whole K step lies inside one tap
+    int u_tap = 0, u_ci0 = 0, u_dy = 0, u_dx = 0;
+
+    auto issue_loads = [&](int step, int buf) {
+        char* xs = smem + buf * STAGE;
+        char* ws = xs + BP * 128;
+        if (!SMALLC) {
+            const int tapoff = (u_dy * a.dil * a.W + u_dx * a.dil) * a.Cin + u_ci0 + chunk * EPC;
+#pragma unroll
+            for (int j = 0; j < NXI; ++j) {
+                const bool ok = (xmask[j] >> u_tap) & 1u;
+                const char* g = ok ? a.src + (ptrdiff_t)(xbase[j] + tapoff) * ES : a.zero;
+                glds16(g, xs + (j * 4 + wave) * 1024);
+            }
+            u_ci0 += BK;
+            if (u_ci0 >= a.Cin) {
+                u_ci0 = 0; ++u_tap; ++u_dx;
+                if (u_dx == a.ks) { u_dx = 0; ++u_dy; }
+            }
+        } else {
+            const int k = step * BK + chunk * EPC;
+            const int tap = k >> a.log2Cin, ci = k & (a.Cin - 1);
+            const int toff = s_tapoff[tap & 31] + ci;
+#pragma unroll
+            for (int j = 0; j < NXI; ++j) {
+                const bool ok = (tap < ntaps) && ((xmask[j] >> (tap & 31)) & 1u);
+                const char* g = ok ? a.src + (ptrdiff_t)(xbase[j] + toff) * ES : a.zero;
+                glds16(g, xs + (j * 4 + wave) * 1024);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NWI; ++j) {
+            if ((j * 4 + wave) * 8 < BC) glds16(wptr[j] + (size_t)step * BK * ES, ws + (j * 4 + wave) * 1024);
+        }
+    };
+
+    // ---- per-lane fragment read offsets ------------------------------------------------------
+    const int frow = lane & 15, fq = lane >> 4;
+    const int fswz = (frow >> 1) & 7;
+    int foff[2];
+    foff[0] = frow * 128 + (((0 + fq) ^ fswz) << 4);
+    foff[1] = frow * 128 + (((4 + fq) ^ fswz) << 4);
+    const int x_tile_off = wp * (BP / WP) * 128;
+    const int w_tile_off = BP * 128 + wc * (BC / WC) * 128;
+
+    f32x4 acc[TC][TP];
+#pragma unroll
+    for (int i = 0; i < TC; ++i)
+#pragma unroll
+        for (int j = 0; j < TP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    issue_loads(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int s = 0; s < nsteps; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nsteps) issue_loads(s + 1, buf ^ 1);
+        const char* xs = smem + buf * STAGE + x_tile_off;
+        const char* ws = smem + buf * STAGE + w_tile_off;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            f32x4 wf[TC], xf[TP];
+#pragma unroll
+            for (int i = 0; i < TC; ++i) wf[i] = *reinterpret_cast<const f32x4*>(ws + i * 16 * 128 + foff[ks]);
+#pragma unroll
+            for (int j = 0; j < TP; ++j) xf[j] = *reinterpret_cast<const f32x4*>(xs + j * 16 * 128 + foff[ks]);
+#pragma unroll
+            for (int i = 0; i < TC; ++i)
+#pragma unroll
+                for (int j = 0; j < TP; ++j) mma_step(acc[i][j], wf[i], xf[j], (T*)nullptr);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // ---- epilogue ------------------------------------------------------------------------------
+    float* ct = reinterpret_cast<float*>(smem);
+    if (!a.nchw) {
+        constexpr int LD = BC + 4;                                   // [pixel][channel] f32
+#pragma unroll
+        for (int i = 0; i < TC; ++i)
+#pragma unroll
+            for (int j = 0; j < TP; ++j) {
+                const int px = wp * (BP / WP) + j * 16 + frow;
+                const int ch = wc * (BC / WC) + i * 16 + 4 * fq;
+                *reinterpret_cast<f32x4*>(ct + px * LD + ch) = acc[i][j];
+            }
+        __syncthreads();
+        constexpr int TPP = BC / 8;                                  // threads per pixel (8 channels each)
+        constexpr int PPP = 256 / TPP;                               // pixels per pass
+        const int cg = tid % TPP, prow = tid / TPP;
+        const int c = c0 + cg * 8;
+        if (c < a.Cout) {
+            float s1[8], b1[8], s2[8], b2[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                s1[i] = a.scale1 ? a.scale1[c + i] : 1.f;
+                b1[i] = a.shift1 ? a.shift1[c + i] : 0.f;
+                s2[i] = a.scale2 ? a.scale2[c + i] : 1.f;
+                b2[i] = a.shift2 ? a.shift2[c + i] : 0.f;
+            }
+            for (int pass = 0; pass < BP / PPP; ++pass) {
+                const int px = pass * PPP + prow;
+                const int m = m0 + px;
+                if (m >= a.M) break;
+                float v[8];
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(ct + px * LD + cg * 8);
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(ct + px * LD + cg * 8 + 4);
+                v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+                const size_t off = ((size_t)m * a.Cout + c) * ES;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = apply_act(v[i] * s1[i] + b1[i], a.act1);
+                if (a.residual) {
+                    float r[8];
+                    load8<T>(a.residual + off, r);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] += r[i];
+                }
+                if (a.out_raw) store8<T>(a.out_raw + off, v);
+                if (a.out_act) {
+                    float u[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) u[i] = apply_act(v[i] * s2[i] + b2[i], a.act2);
+                    store8<T>(a.out_act + off, u);
+                }
+            }
+        }
+    } else {
+        // head: f32 NCHW [B, Cout, Ho*Wo] (model.py:136), pixel-contiguous rows
+        constexpr int LD = BP + 4;                                   // [channel][pixel] f32
+#pragma unroll
+        for (int i = 0; i < TC; ++i)
+#pragma unroll
+            for (int j = 0; j < TP; ++j) {
+                const int px = wp * (BP / WP) + j * 16 + frow;
+                const int ch = wc * (BC / WC) + i * 16 + 4 * fq;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ct[(ch + r) * LD + px] = acc[i][j][r];
+            }
+        __syncthreads();
+        constexpr int TPC = BP / 4;                                  // threads per channel row (4 pixels each)
+        constexpr int CPP = 256 / TPC;                               // channels per pass
+        const int pq = tid % TPC, crow = tid / TPC;
+        const int m = m0 + 4 * pq;
+        float* out = reinterpret_cast<float*>(a.out_raw);
+        const bool vec = (a.HoWo & 3) == 0;
+        for (int pass = 0; pass < BC / CPP; ++pass) {
+            const int chl = pass * CPP + crow;
+            const int c = c0 + chl;
+            if (c >= a.Cout || m >= a.M) continue;
+            const float s1 = a.scale1 ? a.scale1[c] : 1.f, b1 = a.shift1 ? a.shift1[c] : 0.f;
+            const f32x4 t4 = *reinterpret_cast<const f32x4*>(ct + chl * LD + 4 * pq);
+            float v[4] = {t4.x, t4.y, t4.z, t4.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = apply_act(v[i] * s1 + b1, a.act1);
+            if (vec) {
+                const int b = m / a.HoWo, p = m - b * a.HoWo;
+                *reinterpret_cast<float4*>(out + ((size_t)b * a.Cout + c) * a.HoWo + p) =
+                    make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int mi = m + i;
+                    if (mi < a.M) {
+                        const int b = mi / a.HoWo, p = mi - b * a.HoWo;
+                        out[((size_t)b * a.Cout + c) * a.HoWo + p] = v[i];
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <typename T, int BP, int BC>
+constexpr size_t conv_lds_bytes() {
+    size_t stage = 2 * (size_t)(BP + BC) * 128 + 128;               // + tap table
+    size_t epi_a = (size_t)BP * (BC + 4) * 4, epi_b = (size_t)BC * (BP + 4) * 4;
+    size_t e = epi_a > epi_b ? epi_a : epi_b;
+    return stage > e ? stage : e;
+}
+
+struct TileChoice {
+    int bp, bc;
+};
+
+TileChoice choose_tile(int cout) {
+    if (cout <= 16) return {256, 16};
+    if (cout <= 32) return {256, 32};
+    if (cout <= 64) return {128, 64};
+    return {128, 128};
+}
+
+template <typename T, int BP, int BC, int WP, int WC>
+int launch_tile(const ConvKArgs& a, bool smallc, hipStream_t st, const char** kname) {
+    const size_t lds = conv_lds_bytes<T, BP, BC>();
+    const int grid = a.n_ctiles * a.n_ptiles;
+    if (smallc) {
+        auto k = conv_igemm_kernel<T, BP, BC, WP, WC, true>;
+        if (kname) *kname = "conv_igemm_kernel<smallc>";
+        PPN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)lds));
+        hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, a);
+    } else {
+        auto k = conv_igemm_kernel<T, BP, BC, WP, WC, false>;
+        if (kname) *kname = "conv_igemm_kernel";
+        PPN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)lds));
+        hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, a);
+    }
+    PPN_LAUNCH_CHECK();
+    return PPN_OK;
+}
+
+template <typename T>
+int launch_dtype(const ConvKArgs& a, bool smallc, TileChoice tc, hipStream_t st, const char** kname) {
+    if (tc.bc == 16) return launch_tile<T, 256, 16, 4, 1>(a, smallc, st, kname);
+    if (tc.bc == 32) return launch_tile<T, 256, 32, 4, 1>(a, smallc, st, kname);
+    if (tc.bc == 64) return launch_tile<T, 128, 64, 2, 2>(a, smallc, st, kname);
+    return launch_tile<T, 128, 128, 2, 2>(a, smallc, st, kname);
+}
+
+int ilog2_exact(int v) {
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return (1 << l) == v ? l : -1;
+}
+
+// weight packing: [cout,cin,k,k] f32 -> [cout_pad][k_total] T with k = (ky*ks+kx)*cin + ci
+template <typename T>
+__global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ out, int cout, int cin, int ks,
+                                   int cout_pad, int ktot) {
+    const size_t n = (size_t)cout_pad * ktot;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int co = (int)(i / ktot), k = (int)(i % ktot);
+        float v = 0.f;
+        if (co < cout && k < ks * ks * cin) {
+            const int tap = k / cin, ci = k % cin;
+            v = w[((size_t)co * cin + ci) * ks * ks + tap];
+        }
+        out[i] = (T)v;
+    }
+}
+
+}  // namespace
+
+namespace ppn {
+int conv_launch(const ppn_conv_desc* d, hipStream_t st, const char** kname);
+}
+
+extern "C" int ppn_conv_tiling(int32_t dtype, int32_t cin, int32_t cout, int32_t ksize, int32_t* k_step,
+                               int32_t* cout_tile) {
+    if (dtype != PPN_F32 && dtype != PPN_BF16) return ppn::fail(PPN_E_INVALID, "bad dtype %d", dtype);
+    if (cin < 1 || cout < 1 || ksize < 1) return ppn::fail(PPN_E_INVALID, "bad conv shape");
+    if (k_step) *k_step = dtype == PPN_F32 ? 32 : 64;
+    if (cout_tile) *cout_tile = choose_tile(cout).bc;
+    return PPN_OK;
+}
+
+int ppn::conv_launch(const ppn_conv_desc* d, hipStream_t st, const char** kname) {
+    if (!d) return ppn::fail(PPN_E_INVALID, "conv desc is NULL");
+    if (d->dtype != PPN_F32 && d->dtype != PPN_BF16) return ppn::fail(PPN_E_INVALID, "bad dtype %d", d->dtype);
+    const int bk = d->dtype == PPN_F32 ? 32 : 64, epc = d->dtype == PPN_F32 ? 4 : 8;
+    if (d->batch < 1 || d->in_h < 1 || d->in_w < 1 || d->cin < 1 || d->cout < 1)
+        return ppn::fail(PPN_E_INVALID, "bad conv geometry");
+    if (d->ksize < 1 || d->ksize > 5) return ppn::fail(PPN_E_UNSUPPORTED, "ksize %d not supported by the generic kernel", d->ksize);
+    if (d->cin % epc != 0) return ppn::fail(PPN_E_UNSUPPORTED, "cin %d must be a multiple of %d", d->cin, epc);
+    const int eff = d->dilation * (d->ksize - 1) + 1;
+    const int oh = (d->in_h + 2 * d->pad - eff) / d->stride + 1, ow = (d->in_w + 2 * d->pad - eff) / d->stride + 1;
+    if (oh != d->out_h || ow != d->out_w)
+        return ppn::fail(PPN_E_INVALID, "out size %dx%d inconsistent with %dx%d", d->out_h, d->out_w, oh, ow);
+    const bool smallc = (d->cin % bk) != 0;
+    const int log2c = ilog2_exact(d->cin);
+    if (smallc && log2c < 0) return ppn::fail(PPN_E_UNSUPPORTED, "cin %d < K step must be a power of two", d->cin);
+    const int kreal = d->ksize * d->ksize * d->cin;
+    const int kpad = ((kreal + bk - 1) / bk) * bk;
+    if (d->k_total != kpad) return ppn::fail(PPN_E_INVALID, "k_total %d != %d", d->k_total, kpad);
+    TileChoice tc = choose_tile(d->cout);
+    if (d->cout_pad % tc.bc != 0 || d->cout_pad < d->cout)
+        return ppn::fail(PPN_E_INVALID, "cout_pad %d must be a multiple of %d and >= cout", d->cout_pad, tc.bc);
+    if (!d->src || !d->weight || !d->zero_page) return ppn::fail(PPN_E_INVALID, "NULL src/weight/zero_page");
+    if (!d->out_raw && !d->out_act) return ppn::fail(PPN_E_INVALID, "conv has no output");
+    if (d->out_nchw_f32) {
+        if (d->residual || d->out_act || !d->out_raw)
+            return ppn::fail(PPN_E_UNSUPPORTED, "NCHW head output supports out_raw only");
+    } else if (d->cout % 8 != 0) {
+        return ppn::fail(PPN_E_UNSUPPORTED, "NHWC output needs cout %% 8 == 0 (got %d)", d->cout);
+    }
+    const long long m = (long long)d->batch * d->out_h * d->out_w;
+    const long long in_elems = (long long)d->batch * d->in_h * d->in_w * d->cin;
+    if (m > 0x7fffffffLL || in_elems > 0x7fffffffLL) return ppn::fail(PPN_E_UNSUPPORTED, "tensor too large for 32-bit indexing");
+    ConvKArgs a;
+    a.src = static_cast<const char*>(d->src);
+    a.wgt = static_cast<const char*>(d->weight);
+    a.scale1 = d->scale1; a.shift1 = d->shift1;
+    a.residual = static_cast<const char*>(d->residual);
+    a.out_raw = static_cast<char*>(d->out_raw);
+    a.scale2 = d->scale2; a.shift2 = d->shift2;
+    a.out_act = static_cast<char*>(d->out_act);
+    a.zero = static_cast<const char*>(d->zero_page);
+    a.B = d->batch; a.H = d->in_h; a.W = d->in_w; a.Cin = d->cin; a.Ho = d->out_h; a.Wo = d->out_w; a.Cout = d->cout;
+    a.ks = d->ksize; a.stride = d->stride; a.dil = d->dilation; a.pad = d->pad;
+    a.Ktot = d->k_total; a.M = (int)m; a.HoWo = d->out_h * d->out_w;
+    a.act1 = d->act1; a.act2 = d->act2; a.nchw = d->out_nchw_f32;
+    a.log2Cin = log2c < 0 ? 0 : log2c;
+    a.n_ctiles = d->cout_pad / tc.bc;
+    a.n_ptiles = (int)((m + tc.bp - 1) / tc.bp);
+    if (d->dtype == PPN_F32) return launch_dtype<float>(a, smallc, tc, st, kname);
+    return launch_dtype<__bf16>(a, smallc, tc, st, kname);
+}
+
+extern "C" int ppn_conv2d_fused(const ppn_conv_desc* d, void* stream) {
+    return ppn::conv_launch(d, static_cast<hipStream_t>(stream), nullptr);
+}
+
+extern "C" int ppn_pack_weight(int32_t dtype, const float* w, int32_t cout, int32_t cin, int32_t ksize,
+                               int32_t cout_pad, int32_t k_total, void* out, void* stream) {
+    if (!w || !out || cout < 1 || cin < 1 || ksize < 1 || cout_pad < cout || k_total < ksize * ksize * cin)
+        return ppn::fail(PPN_E_INVALID, "ppn_pack_weight: bad arguments");
+    const size_t n = (size_t)cout_pad * k_total;
+    const int blocks = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == PPN_F32)
+        hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(blocks), dim3(256), 0, st, w, static_cast<float*>(out), cout,
+                           cin, ksize, cout_pad, k_total);
+    else if (dtype == PPN_BF16)
+        hipLaunchKernelGGL(pack_weight_kernel<__bf16>, dim3(blocks), dim3(256), 0, st, w, static_cast<__bf16*>(out),
+                           cout, cin, ksize, cout_pad, k_total);
+    else
+        return ppn::fail(PPN_E_INVALID, "bad dtype %d", dtype);
+    PPN_LAUNCH_CHECK();
+    return PPN_OK;
+}

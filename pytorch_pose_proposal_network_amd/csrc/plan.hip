@@ -1,0 +1,118 @@
+// A recorded forward pass: the ordered list of fused launches of PoseProposalNet.forward
+// (model.py:104-136), replayed on a stream.  ppn_plan_run_timed brackets every launch with HIP events on
+// the launch stream so bench.py can report per-kernel durations next to rocprofv3.
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+namespace ppn {
+int conv_launch(const ppn_conv_desc* d, hipStream_t st, const char** kname);
+int stem_launch(int dtype, int src_is_u8, const void* src, int batch, int h, int w, const float* weight,
+                const float* scale, const float* shift, const float* mean, const float* stdv, void* out,
+                hipStream_t st);
+}  // namespace ppn
+
+struct ppn_plan {
+    struct Op {
+        int kind;  // 0 conv, 1 stem
+        ppn_conv_desc conv;
+        int dtype, src_is_u8, batch, h, w;
+        const void* src;
+        const float *weight, *scale, *shift;
+        float mean[3], stdv[3];
+        void* out;
+        std::string kname;
+    };
+    std::vector<Op> ops;
+    std::vector<hipEvent_t> events;
+};
+
+static int run_op(ppn_plan::Op& op, hipStream_t st) {
+    if (op.kind == 0) {
+        const char* kn = nullptr;
+        int rc = ppn::conv_launch(&op.conv, st, &kn);
+        if (rc == PPN_OK && kn && op.kname.empty()) op.kname = kn;
+        return rc;
+    }
+    if (op.kname.empty()) op.kname = op.dtype == PPN_F32 ? "stem7x7_kernel<float>" : "stem7x7_kernel<__bf16>";
+    return ppn::stem_launch(op.dtype, op.src_is_u8, op.src, op.batch, op.h, op.w, op.weight, op.scale, op.shift,
+                            op.mean, op.stdv, op.out, st);
+}
+
+extern "C" int ppn_plan_create(ppn_plan** out) {
+    if (!out) return ppn::fail(PPN_E_INVALID, "ppn_plan_create: NULL out");
+    *out = new (std::nothrow) ppn_plan();
+    return *out ? PPN_OK : ppn::fail(PPN_E_HIP, "out of host memory");
+}
+
+extern "C" int ppn_plan_add_conv(ppn_plan* p, const ppn_conv_desc* d) {
+    if (!p || !d) return ppn::fail(PPN_E_INVALID, "ppn_plan_add_conv: NULL argument");
+    ppn_plan::Op op{};
+    op.kind = 0;
+    op.conv = *d;
+    p->ops.push_back(op);
+    return PPN_OK;
+}
+
+extern "C" int ppn_plan_add_stem(ppn_plan* p, int32_t dtype, int32_t src_is_u8, const void* src, int32_t batch,
+                                 int32_t h, int32_t w, const float* weight, const float* scale, const float* shift,
+                                 const float* mean, const float* std_, void* out) {
+    if (!p) return ppn::fail(PPN_E_INVALID, "ppn_plan_add_stem: NULL plan");
+    ppn_plan::Op op{};
+    op.kind = 1;
+    op.dtype = dtype; op.src_is_u8 = src_is_u8; op.src = src; op.batch = batch; op.h = h; op.w = w;
+    op.weight = weight; op.scale = scale; op.shift = shift; op.out = out;
+    for (int i = 0; i < 3; ++i) { op.mean[i] = mean ? mean[i] : 0.f; op.stdv[i] = std_ ? std_[i] : 1.f; }
+    p->ops.push_back(op);
+    return PPN_OK;
+}
+
+extern "C" int ppn_plan_set_input(ppn_plan* p, const void* src) {
+    if (!p || !src) return ppn::fail(PPN_E_INVALID, "ppn_plan_set_input: NULL argument");
+    for (auto& op : p->ops)
+        if (op.kind == 1) { op.src = src; return PPN_OK; }
+    return ppn::fail(PPN_E_INVALID, "ppn_plan_set_input: plan has no input layer");
+}
+
+extern "C" int ppn_plan_run(ppn_plan* p, void* stream) {
+    if (!p) return ppn::fail(PPN_E_INVALID, "ppn_plan_run: NULL plan");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    for (auto& op : p->ops)
+        if (int rc = run_op(op, st)) return rc;
+    return PPN_OK;
+}
+
+extern "C" int ppn_plan_run_timed(ppn_plan* p, void* stream, float* ms, int32_t n_ms) {
+    if (!p || !ms) return ppn::fail(PPN_E_INVALID, "ppn_plan_run_timed: NULL argument");
+    const size_t n = p->ops.size();
+    if ((size_t)n_ms < n) return ppn::fail(PPN_E_INVALID, "ms buffer too small (%d < %zu)", n_ms, n);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    while (p->events.size() < n + 1) {
+        hipEvent_t e;
+        PPN_HIP_CHECK(hipEventCreate(&e));
+        p->events.push_back(e);
+    }
+    PPN_HIP_CHECK(hipEventRecord(p->events[0], st));
+    for (size_t i = 0; i < n; ++i) {
+        if (int rc = run_op(p->ops[i], st)) return rc;
+        PPN_HIP_CHECK(hipEventRecord(p->events[i + 1], st));
+    }
+    PPN_HIP_CHECK(hipEventSynchronize(p->events[n]));
+    for (size_t i = 0; i < n; ++i) PPN_HIP_CHECK(hipEventElapsedTime(&ms[i], p->events[i], p->events[i + 1]));
+    return PPN_OK;
+}
+
+extern "C" int ppn_plan_size(const ppn_plan* p) { return p ? (int)p->ops.size() : 0; }
+
+extern "C" const char* ppn_plan_kernel_name(const ppn_plan* p, int32_t i) {
+    if (!p || i < 0 || (size_t)i >= p->ops.size()) return "";
+    return p->ops[i].kname.c_str();
+}
+
+extern "C" int ppn_plan_destroy(ppn_plan* p) {
+    if (!p) return PPN_OK;
+    for (auto e : p->events) (void)hipEventDestroy(e);
+    delete p;
+    return PPN_OK;
+}

@@ -55,11 +55,12 @@ _SIGNATURES = {
                                   C.POINTER(C.c_int32)]),
     "ppn_conv2d_fused": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     "ppn_stem7x7": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32] +
-                    [C.c_void_p] * 7 + [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+                    [C.c_void_p] * 3 + [C.POINTER(C.c_float)] * 2 + [C.c_void_p, C.c_void_p]),
     "ppn_plan_create": (C.c_int, [C.POINTER(C.c_void_p)]),
     "ppn_plan_add_conv": (C.c_int, [C.c_void_p, C.POINTER(ConvDesc)]),
     "ppn_plan_add_stem": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32] +
-                          [C.c_void_p] * 7 + [C.c_int32, C.c_void_p, C.c_void_p]),
+                          [C.c_void_p] * 3 + [C.POINTER(C.c_float)] * 2 + [C.c_void_p]),
+    "ppn_plan_set_input": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ppn_plan_run": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ppn_plan_run_timed": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.c_int32]),
     "ppn_plan_size": (C.c_int, [C.c_void_p]),

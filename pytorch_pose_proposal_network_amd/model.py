@@ -1,0 +1,284 @@
+"""``PoseProposalNet`` with the reference's surface (model.py:51-136) over the HIP conv stack.
+
+    backbone = drn.drn_d_22()                       # spec object, mirrors rt_test.py:56-61
+    model = PoseProposalNet(backbone, local_grid_size=(21, 21)).cuda()
+    model.load_state_dict(checkpoint['state_dict']) # reference names
+    model.eval()
+    head = model(image)                             # f32 [B,3,S,S] cuda -> f32 [B,7605,S/16,S/16]
+
+``forward`` launches one fused HIP kernel per convolution through libppn.so (ctypes, C ABI); PyTorch
+is used for device memory and streams only.  ``compute_dtype='float32'`` is the exact-f32 MFMA parity
+mode (1e-4 on the head), ``'bfloat16'`` the performance mode (bf16 operands, f32 accumulation, f32 head).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import arch as A
+from . import config as cfg
+from . import lib as L
+
+
+class DRNSpec:
+    """What ``drn.drn_d_22()`` returns here: the architecture name (there are no nn.Modules to hold)."""
+
+    def __init__(self, arch: str):
+        if arch not in A.DRN_D:
+            raise ValueError(f"unknown DRN-D variant {arch!r}; have {sorted(A.DRN_D)}")
+        self.arch = arch
+
+    def children(self):            # `nn.Sequential(*list(model.children())[:-2])` keeps working
+        return [self, None, None]
+
+    def __repr__(self):
+        return f"DRNSpec({self.arch})"
+
+
+def _arch_of(backbone) -> str:
+    if isinstance(backbone, str):
+        return backbone
+    if isinstance(backbone, DRNSpec):
+        return backbone.arch
+    if isinstance(backbone, (list, tuple)) and backbone and isinstance(backbone[0], DRNSpec):
+        return backbone[0].arch
+    raise TypeError("backbone must be a DRN-D name or the object returned by drn.drn_d_*()")
+
+
+class _Plan:
+    def __init__(self, handle, buffers, head, n_ops, flops):
+        self.handle, self.buffers, self.head, self.n_ops, self.flops = handle, buffers, head, n_ops, flops
+
+
+class PoseProposalNet:
+    def __init__(self, backbone="drn_d_22", insize=(384, 384), outsize=(24, 24),
+                 keypoint_names=cfg.KEYPOINT_NAMES, local_grid_size=(21, 21), edges=cfg.EDGES,
+                 compute_dtype: str = "float32"):
+        self.arch = _arch_of(backbone)
+        self.insize = insize
+        self.outsize = outsize
+        self.keypoint_names = keypoint_names
+        self.edges = edges
+        self.local_grid_size = local_grid_size
+        inW, inH = insize
+        outW, outH = outsize
+        sW, sH = local_grid_size
+        self.gridsize = (int(inW / outW), int(inH / outH))
+        self.lastsize = 6 * len(keypoint_names) + sW * sH * len(edges)          # model.py:64
+        self.compute_dtype = {"float32": L.PPN_F32, "fp32": L.PPN_F32, "bfloat16": L.PPN_BF16,
+                              "bf16": L.PPN_BF16}[compute_dtype]
+        self.training = False
+        self.device = torch.device("cuda")
+        self._ops: List[A.ConvOp] = A.build_program(self.arch, self.lastsize)
+        self._spec = dict(A.param_spec(self.arch, self.lastsize))
+        self._sd: Dict[str, torch.Tensor] = {}
+        self._dev: Dict[str, torch.Tensor] = {}      # packed weights / folded BN on the device
+        self._plans: Dict[tuple, _Plan] = {}
+        self._lib = None
+        self._mean = (C.c_float * 3)(*cfg.MEAN)
+        self._std = (C.c_float * 3)(*cfg.STD)
+
+    # ---- nn.Module-like surface -------------------------------------------------------------
+    def cuda(self, device=None):
+        self.device = torch.device("cuda" if device is None else device)
+        return self
+
+    def eval(self):
+        self.training = False
+        return self
+
+    def train(self, mode: bool = True):
+        if mode:
+            raise NotImplementedError("train-mode BatchNorm (SURVEY.md 8 A16) is not built yet: inference only")
+        self.training = False
+        return self
+
+    def state_dict(self):
+        return dict(self._sd)
+
+    def load_state_dict(self, state_dict, strict: bool = True):
+        """Accepts the reference checkpoint's ``state_dict`` (rt_test.py:74-75); ``module.``-prefixed DDP
+        checkpoints are stripped as main.py:311-318 does."""
+        sd = {}
+        for k, v in state_dict.items():
+            if k.startswith("module."):
+                k = k[len("module."):]
+            t = v if isinstance(v, torch.Tensor) else torch.from_numpy(np.asarray(v))
+            sd[k] = t.detach().cpu()
+        missing = [k for k in self._spec if k not in sd]
+        unexpected = [k for k in sd if k not in self._spec]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"load_state_dict: missing {missing[:5]} ({len(missing)}), "
+                               f"unexpected {unexpected[:5]} ({len(unexpected)})")
+        for k, shape in self._spec.items():
+            if k in sd and tuple(sd[k].shape) != tuple(shape):
+                raise RuntimeError(f"load_state_dict: {k} has shape {tuple(sd[k].shape)}, expected {tuple(shape)}")
+        self._sd = sd
+        self._prepare()
+        return self
+
+    # ---- weight preparation -------------------------------------------------------------------
+    def _fold_bn(self, prefix: str):
+        sd = self._sd
+        g = sd[prefix + ".weight"].double()
+        b = sd[prefix + ".bias"].double()
+        m = sd[prefix + ".running_mean"].double()
+        v = sd[prefix + ".running_var"].double()
+        s = g / torch.sqrt(v + 1e-5)                         # nn.BatchNorm2d eps
+        return s, b - m * s
+
+    def _prepare(self):
+        lib = self._lib = L.load()
+        dev = self.device
+        self._dev.clear()
+        for p in self._plans.values():
+            lib.ppn_plan_destroy(p.handle)
+        self._plans.clear()
+        self._dev["zero"] = torch.zeros(64, dtype=torch.float32, device=dev)
+        stream = L.current_stream_ptr()
+        tdt = torch.float32 if self.compute_dtype == L.PPN_F32 else torch.bfloat16
+        for op in self._ops:
+            w = self._sd[op.weight].float().contiguous()
+            s1 = b1 = None
+            if op.bn1:
+                s1, b1 = self._fold_bn(op.bn1)
+            if op.bias:
+                bias = self._sd[op.bias].double()
+                b1 = bias * s1 + b1 if s1 is not None else bias
+            if s1 is not None:
+                self._dev[op.name + ".s1"] = s1.float().to(dev)
+            if b1 is not None:
+                self._dev[op.name + ".b1"] = b1.float().to(dev)
+            if op.bn2:
+                s2, b2 = self._fold_bn(op.bn2)
+                self._dev[op.name + ".s2"] = s2.float().to(dev)
+                self._dev[op.name + ".b2"] = b2.float().to(dev)
+            if op.k == 7:                                     # stem keeps the reference layout in f32
+                self._dev[op.name + ".w"] = w.to(dev)
+                continue
+            kstep, ctile = C.c_int32(), C.c_int32()
+            L.check(lib.ppn_conv_tiling(self.compute_dtype, op.cin, op.cout, op.k, C.byref(kstep), C.byref(ctile)),
+                    "ppn_conv_tiling")
+            kreal = op.k * op.k * op.cin
+            ktot = (kreal + kstep.value - 1) // kstep.value * kstep.value
+            cpad = (op.cout + ctile.value - 1) // ctile.value * ctile.value
+            wd = w.to(dev)
+            packed = torch.empty(cpad, ktot, dtype=tdt, device=dev)
+            L.check(lib.ppn_pack_weight(self.compute_dtype, wd.data_ptr(), op.cout, op.cin, op.k, cpad, ktot,
+                                        packed.data_ptr(), stream), "ppn_pack_weight")
+            self._dev[op.name + ".w"] = packed
+            self._dev[op.name + ".geom"] = (ktot, cpad)
+        torch.cuda.synchronize(dev)
+
+    # ---- plans ------------------------------------------------------------------------------------
+    def _ptr(self, key: Optional[str]):
+        t = self._dev.get(key) if key else None
+        return t.data_ptr() if t is not None else None
+
+    def _build_plan(self, batch: int, h: int, w: int, src: torch.Tensor, src_is_u8: bool) -> _Plan:
+        lib = self._lib
+        dev = self.device
+        tdt = torch.float32 if self.compute_dtype == L.PPN_F32 else torch.bfloat16
+        shapes = A.tensor_shapes(self._ops, h, w)
+        bufs: Dict[str, torch.Tensor] = {}
+        for name, (th, tw, tc) in shapes.items():
+            if name == "input":
+                continue
+            if name == "head":
+                bufs[name] = torch.empty(batch, tc, th, tw, dtype=torch.float32, device=dev)
+            else:
+                bufs[name] = torch.empty(batch, th, tw, tc, dtype=tdt, device=dev)
+        handle = C.c_void_p()
+        L.check(lib.ppn_plan_create(C.byref(handle)), "ppn_plan_create")
+        for op in self._ops:
+            ih, iw, _ = shapes[op.src]
+            oh, ow = A.out_hw(op, ih, iw)
+            if op.k == 7:
+                assert op.src == "input" and op.out_act is None
+                L.check(lib.ppn_plan_add_stem(handle, self.compute_dtype, 1 if src_is_u8 else 0, src.data_ptr(),
+                                              batch, h, w, self._ptr(op.name + ".w"), self._ptr(op.name + ".s1"),
+                                              self._ptr(op.name + ".b1"), self._mean, self._std,
+                                              bufs[op.out_raw].data_ptr()), "ppn_plan_add_stem")
+                continue
+            d = L.ConvDesc()
+            d.dtype = self.compute_dtype
+            d.batch, d.in_h, d.in_w, d.cin = batch, ih, iw, op.cin
+            d.out_h, d.out_w, d.cout = oh, ow, op.cout
+            d.ksize, d.stride, d.dilation, d.pad = op.k, op.stride, op.dilation, op.pad
+            d.k_total, d.cout_pad = self._dev[op.name + ".geom"]
+            d.act1, d.act2 = op.act1, op.act2
+            d.out_nchw_f32 = 1 if op.nchw_f32_out else 0
+            d.src = bufs[op.src].data_ptr()
+            d.weight = self._ptr(op.name + ".w")
+            d.scale1, d.shift1 = self._ptr(op.name + ".s1"), self._ptr(op.name + ".b1")
+            d.residual = bufs[op.residual].data_ptr() if op.residual else None
+            d.out_raw = bufs[op.out_raw].data_ptr() if op.out_raw else None
+            d.scale2, d.shift2 = self._ptr(op.name + ".s2"), self._ptr(op.name + ".b2")
+            d.out_act = bufs[op.out_act].data_ptr() if op.out_act else None
+            d.zero_page = self._dev["zero"].data_ptr()
+            L.check(lib.ppn_plan_add_conv(handle, C.byref(d)), f"ppn_plan_add_conv({op.name})")
+        return _Plan(handle, bufs, bufs["head"], len(self._ops), A.conv_flops(self._ops, h, w) * batch)
+
+    def _plan_for(self, x: torch.Tensor, src_is_u8: bool) -> _Plan:
+        if not self._dev:
+            raise RuntimeError("PoseProposalNet: call load_state_dict() first")
+        if src_is_u8:
+            b, h, w, _ = x.shape
+        else:
+            b, _, h, w = x.shape
+        key = (b, h, w, src_is_u8)
+        plan = self._plans.get(key)
+        if plan is None:
+            plan = self._plans[key] = self._build_plan(b, h, w, x, src_is_u8)
+        L.check(self._lib.ppn_plan_set_input(plan.handle, x.data_ptr()), "ppn_plan_set_input")
+        plan.keepalive = x
+        return plan
+
+    # ---- forward --------------------------------------------------------------------------------
+    def forward(self, input: torch.Tensor) -> torch.Tensor:
+        """model.py:104-136: f32 [B,3,H,W] normalised image -> sigmoid head f32 [B,lastsize,H/16,W/16].
+
+        The returned tensor is owned by the model's plan for this input buffer and is overwritten by the
+        next forward of the same shape (clone it to keep it)."""
+        if not (input.is_cuda and input.dtype == torch.float32 and input.dim() == 4 and input.shape[1] == 3):
+            raise ValueError("forward expects a float32 CUDA tensor [B,3,H,W]")
+        x = input.contiguous()
+        plan = self._plan_for(x, False)
+        L.check(self._lib.ppn_plan_run(plan.handle, L.current_stream_ptr()), "ppn_plan_run")
+        return plan.head
+
+    __call__ = forward
+
+    def forward_u8(self, frames: torch.Tensor) -> torch.Tensor:
+        """Fused rt_test.py:97-101 + forward: u8 [B,H,W,3] RGB frames on the device -> head."""
+        if not (frames.is_cuda and frames.dtype == torch.uint8 and frames.dim() == 4 and frames.shape[3] == 3):
+            raise ValueError("forward_u8 expects a uint8 CUDA tensor [B,H,W,3]")
+        x = frames.contiguous()
+        plan = self._plan_for(x, True)
+        L.check(self._lib.ppn_plan_run(plan.handle, L.current_stream_ptr()), "ppn_plan_run")
+        return plan.head
+
+    def profile_layers(self, x: torch.Tensor, src_is_u8: bool = False):
+        """Per-launch durations (ms) measured with HIP events on the launch stream: [(op name, kernel, ms, flops)]."""
+        plan = self._plan_for(x.contiguous(), src_is_u8)
+        ms = (C.c_float * plan.n_ops)()
+        L.check(self._lib.ppn_plan_run_timed(plan.handle, L.current_stream_ptr(), ms, plan.n_ops), "ppn_plan_run_timed")
+        b = x.shape[0]
+        h, w = (x.shape[1], x.shape[2]) if src_is_u8 else (x.shape[2], x.shape[3])
+        shapes = A.tensor_shapes(self._ops, h, w)
+        out = []
+        for i, op in enumerate(self._ops):
+            oh, ow, _ = shapes[op.out_raw or op.out_act]
+            fl = 2 * op.cin * op.cout * op.k * op.k * oh * ow * b
+            out.append((op.name, self._lib.ppn_plan_kernel_name(plan.handle, i).decode(), float(ms[i]), fl))
+        return out
+
+    def __del__(self):
+        try:
+            for p in self._plans.values():
+                self._lib.ppn_plan_destroy(p.handle)
+        except Exception:
+            pass

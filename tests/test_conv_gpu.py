@@ -1,0 +1,220 @@
+"""GPU parity of the fused conv kernels (through the C ABI) against plain PyTorch fp32 ops of the same
+layer (torch CPU), covering every shape class of SURVEY.md 2.1: stride 2, dilation 2/4, 1x1, Cin < K step,
+residual, dual (pre-activation) output, bias+LReLU, and the NCHW sigmoid head with Cout = 7605."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+F32_TOL = 2e-5      # relative to the output scale; exact-f32 MFMA vs torch CPU summation order
+BF16_TOL = 2e-2
+
+
+def _act(v, a):
+    return [lambda t: t, F.relu, lambda t: F.leaky_relu(t, 0.1), torch.sigmoid][a](v)
+
+
+def run_conv(x, w, dtype, stride=1, dil=1, pad=0, s1=None, b1=None, act1=0, residual=None, s2=None, b2=None, act2=0,
+             want_raw=True, want_act=False, nchw=False):
+    """x [B,Cin,H,W], w [Cout,Cin,k,k] CPU f32 -> (raw, act) as NCHW CPU f32 tensors via libppn."""
+    from pytorch_pose_proposal_network_amd import lib as L
+    lib = L.load()
+    dev = torch.device("cuda")
+    tdt = torch.float32 if dtype == L.PPN_F32 else torch.bfloat16
+    B, Cin, H, W = x.shape
+    Cout, _, k, _ = w.shape
+    eff = dil * (k - 1) + 1
+    Ho, Wo = (H + 2 * pad - eff) // stride + 1, (W + 2 * pad - eff) // stride + 1
+    kstep, ctile = C.c_int32(), C.c_int32()
+    L.check(lib.ppn_conv_tiling(dtype, Cin, Cout, k, C.byref(kstep), C.byref(ctile)))
+    ktot = (k * k * Cin + kstep.value - 1) // kstep.value * kstep.value
+    cpad = (Cout + ctile.value - 1) // ctile.value * ctile.value
+    st = torch.cuda.current_stream().cuda_stream
+    wd = w.contiguous().to(dev)
+    packed = torch.empty(cpad, ktot, dtype=tdt, device=dev)
+    L.check(lib.ppn_pack_weight(dtype, wd.data_ptr(), Cout, Cin, k, cpad, ktot, packed.data_ptr(), st))
+    xs = x.permute(0, 2, 3, 1).contiguous().to(dev, tdt)
+    zero = torch.zeros(64, device=dev)
+    keep = [wd, packed, xs, zero]
+    d = L.ConvDesc()
+    d.dtype, d.batch, d.in_h, d.in_w, d.cin = dtype, B, H, W, Cin
+    d.out_h, d.out_w, d.cout = Ho, Wo, Cout
+    d.ksize, d.stride, d.dilation, d.pad = k, stride, dil, pad
+    d.k_total, d.cout_pad, d.act1, d.act2, d.out_nchw_f32 = ktot, cpad, act1, act2, int(nchw)
+    d.src, d.weight, d.zero_page = xs.data_ptr(), packed.data_ptr(), zero.data_ptr()
+
+    def dv(t):
+        if t is None:
+            return None
+        t = t.float().contiguous().to(dev)
+        keep.append(t)
+        return t.data_ptr()
+
+    d.scale1, d.shift1, d.scale2, d.shift2 = dv(s1), dv(b1), dv(s2), dv(b2)
+    if residual is not None:
+        r = residual.permute(0, 2, 3, 1).contiguous().to(dev, tdt)
+        keep.append(r)
+        d.residual = r.data_ptr()
+    raw = act = None
+    if want_raw:
+        raw = (torch.full((B, Cout, Ho, Wo), float("nan"), device=dev) if nchw
+               else torch.full((B, Ho, Wo, Cout), float("nan"), device=dev).to(tdt))
+        d.out_raw = raw.data_ptr()
+    if want_act:
+        act = torch.full((B, Ho, Wo, Cout), float("nan"), device=dev).to(tdt)
+        d.out_act = act.data_ptr()
+    L.check(lib.ppn_conv2d_fused(C.byref(d), st), "ppn_conv2d_fused")
+    torch.cuda.synchronize()
+    out = []
+    for t in (raw, act):
+        if t is None:
+            out.append(None)
+        elif nchw:
+            out.append(t.float().cpu())
+        else:
+            out.append(t.float().cpu().permute(0, 3, 1, 2).contiguous())
+    return out
+
+
+def ref_conv(x, w, stride=1, dil=1, pad=0, s1=None, b1=None, act1=0, residual=None, s2=None, b2=None, act2=0):
+    y = F.conv2d(x.double(), w.double(), None, stride, pad, dil)
+    if s1 is not None:
+        y = y * s1.double().view(1, -1, 1, 1)
+    if b1 is not None:
+        y = y + b1.double().view(1, -1, 1, 1)
+    y = _act(y, act1)
+    if residual is not None:
+        y = y + residual.double()
+    u = y
+    if s2 is not None:
+        u = u * s2.double().view(1, -1, 1, 1) + b2.double().view(1, -1, 1, 1)
+    u = _act(u, act2)
+    return y.float(), u.float()
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def q(t, dtype):
+    """Round inputs to bf16 first in bf16 mode so that only accumulation/epilogue error is measured."""
+    from pytorch_pose_proposal_network_amd import lib as L
+    return t.to(torch.bfloat16).float() if dtype == L.PPN_BF16 else t
+
+
+CASES = [
+    # name,           B, Cin, Cout, H,  W,  k, s, d, p
+    ("L6_512_d4",      1, 512, 512, 12, 12, 3, 1, 4, 4),
+    ("L5_128_256_d2",  2, 128, 256, 10, 14, 3, 1, 2, 2),
+    ("L4_s2",          2, 64, 128, 18, 22, 3, 2, 1, 1),
+    ("ds_1x1_s2",      2, 64, 128, 18, 22, 1, 2, 1, 0),
+    ("L3_ds_cin32",    1, 32, 64, 20, 20, 1, 2, 1, 0),
+    ("L3_c1_cin32",    1, 32, 64, 20, 24, 3, 2, 1, 1),
+    ("L1_cin16",       1, 16, 16, 24, 40, 3, 1, 1, 1),
+    ("L2_cin16_s2",    2, 16, 32, 26, 30, 3, 2, 1, 1),
+    ("neck_1x1",       3, 512, 128, 6, 6, 1, 1, 1, 0),
+    ("odd_M",          1, 64, 64, 7, 9, 3, 1, 1, 1),
+    ("d54_2048_512",   1, 2048, 512, 6, 6, 3, 1, 2, 2),
+]
+
+
+@pytest.mark.parametrize("dtype_name", ["f32", "bf16"])
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_conv_bn_relu(case, dtype_name):
+    from pytorch_pose_proposal_network_amd import lib as L
+    dtype = L.PPN_F32 if dtype_name == "f32" else L.PPN_BF16
+    _, B, Cin, Cout, H, W, k, s, dl, p = case
+    x = q(rnd(B, Cin, H, W, seed=1), dtype)
+    w = q(rnd(Cout, Cin, k, k, seed=2, scale=(2.0 / (Cin * k * k)) ** 0.5), dtype)
+    s1 = 0.5 + torch.rand(Cout, generator=torch.Generator().manual_seed(3))
+    b1 = rnd(Cout, seed=4, scale=0.3)
+    raw, _ = run_conv(x, w, dtype, s, dl, p, s1, b1, act1=1)
+    ref, _ = ref_conv(x, w, s, dl, p, s1, b1, act1=1)
+    tol = (F32_TOL if dtype == L.PPN_F32 else BF16_TOL) * max(1.0, float(ref.abs().max()))
+    assert raw.shape == ref.shape
+    assert float((raw - ref).abs().max()) <= tol
+
+
+@pytest.mark.parametrize("dtype_name", ["f32", "bf16"])
+def test_preact_block_epilogue(dtype_name):
+    """conv2 of a BasicBlock: raw = acc + residual, act = relu(bn_next(raw))  (drn.py:42-57)."""
+    from pytorch_pose_proposal_network_amd import lib as L
+    dtype = L.PPN_F32 if dtype_name == "f32" else L.PPN_BF16
+    B, Cc, H, W = 2, 128, 12, 12
+    x, res = q(rnd(B, Cc, H, W, seed=5), dtype), q(rnd(B, Cc, H, W, seed=6), dtype)
+    w = q(rnd(Cc, Cc, 3, 3, seed=7, scale=0.03), dtype)
+    s2, b2 = 0.5 + torch.rand(Cc), rnd(Cc, seed=8, scale=0.2)
+    raw, act = run_conv(x, w, dtype, 1, 2, 2, residual=res, s2=s2, b2=b2, act2=1, want_act=True)
+    rr, ra = ref_conv(x, w, 1, 2, 2, residual=res, s2=s2, b2=b2, act2=1)
+    tol = F32_TOL * 10 if dtype == L.PPN_F32 else BF16_TOL * 2
+    assert float((raw - rr).abs().max()) <= tol * max(1.0, float(rr.abs().max()))
+    assert float((act - ra).abs().max()) <= tol * max(1.0, float(ra.abs().max()))
+    # act only (no raw store) -- Bottleneck tail: relu(bn3(conv) + residual)
+    _, act2 = run_conv(x, w, dtype, 1, 2, 2, s1=s2, b1=b2, residual=res, act2=1, want_raw=False, want_act=True)
+    y = F.relu(F.conv2d(x, w, None, 1, 2, 2) * s2.view(1, -1, 1, 1) + b2.view(1, -1, 1, 1) + res)
+    assert float((act2 - y).abs().max()) <= tol * max(1.0, float(y.abs().max()))
+
+
+@pytest.mark.parametrize("dtype_name", ["f32", "bf16"])
+def test_head_nchw_sigmoid_7605(dtype_name):
+    """conv3: 1x1 512->7605 + bias -> sigmoid, f32 NCHW output (model.py:133-136)."""
+    from pytorch_pose_proposal_network_amd import lib as L
+    dtype = L.PPN_F32 if dtype_name == "f32" else L.PPN_BF16
+    for (B, H, W) in ((2, 24, 24), (1, 6, 6), (1, 5, 7)):
+        x = q(rnd(B, 512, H, W, seed=9), dtype)
+        w = q(rnd(7605, 512, 1, 1, seed=10, scale=0.06), dtype)
+        bias = rnd(7605, seed=11, scale=0.1)
+        raw, _ = run_conv(x, w, dtype, b1=bias, act1=3, nchw=True)
+        ref, _ = ref_conv(x, w, b1=bias, act1=3)
+        assert raw.shape == (B, 7605, H, W)
+        assert float((raw - ref).abs().max()) <= (2e-6 if dtype == L.PPN_F32 else 5e-3)
+
+
+def test_lrelu_bias_bn():
+    from pytorch_pose_proposal_network_amd import lib as L
+    x, w = rnd(1, 512, 6, 6, seed=12), rnd(512, 512, 3, 3, seed=13, scale=0.02)
+    s1, b1 = 0.5 + torch.rand(512), rnd(512, seed=14)
+    raw, _ = run_conv(x, w, L.PPN_F32, 1, 1, 1, s1, b1, act1=2)
+    ref, _ = ref_conv(x, w, 1, 1, 1, s1, b1, act1=2)
+    assert float((raw - ref).abs().max()) <= F32_TOL * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("dtype_name", ["f32", "bf16"])
+@pytest.mark.parametrize("u8", [True, False])
+def test_stem7x7(dtype_name, u8):
+    from pytorch_pose_proposal_network_amd import lib as L, prng
+    lib = L.load()
+    dtype = L.PPN_F32 if dtype_name == "f32" else L.PPN_BF16
+    tdt = torch.float32 if dtype == L.PPN_F32 else torch.bfloat16
+    B, H, W = 2, 37, 70            # not multiples of the 16x64 tile
+    frames = torch.from_numpy(prng.u8_frames(5, B, (H, W)))
+    mean, std = torch.tensor([0.485, 0.456, 0.406]), torch.tensor([0.229, 0.224, 0.225])
+    xn = (frames.permute(0, 3, 1, 2).float() - mean.view(1, 3, 1, 1)) / std.view(1, 3, 1, 1)
+    w = rnd(16, 3, 7, 7, seed=15, scale=0.002)
+    s1, b1 = 0.5 + torch.rand(16), rnd(16, seed=16, scale=0.3)
+    dev = torch.device("cuda")
+    out = torch.full((B, H, W, 16), float("nan"), device=dev).to(tdt)
+    src = frames.to(dev) if u8 else xn.contiguous().to(dev)
+    wd, sd_, bd = w.to(dev), s1.to(dev), b1.to(dev)
+    m3, s3 = (C.c_float * 3)(0.485, 0.456, 0.406), (C.c_float * 3)(0.229, 0.224, 0.225)
+    L.check(lib.ppn_stem7x7(dtype, int(u8), src.data_ptr(), B, H, W, wd.data_ptr(), sd_.data_ptr(), bd.data_ptr(),
+                            m3, s3, out.data_ptr(), torch.cuda.current_stream().cuda_stream), "ppn_stem7x7")
+    torch.cuda.synchronize()
+    got = out.float().cpu().permute(0, 3, 1, 2)
+    ref = F.relu(F.conv2d(xn.double(), w.double(), None, 1, 3) * s1.double().view(1, -1, 1, 1) + b1.double().view(1, -1, 1, 1)).float()
+    tol = (1e-5 if dtype == L.PPN_F32 else 2e-2) * float(ref.abs().max())
+    assert float((got - ref).abs().max()) <= tol
+
+
+def test_conv_rejects_bad_descriptors():
+    from pytorch_pose_proposal_network_amd import lib as L
+    lib = L.load()
+    d = L.ConvDesc()
+    assert lib.ppn_conv2d_fused(C.byref(d), None) != 0
+    assert b"" != lib.ppn_last_error()
+    assert lib.ppn_conv2d_fused(None, None) != 0

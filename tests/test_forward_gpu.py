@@ -1,0 +1,102 @@
+"""GPU parity of PoseProposalNet.forward (HIP conv stack through the C ABI) against the golden head
+tensors produced by the reference itself (tests/golden/make_golden.py).
+
+Tolerances (BASELINE.json north_star): f32 mode 1e-4 absolute on the sigmoid head.  bf16 mode is the
+performance mode; its own tolerance is stated here: 3e-2 max / 4e-3 mean absolute on the head."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from pytorch_pose_proposal_network_amd import prng, synth
+
+pytestmark = pytest.mark.gpu
+
+F32_TOL = 1e-4
+BF16_MAX_TOL, BF16_MEAN_TOL = 3e-2, 4e-3
+
+
+def _model(arch, g, dtype):
+    from pytorch_pose_proposal_network_amd import drn, model
+    stats = {k[3:]: g[k] for k in g.files if k.startswith("bn/")}
+    sd = synth.make_state_dict(arch, int(g["seed_w"]), bn_stats=stats)
+    m = model.PoseProposalNet(getattr(drn, arch)(), local_grid_size=(21, 21), compute_dtype=dtype).cuda()
+    m.load_state_dict(sd)
+    return m.eval()
+
+
+def _frames(g):
+    size, batch = int(g["size"]), int(g["batch"])
+    return prng.u8_frames(int(g["seed_in"]), batch, (size, size))
+
+
+@pytest.mark.parametrize("name", ["forward_d22_96", "forward_d38_96", "forward_d54_96"])
+def test_forward_f32_small_full_head(golden_dir, name):
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    m = _model(str(g["arch"]), g, "float32")
+    u8 = _frames(g)
+    x = torch.from_numpy(synth.normalized_frames(u8)).cuda()
+    head = m(x).cpu().numpy()
+    assert head.shape == g["head"].shape
+    err = np.abs(head - g["head"]).max()
+    assert err <= F32_TOL, err
+    # fused-normalisation entry (rt_test.inference path) gives the same head
+    head2 = m.forward_u8(torch.from_numpy(u8).cuda()).cpu().numpy()
+    assert np.abs(head2 - g["head"]).max() <= F32_TOL
+
+
+def test_forward_f32_384(golden_dir):
+    g = np.load(os.path.join(golden_dir, "forward_d22_384.npz"))
+    m = _model("drn_d_22", g, "float32")
+    x = torch.from_numpy(synth.normalized_frames(_frames(g))).cuda()
+    head = m(x).cpu().numpy()
+    assert head.shape == (2, 7605, 24, 24)
+    err = np.abs(head.reshape(-1)[g["head_idx"]] - g["head_val"]).max()
+    assert err <= F32_TOL, err
+    assert np.allclose(head.astype(np.float64).sum(axis=(2, 3)), g["head_chan_sum"], atol=2e-2)
+
+
+@pytest.mark.parametrize("name", ["forward_d22_96", "forward_d54_96"])
+def test_forward_bf16_small(golden_dir, name):
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    m = _model(str(g["arch"]), g, "bfloat16")
+    head = m.forward_u8(torch.from_numpy(_frames(g)).cuda()).cpu().numpy()
+    d = np.abs(head - g["head"])
+    print(f"{name} bf16: max {d.max():.4f} mean {d.mean():.5f}")
+    assert d.max() <= BF16_MAX_TOL and d.mean() <= BF16_MEAN_TOL
+
+
+def test_forward_bf16_384(golden_dir):
+    g = np.load(os.path.join(golden_dir, "forward_d22_384.npz"))
+    m = _model("drn_d_22", g, "bfloat16")
+    head = m.forward_u8(torch.from_numpy(_frames(g)).cuda()).cpu().numpy()
+    d = np.abs(head.reshape(-1)[g["head_idx"]] - g["head_val"])
+    print(f"d22 384 bf16: max {d.max():.4f} mean {d.mean():.5f}")
+    assert d.max() <= BF16_MAX_TOL and d.mean() <= BF16_MEAN_TOL
+
+
+def test_forward_batch_independence_and_replay(golden_dir):
+    """Frames are independent units: image i of a batch equals the same image run alone (sharding property)."""
+    g = np.load(os.path.join(golden_dir, "forward_d22_96.npz"))
+    m = _model("drn_d_22", g, "float32")
+    u8 = prng.u8_frames(77, 5, (96, 96))
+    full = m.forward_u8(torch.from_numpy(u8).cuda()).cpu().numpy()
+    one = m.forward_u8(torch.from_numpy(u8[3:4]).cuda()).cpu().numpy()
+    assert np.array_equal(full[3:4], one)
+    again = m.forward_u8(torch.from_numpy(u8).cuda()).cpu().numpy()
+    assert np.array_equal(full, again)
+
+
+def test_state_dict_validation():
+    from pytorch_pose_proposal_network_amd import model
+    m = model.PoseProposalNet("drn_d_22")
+    sd = synth.make_state_dict("drn_d_22", 0)
+    bad = dict(sd)
+    bad.pop("conv3.bias")
+    with pytest.raises(RuntimeError):
+        m.load_state_dict(bad)
+    ddp = {"module." + k: v for k, v in sd.items()}       # main.py:311-318 parallel checkpoints
+    m.load_state_dict(ddp)
+    with pytest.raises(NotImplementedError):
+        m.train()
