@@ -1,0 +1,188 @@
+#!/usr/bin/env python
+"""Benchmark of the PPN hot path on MI355X: images/sec, DRN-D-22 @ 384x384, bf16 MFMA, batch 32 per GPU.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One *step* = one pass of the hot path over one batch that is already resident in HBM:
+  u8 frames [32,384,384,3] -> fused normalisation + 35 fused conv launches (head f32 [32,7605,24,24])
+  -> limb arg-max + root NMS + limb parse (compact people list left on the device).
+Frames are independent units, so N GPUs = N ranks each with its own 32 frames (weak scaling), no collective
+on the data path; torch.distributed (RCCL) is used only for the timing barrier and the MAX over ranks.
+
+Rank 0 prints ONE JSON line with the contract fields plus
+  roofline      dominant kernel (by time): algorithmic FLOPs of its launches / their HIP-event duration
+  cpu_baseline  the CPU oracle (torch-CPU fp32 forward + NumPy decode) on a bounded sample, N=1 only
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from pytorch_pose_proposal_network_amd import config as cfg, prng, synth  # noqa: E402
+
+BF16_DENSE_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
+F32_MFMA_PEAK_TFLOPS = 157.3
+
+
+def load_bn_stats(arch, seed=0):
+    path = os.path.join(ROOT, "pytorch_pose_proposal_network_amd", "data", f"bn_calib_{arch}_seed{seed}.npz")
+    g = np.load(path)
+    return {k: g[k] for k in g.files}
+
+
+def cpu_baseline(arch, sample, size):
+    """The oracle timed on this host's cores on `sample` frames of the same workload (reported, not a target)."""
+    from oracle import decode_ref as D, forward_ref as Fr
+    torch.set_num_threads(os.cpu_count() or 1)
+    sd = synth.make_state_dict(arch, 0, bn_stats=load_bn_stats(arch))
+    u8 = prng.u8_frames(1234, sample, (size, size))
+    x = Fr.normalize_u8(u8)
+    Fr.forward_ref(sd, x[:1], arch)                               # warm-up
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        head = Fr.forward_ref(sd, Fr.normalize_u8(u8), arch).numpy()
+        for i in range(sample):
+            D.decode_ref(head[i], insize=(size, size))
+        reps += 1
+        if time.perf_counter() - t0 > 10.0 or reps >= 5:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": round(sample * reps / dt, 3), "unit": "images/sec", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": f"{reps} x {sample} frames {size}x{size}: torch-CPU fp32 oracle forward + NumPy decode, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="frames per GPU")
+    ap.add_argument("--size", type=int, default=384)
+    ap.add_argument("--arch", default="drn_d_22")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--layers", action="store_true", help="print the per-layer table to stderr")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from pytorch_pose_proposal_network_amd import decode, drn, model
+
+    B, S = args.batch, args.size
+    net = model.PoseProposalNet(getattr(drn, args.arch)(), insize=(S, S), outsize=(S // 16, S // 16),
+                                compute_dtype="bfloat16" if args.dtype == "bf16" else "float32").cuda(dev)
+    net.load_state_dict(synth.make_state_dict(args.arch, 0, bn_stats=load_bn_stats(args.arch)))
+    net.eval()
+    frames = torch.from_numpy(prng.u8_frames(1234 + rank, B, (S, S))).to(dev)      # resident in HBM
+    dec = decode.Decoder(B, (S // 16, S // 16), (S, S), device=dev)
+
+    def step():
+        head = net.forward_u8(frames)
+        return dec(head)
+
+    for _ in range(args.warmup):
+        step()
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = world * B * args.steps / dt
+    people = int(out.count.sum().item())
+
+    result = None
+    if rank == 0:
+        # ---- per-kernel durations: HIP events on the launch stream around every launch ----------------
+        agg, table = {}, []
+        reps = 5
+        for r in range(reps):
+            for name, kern, ms, fl in net.profile_layers(frames, src_is_u8=True):
+                a = agg.setdefault(kern, [0.0, 0.0, 0])
+                a[0] += ms; a[1] += fl; a[2] += 1
+                if r == 0:
+                    table.append((name, kern, ms, fl))
+        fwd_ms = sum(a[0] for a in agg.values()) / reps
+        fwd_flops = sum(a[1] for a in agg.values()) / reps
+        dom = max(agg.items(), key=lambda kv: kv[1][0])
+        dk, (dms, dfl, dn) = dom
+        peak = BF16_DENSE_PEAK_TFLOPS if args.dtype == "bf16" else F32_MFMA_PEAK_TFLOPS
+        achieved = dfl / (dms * 1e-3) / 1e12
+        if args.layers:
+            for name, kern, ms, fl in table:
+                print(f"{name:28s} {ms*1e3:9.1f} us {fl/ms/1e9 if ms > 0 else 0:9.1f} TFLOP/s  {kern}", file=sys.stderr)
+        # decode kernels: dense bytes of the head read once
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        head = net.forward_u8(frames)
+        torch.cuda.synchronize(dev)
+        ev[0].record(); dec(head); ev[1].record()
+        torch.cuda.synchronize(dev)
+        dec_ms = ev[0].elapsed_time(ev[1])
+        head_bytes = head.numel() * 4
+        result = {
+            "metric": "images/sec (384x384, DRN-D-22) at 1/2/4/8 MI355X",
+            "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"{args.arch} PPN inference {args.dtype}, batch {B}/GPU synthetic {S}x{S} u8 frames: "
+                                   "fused normalise + conv stack + head + decode/NMS/limb-parse (BASELINE configs[1])",
+                       "frames_per_gpu": B, "input": f"{S}x{S}x3 u8", "head": f"{cfg.lastsize()}x{S//16}x{S//16} f32",
+                       "parallelism": f"frames sharded over {world} GPU(s), no data-path collective"},
+            "roofline": {"bound": "mfma", "kernel": dk, "launches_per_step": dn // reps,
+                         "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(achieved / peak, 4), "traffic": None,
+                         "avg_launch_us": round(dms / dn * 1e3, 2),
+                         "flops_per_launch_avg": round(dfl / dn)},
+            "conv_stack": {"ms": round(fwd_ms, 4), "tflops": round(fwd_flops / fwd_ms / 1e9, 2),
+                           "frac_of_mfma_peak": round(fwd_flops / fwd_ms / 1e9 / peak, 4),
+                           "gflop_per_image": round(fwd_flops / B / 1e9, 3)},
+            "decode": {"ms": round(dec_ms, 4), "gbps": round(head_bytes / dec_ms / 1e6, 1),
+                       "frac_of_hbm_peak": round(head_bytes / dec_ms / 1e6 / 8000.0, 4), "people": people},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(args.arch, 4, S)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+
+
+if __name__ == "__main__":
+    main()

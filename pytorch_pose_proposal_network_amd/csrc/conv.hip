@@ -383,15 +383,22 @@ template <typename T, int BP, int BC, int WP, int WC>
 int launch_tile(const ConvKArgs& a, bool smallc, hipStream_t st, const char** kname) {
     const size_t lds = conv_lds_bytes<T, BP, BC>();
     const int grid = a.n_ctiles * a.n_ptiles;
+    // the name as rocprofv3 --kernel-trace prints it (a substring of the demangled symbol)
+    static char names[2][96];
+    if (!names[0][0]) {
+        for (int i = 0; i < 2; ++i)
+            snprintf(names[i], sizeof(names[i]), "conv_igemm_kernel<%s, %d, %d, %d, %d, %s>",
+                     sizeof(T) == 4 ? "float" : "__bf16", BP, BC, WP, WC, i ? "true" : "false");
+    }
     if (smallc) {
         auto k = conv_igemm_kernel<T, BP, BC, WP, WC, true>;
-        if (kname) *kname = "conv_igemm_kernel<smallc>";
+        if (kname) *kname = names[1];
         PPN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)lds));
         hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, a);
     } else {
         auto k = conv_igemm_kernel<T, BP, BC, WP, WC, false>;
-        if (kname) *kname = "conv_igemm_kernel";
+        if (kname) *kname = names[0];
         PPN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)lds));
         hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, a);

@@ -127,8 +127,15 @@ def make_forward(drn, model):
         for k, v in taps.items():
             t = v.numpy().astype(np.float64)
             out["tap/" + k] = np.array([t.mean(), np.abs(t).mean(), t.std()])
+        # fp64 evaluation of the same network: the reference's own fp32 rounding noise on this fixture
+        sd64 = {k: (torch.from_numpy(v).double() if v.dtype != np.int64 else torch.from_numpy(v))
+                for k, v in sd_cal.items()}
+        h64 = Fr.forward_ref(sd64, x.double(), arch_name).numpy()
+        out["ref_f32_noise"] = float(np.abs(ref - h64).max())
+        print(f"   reference fp32 vs fp64 evaluation: max|diff| = {out['ref_f32_noise']:.3e}")
         if full:
             out["head"] = ref
+            out["head_f64"] = h64.astype(np.float32)
         else:
             n = 40000
             idx = (prng.raw_u64(prng.stream_seed(99, 0), n) % np.uint64(ref.size)).astype(np.int64)
