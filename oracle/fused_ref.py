@@ -1,0 +1,83 @@
+"""ORACLE (test infrastructure, never shipped or measured as the product).
+
+Executes the *fused conv program* (pytorch_pose_proposal_network_amd.arch.build_program) with plain
+PyTorch-CPU ops, one F.conv2d per ConvOp followed by the same epilogue algebra the HIP kernel applies:
+
+    v = act1(conv(x, w) * scale1 + shift1) (+ residual);  out_raw = v;  out_act = act2(v * scale2 + shift2)
+
+Two uses:
+  * fp32: must agree with oracle/forward_ref.py (the op-by-op restatement of model.py:104-136 /
+    drn.py:42-57,77-97) -- a CPU-only check of the host lowering (BN folding, pre-activation second
+    output, Bottleneck ReLU-after-add), no GPU needed.
+  * emulate_bf16=True: weights and every stored activation are rounded to bf16 exactly where the HIP bf16
+    mode stores bf16 (accumulation and epilogue stay fp32, the head stays fp32), giving a tight reference
+    for the bf16 kernels that is independent of how much a random network amplifies rounding noise.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from pytorch_pose_proposal_network_amd import arch as A
+
+_ACT = {A.ACT_NONE: lambda t: t, A.ACT_RELU: F.relu, A.ACT_LRELU: lambda t: F.leaky_relu(t, 0.1),
+        A.ACT_SIGMOID: torch.sigmoid}
+
+
+def _t(v):
+    return v if isinstance(v, torch.Tensor) else torch.from_numpy(np.asarray(v))
+
+
+def _fold(sd, prefix):
+    g, b = _t(sd[prefix + ".weight"]).double(), _t(sd[prefix + ".bias"]).double()
+    m, v = _t(sd[prefix + ".running_mean"]).double(), _t(sd[prefix + ".running_var"]).double()
+    s = g / torch.sqrt(v + 1e-5)
+    return s, b - m * s
+
+
+def _bf16(t):
+    return t.to(torch.bfloat16).float()
+
+
+def fused_forward_ref(sd, x: torch.Tensor, arch: str = "drn_d_22", emulate_bf16: bool = False, taps=None):
+    """x f32 [B,3,H,W] (normalised) -> head f32 [B,C,H/16,W/16], walking the fused program."""
+    ops = A.build_program(arch)
+    q = _bf16 if emulate_bf16 else (lambda t: t)
+    tensors = {"input": x.float()}
+    with torch.no_grad():
+        for op in ops:
+            src = tensors[op.src]
+            w = _t(sd[op.weight]).float()
+            if op.k == 7:
+                src_q, w_q = q(src), q(w)          # the stem stages a bf16 patch / bf16 weight fragments
+            else:
+                src_q, w_q = src, q(w)             # other inputs are already-stored (rounded) tensors
+            acc = F.conv2d(src_q, w_q, None, op.stride, op.pad, op.dilation)
+            s1 = b1 = None
+            if op.bn1:
+                s1, b1 = _fold(sd, op.bn1)
+            if op.bias:
+                bias = _t(sd[op.bias]).double()
+                b1 = bias * s1 + b1 if s1 is not None else bias
+            v = acc
+            if s1 is not None:
+                v = v * s1.float().view(1, -1, 1, 1)
+            if b1 is not None:
+                v = v + b1.float().view(1, -1, 1, 1)
+            v = _ACT[op.act1](v)
+            if op.residual:
+                v = v + tensors[op.residual]
+            if op.out_raw:
+                tensors[op.out_raw] = v if op.nchw_f32_out else q(v)
+            if op.out_act:
+                u = v
+                if op.bn2:
+                    s2, b2 = _fold(sd, op.bn2)
+                    u = u * s2.float().view(1, -1, 1, 1) + b2.float().view(1, -1, 1, 1)
+                tensors[op.out_act] = q(_ACT[op.act2](u))
+            if taps is not None:
+                taps[op.name] = tensors[op.out_raw or op.out_act]
+    return tensors["head"]

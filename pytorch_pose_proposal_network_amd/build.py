@@ -25,6 +25,15 @@ SOURCES = [
 ]
 
 
+def torch_lib_dir():
+    import importlib.util
+    spec = importlib.util.find_spec("torch")
+    if spec is None or not spec.submodule_search_locations:
+        return None
+    d = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    return d if os.path.exists(os.path.join(d, "libamdhip64.so")) else None
+
+
 def _stale(out, deps):
     if not os.path.exists(out):
         return True
@@ -52,7 +61,12 @@ def build(force: bool = False, verbose: bool = True) -> str:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed: " + " ".join(cmd))
     if force or procs or _stale(LIB, objs):
+        # Link against the HIP runtime PyTorch-ROCm bundles (torch/lib/libamdhip64.so) so that the process
+        # holds ONE runtime: streams, events and allocations are then shared with torch by construction.
+        tl = torch_lib_dir()
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        if tl:
+            cmd += ["-L" + tl, "-Wl,-rpath," + tl]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

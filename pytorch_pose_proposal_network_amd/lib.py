@@ -82,6 +82,7 @@ def load():
         raise PPNError(
             f"{LIB_PATH} is missing: build it with `python -m pytorch_pose_proposal_network_amd.build` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    import torch  # noqa: F401  -- load PyTorch-ROCm's HIP runtime first: libppn.so binds to the same one
     lib = C.CDLL(LIB_PATH)
     missing = []
     for name, (res, args) in _SIGNATURES.items():

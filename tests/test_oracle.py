@@ -130,3 +130,18 @@ def test_prng_is_stable():
     assert prng.raw_u64(0, 2).tolist() == [16294208416658607535, 7960286522194355700]
     f = prng.u8_frames(1234, 1, (4, 4))
     assert f.shape == (1, 4, 4, 3) and f.dtype == np.uint8
+
+
+@pytest.mark.parametrize("name", ["forward_d22_96", "forward_d54_96"])
+def test_fused_program_equals_reference_order(golden_dir, name):
+    """Host lowering (arch.build_program: BN folding, pre-activation second output, Bottleneck tail) executed
+    with torch-CPU ops must reproduce the reference head."""
+    from oracle import fused_ref
+    g = _load(golden_dir, name + ".npz")
+    arch_name = str(g["arch"])
+    stats = {k[3:]: g[k] for k in g.files if k.startswith("bn/")}
+    sd = synth.make_state_dict(arch_name, int(g["seed_w"]), bn_stats=stats)
+    x = Fr.normalize_u8(prng.u8_frames(int(g["seed_in"]), int(g["batch"]), (96, 96)))
+    out = fused_ref.fused_forward_ref(sd, x, arch_name).numpy()
+    err, err64 = np.abs(out - g["head"]).max(), np.abs(out - g["head_f64"]).max()
+    assert err <= 1e-4 or err64 <= 1.5 * float(g["ref_f32_noise"]), (err, err64)
