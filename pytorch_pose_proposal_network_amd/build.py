@@ -20,6 +20,7 @@ SOURCES = [
     ("abi.cpp", ["-x", "hip"]),
     ("decode.hip", ["-ffp-contract=off"]),
     ("conv.hip", []),
+    ("conv_big.hip", []),
     ("stem.hip", []),
     ("plan.hip", []),
 ]

@@ -18,104 +18,11 @@
 // which covers conv->BN->ReLU (drn.py:192-202), the pre-activation BasicBlock (drn.py:42-57: the
 // second output is the NEXT block's relu(bn1(x)), so zero padding happens after BN/ReLU as in the
 // reference), Bottleneck (drn.py:77-97) and the PPN neck/head incl. bias + sigmoid (model.py:113-134).
-#include <hip/hip_bf16.h>
-
-#include "common.h"
+#include "conv_common.h"
 
 namespace {
 
-typedef __attribute__((ext_vector_type(4))) float f32x4;
-typedef __attribute__((ext_vector_type(8))) short s16x8;
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-
-struct ConvKArgs {
-    const char* src;
-    const char* wgt;
-    const float* scale1;
-    const float* shift1;
-    const char* residual;
-    char* out_raw;
-    const float* scale2;
-    const float* shift2;
-    char* out_act;
-    const char* zero;
-    int B, H, W, Cin, Ho, Wo, Cout, ks, stride, dil, pad;
-    int Ktot;      // padded GEMM depth (multiple of BK)
-    int M;         // B*Ho*Wo
-    int HoWo;
-    int act1, act2, nchw;
-    int log2Cin;
-    int n_ctiles, n_ptiles;
-};
-
-template <typename T>
-struct Elem;
-template <>
-struct Elem<float> {
-    static constexpr int EPC = 4;  // elements per 16-byte chunk
-};
-template <>
-struct Elem<__bf16> {
-    static constexpr int EPC = 8;
-};
-
-__device__ __forceinline__ float apply_act(float v, int act) {
-    switch (act) {
-        case PPN_ACT_RELU: return v > 0.f ? v : 0.f;
-        case PPN_ACT_LRELU: return v > 0.f ? v : v * 0.1f;      // nn.LeakyReLU(0.1), model.py:88
-        case PPN_ACT_SIGMOID: return 1.0f / (1.0f + __expf(-v));
-        default: return v;
-    }
-}
-
-__device__ __forceinline__ void glds16(const char* gptr, char* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)gptr,
-                                     (void __attribute__((address_space(3)))*)lds_wave_base, 16, 0, 0);
-}
-
-// One K-substep (4 chunks = 128 B/4 of a row): acc += Wfrag x Xfrag
-__device__ __forceinline__ void mma_step(f32x4& acc, const f32x4& wf, const f32x4& xf, float*) {
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf.x, xf.x, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf.y, xf.y, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf.z, xf.z, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf.w, xf.w, acc, 0, 0, 0);
-}
-__device__ __forceinline__ void mma_step(f32x4& acc, const f32x4& wf, const f32x4& xf, __bf16*) {
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf), __builtin_bit_cast(bf16x8, xf),
-                                                  acc, 0, 0, 0);
-}
-
-template <typename T>
-__device__ __forceinline__ void load8(const char* p, float* v);
-template <>
-__device__ __forceinline__ void load8<float>(const char* p, float* v) {
-    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 16);
-    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-}
-template <>
-__device__ __forceinline__ void load8<__bf16>(const char* p, float* v) {
-    const uint4 a = *reinterpret_cast<const uint4*>(p);
-    const unsigned u[4] = {a.x, a.y, a.z, a.w};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        v[2 * i] = __uint_as_float(u[i] << 16);
-        v[2 * i + 1] = __uint_as_float(u[i] & 0xffff0000u);
-    }
-}
-template <typename T>
-__device__ __forceinline__ void store8(char* p, const float* v);
-template <>
-__device__ __forceinline__ void store8<float>(char* p, const float* v) {
-    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
-    *reinterpret_cast<float4*>(p + 16) = make_float4(v[4], v[5], v[6], v[7]);
-}
-template <>
-__device__ __forceinline__ void store8<__bf16>(char* p, const float* v) {
-    bf16x8 o;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) o[i] = (__bf16)v[i];                 // RNE, v_cvt_pk_bf16_f32
-    *reinterpret_cast<bf16x8*>(p) = o;
-}
+using namespace ppnconv;
 
 // BP x BC output tile per 256-thread workgroup; WP x WC waves; SMALLC: Cin < BK (several taps per K step).
 template <typename T, int BP, int BC, int WP, int WC, bool SMALLC>
@@ -447,8 +354,11 @@ extern "C" int ppn_conv_tiling(int32_t dtype, int32_t cin, int32_t cout, int32_t
                                int32_t* cout_tile) {
     if (dtype != PPN_F32 && dtype != PPN_BF16) return ppn::fail(PPN_E_INVALID, "bad dtype %d", dtype);
     if (cin < 1 || cout < 1 || ksize < 1) return ppn::fail(PPN_E_INVALID, "bad conv shape");
-    if (k_step) *k_step = dtype == PPN_F32 ? 32 : 64;
-    if (cout_tile) *cout_tile = choose_tile(cout).bc;
+    const int bk = dtype == PPN_F32 ? 32 : 64;
+    if (k_step) *k_step = bk;
+    BigTile bt;
+    const bool big = (cin % bk == 0) && big_tile_for(cout, 1, &bt);
+    if (cout_tile) *cout_tile = big ? bt.bc : choose_tile(cout).bc;
     return PPN_OK;
 }
 
@@ -470,9 +380,13 @@ int ppn::conv_launch(const ppn_conv_desc* d, hipStream_t st, const char** kname)
     const int kreal = d->ksize * d->ksize * d->cin;
     const int kpad = ((kreal + bk - 1) / bk) * bk;
     if (d->k_total != kpad) return ppn::fail(PPN_E_INVALID, "k_total %d != %d", d->k_total, kpad);
+    const long long m = (long long)d->batch * d->out_h * d->out_w;
     TileChoice tc = choose_tile(d->cout);
-    if (d->cout_pad % tc.bc != 0 || d->cout_pad < d->cout)
-        return ppn::fail(PPN_E_INVALID, "cout_pad %d must be a multiple of %d and >= cout", d->cout_pad, tc.bc);
+    BigTile bt{0, 0};
+    const bool big = !smallc && big_tile_for(d->cout, m, &bt);
+    const int bc = big ? bt.bc : tc.bc, bp = big ? bt.bp : tc.bp;
+    if (d->cout_pad % bc != 0 || d->cout_pad < d->cout)
+        return ppn::fail(PPN_E_INVALID, "cout_pad %d must be a multiple of %d and >= cout", d->cout_pad, bc);
     if (!d->src || !d->weight || !d->zero_page) return ppn::fail(PPN_E_INVALID, "NULL src/weight/zero_page");
     if (!d->out_raw && !d->out_act) return ppn::fail(PPN_E_INVALID, "conv has no output");
     if (d->out_nchw_f32) {
@@ -481,7 +395,6 @@ int ppn::conv_launch(const ppn_conv_desc* d, hipStream_t st, const char** kname)
     } else if (d->cout % 8 != 0) {
         return ppn::fail(PPN_E_UNSUPPORTED, "NHWC output needs cout %% 8 == 0 (got %d)", d->cout);
     }
-    const long long m = (long long)d->batch * d->out_h * d->out_w;
     const long long in_elems = (long long)d->batch * d->in_h * d->in_w * d->cin;
     if (m > 0x7fffffffLL || in_elems > 0x7fffffffLL) return ppn::fail(PPN_E_UNSUPPORTED, "tensor too large for 32-bit indexing");
     ConvKArgs a;
@@ -498,8 +411,9 @@ int ppn::conv_launch(const ppn_conv_desc* d, hipStream_t st, const char** kname)
     a.Ktot = d->k_total; a.M = (int)m; a.HoWo = d->out_h * d->out_w;
     a.act1 = d->act1; a.act2 = d->act2; a.nchw = d->out_nchw_f32;
     a.log2Cin = log2c < 0 ? 0 : log2c;
-    a.n_ctiles = d->cout_pad / tc.bc;
-    a.n_ptiles = (int)((m + tc.bp - 1) / tc.bp);
+    a.n_ctiles = d->cout_pad / bc;
+    a.n_ptiles = (int)((m + bp - 1) / bp);
+    if (big) return launch_big(a, d->dtype, bt, st, kname);
     if (d->dtype == PPN_F32) return launch_dtype<float>(a, smallc, tc, st, kname);
     return launch_dtype<__bf16>(a, smallc, tc, st, kname);
 }

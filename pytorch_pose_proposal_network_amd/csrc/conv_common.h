@@ -1,0 +1,109 @@
+// Shared device helpers of the fused implicit-GEMM convolution kernels (conv.hip, conv_big.hip).
+#pragma once
+#include <hip/hip_bf16.h>
+
+#include "common.h"
+
+namespace ppnconv {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+
+struct ConvKArgs {
+    const char* src;
+    const char* wgt;
+    const float* scale1;
+    const float* shift1;
+    const char* residual;
+    char* out_raw;
+    const float* scale2;
+    const float* shift2;
+    char* out_act;
+    const char* zero;
+    int B, H, W, Cin, Ho, Wo, Cout, ks, stride, dil, pad;
+    int Ktot;      // padded GEMM depth (multiple of BK)
+    int M;         // B*Ho*Wo
+    int HoWo;
+    int act1, act2, nchw;
+    int log2Cin;
+    int n_ctiles, n_ptiles;
+};
+
+template <typename T>
+struct Elem;
+template <>
+struct Elem<float> {
+    static constexpr int EPC = 4;  // elements per 16-byte chunk
+};
+template <>
+struct Elem<__bf16> {
+    static constexpr int EPC = 8;
+};
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    switch (act) {
+        case PPN_ACT_RELU: return v > 0.f ? v : 0.f;
+        case PPN_ACT_LRELU: return v > 0.f ? v : v * 0.1f;      // nn.LeakyReLU(0.1), model.py:88
+        case PPN_ACT_SIGMOID: return 1.0f / (1.0f + __expf(-v));
+        default: return v;
+    }
+}
+
+__device__ __forceinline__ void glds16(const char* gptr, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)gptr,
+                                     (void __attribute__((address_space(3)))*)lds_wave_base, 16, 0, 0);
+}
+
+// One K-substep (4 chunks = 128 B/4 of a row): acc += Wfrag x Xfrag
+__device__ __forceinline__ void mma_step(f32x4& acc, const f32x4& wf, const f32x4& xf, float*) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf.x, xf.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf.y, xf.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf.z, xf.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf.w, xf.w, acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma_step(f32x4& acc, const f32x4& wf, const f32x4& xf, __bf16*) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf), __builtin_bit_cast(bf16x8, xf),
+                                                  acc, 0, 0, 0);
+}
+
+template <typename T>
+__device__ __forceinline__ void load8(const char* p, float* v);
+template <>
+__device__ __forceinline__ void load8<float>(const char* p, float* v) {
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 16);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+template <>
+__device__ __forceinline__ void load8<__bf16>(const char* p, float* v) {
+    const uint4 a = *reinterpret_cast<const uint4*>(p);
+    const unsigned u[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        v[2 * i] = __uint_as_float(u[i] << 16);
+        v[2 * i + 1] = __uint_as_float(u[i] & 0xffff0000u);
+    }
+}
+template <typename T>
+__device__ __forceinline__ void store8(char* p, const float* v);
+template <>
+__device__ __forceinline__ void store8<float>(char* p, const float* v) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(p + 16) = make_float4(v[4], v[5], v[6], v[7]);
+}
+template <>
+__device__ __forceinline__ void store8<__bf16>(char* p, const float* v) {
+    bf16x8 o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (__bf16)v[i];                 // RNE, v_cvt_pk_bf16_f32
+    *reinterpret_cast<bf16x8*>(p) = o;
+}
+
+// conv_big.hip: 512-thread, (BP x BC) = ({128,192,256} x {128,256}) tiles for Cin % K-step == 0 layers
+struct BigTile {
+    int bp, bc;
+};
+bool big_tile_for(int cout, long long m, BigTile* out);
+int launch_big(const ConvKArgs& a, int dtype, BigTile t, hipStream_t st, const char** kname);
+
+}  // namespace ppnconv
