@@ -110,7 +110,7 @@ typedef struct ppn_conv_desc {
     int32_t act1, act2;
     int32_t out_nchw_f32;        /* 1: out_raw is f32 NCHW [B,cout,H,W] (the head, model.py:136)     */
     const void* src;             /* NHWC [B,in_h,in_w,cin] dtype                                      */
-    const void* weight;          /* packed [cout_pad][k_total] dtype, k = (ky*ksize+kx)*cin + ci      */
+    const void* weight;          /* packed [cout_pad][k_total] dtype, depth order per ppn_conv_tiling  */
     const float* scale1;         /* [cout] or NULL (=1)                                               */
     const float* shift1;         /* [cout] or NULL (=0)                                               */
     const void* residual;        /* NHWC [B,out_h,out_w,cout] dtype or NULL                           */
@@ -121,8 +121,14 @@ typedef struct ppn_conv_desc {
     const void* zero_page;       /* >= 256 B of zeros on device (padding source)                      */
 } ppn_conv_desc;
 
-/* GEMM-depth step / channel tile the packer must pad to for a conv of this shape and dtype. */
-int ppn_conv_tiling(int32_t dtype, int32_t cin, int32_t cout, int32_t ksize, int32_t* k_step, int32_t* cout_tile);
+/* GEMM-depth step / channel tile the packer must pad to for a conv of this shape and dtype, and the order of
+ * the GEMM depth index in the packed weight rows:
+ *   k_order 0:  k = (ky*ksize + kx)*cin + ci                      (tap-major)
+ *   k_order 1:  k = ((ci / k_step)*ksize*ksize + ky*ksize + kx)*k_step + ci % k_step
+ *               (channel-chunk-major: the 9 taps of one 64-channel slab are consecutive K steps, so the
+ *                shifted re-reads of an input row hit L2 instead of the Infinity Cache)                    */
+int ppn_conv_tiling(int32_t dtype, int32_t cin, int32_t cout, int32_t ksize, int32_t* k_step, int32_t* cout_tile,
+                    int32_t* k_order);
 
 int ppn_conv2d_fused(const ppn_conv_desc* d, void* stream);
 
@@ -156,9 +162,10 @@ int ppn_plan_size(const ppn_plan* p);
 const char* ppn_plan_kernel_name(const ppn_plan* p, int32_t i);
 int ppn_plan_destroy(ppn_plan* p);
 
-/* Weight packing: reference layout f32 [cout,cin,k,k] -> [cout_pad][k_total] dtype, zero padded. */
+/* Weight packing: reference layout f32 [cout,cin,k,k] -> [cout_pad][k_total] dtype, zero padded, with the
+ * depth order/step reported by ppn_conv_tiling. */
 int ppn_pack_weight(int32_t dtype, const float* w, int32_t cout, int32_t cin, int32_t ksize, int32_t cout_pad,
-                    int32_t k_total, void* out, void* stream);
+                    int32_t k_total, int32_t k_order, int32_t k_step, void* out, void* stream);
 
 #ifdef __cplusplus
 }

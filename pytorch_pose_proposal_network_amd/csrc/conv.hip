@@ -331,14 +331,21 @@ int ilog2_exact(int v) {
 // weight packing: [cout,cin,k,k] f32 -> [cout_pad][k_total] T with k = (ky*ks+kx)*cin + ci
 template <typename T>
 __global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ out, int cout, int cin, int ks,
-                                   int cout_pad, int ktot) {
+                                   int cout_pad, int ktot, int korder, int kstep) {
     const size_t n = (size_t)cout_pad * ktot;
+    const int ntaps = ks * ks;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const int co = (int)(i / ktot), k = (int)(i % ktot);
         float v = 0.f;
-        if (co < cout && k < ks * ks * cin) {
-            const int tap = k / cin, ci = k % cin;
-            v = w[((size_t)co * cin + ci) * ks * ks + tap];
+        if (co < cout && k < ntaps * cin) {
+            int tap, ci;
+            if (korder == 0) {
+                tap = k / cin; ci = k % cin;
+            } else {
+                const int blk = k / kstep, within = k % kstep;     // blk = cchunk*ntaps + tap
+                tap = blk % ntaps; ci = (blk / ntaps) * kstep + within;
+            }
+            v = w[((size_t)co * cin + ci) * ntaps + tap];
         }
         out[i] = (T)v;
     }
@@ -351,7 +358,7 @@ int conv_launch(const ppn_conv_desc* d, hipStream_t st, const char** kname);
 }
 
 extern "C" int ppn_conv_tiling(int32_t dtype, int32_t cin, int32_t cout, int32_t ksize, int32_t* k_step,
-                               int32_t* cout_tile) {
+                               int32_t* cout_tile, int32_t* k_order) {
     if (dtype != PPN_F32 && dtype != PPN_BF16) return ppn::fail(PPN_E_INVALID, "bad dtype %d", dtype);
     if (cin < 1 || cout < 1 || ksize < 1) return ppn::fail(PPN_E_INVALID, "bad conv shape");
     const int bk = dtype == PPN_F32 ? 32 : 64;
@@ -359,6 +366,7 @@ extern "C" int ppn_conv_tiling(int32_t dtype, int32_t cin, int32_t cout, int32_t
     BigTile bt;
     const bool big = (cin % bk == 0) && big_tile_for(cout, 1, &bt);
     if (cout_tile) *cout_tile = big ? bt.bc : choose_tile(cout).bc;
+    if (k_order) *k_order = big ? 1 : 0;
     return PPN_OK;
 }
 
@@ -423,18 +431,21 @@ extern "C" int ppn_conv2d_fused(const ppn_conv_desc* d, void* stream) {
 }
 
 extern "C" int ppn_pack_weight(int32_t dtype, const float* w, int32_t cout, int32_t cin, int32_t ksize,
-                               int32_t cout_pad, int32_t k_total, void* out, void* stream) {
+                               int32_t cout_pad, int32_t k_total, int32_t k_order, int32_t k_step, void* out,
+                               void* stream) {
     if (!w || !out || cout < 1 || cin < 1 || ksize < 1 || cout_pad < cout || k_total < ksize * ksize * cin)
         return ppn::fail(PPN_E_INVALID, "ppn_pack_weight: bad arguments");
+    if (k_order != 0 && (k_order != 1 || k_step < 1 || cin % k_step != 0))
+        return ppn::fail(PPN_E_INVALID, "ppn_pack_weight: k_order %d needs cin %% k_step == 0", k_order);
     const size_t n = (size_t)cout_pad * k_total;
     const int blocks = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (dtype == PPN_F32)
         hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(blocks), dim3(256), 0, st, w, static_cast<float*>(out), cout,
-                           cin, ksize, cout_pad, k_total);
+                           cin, ksize, cout_pad, k_total, k_order, k_step);
     else if (dtype == PPN_BF16)
         hipLaunchKernelGGL(pack_weight_kernel<__bf16>, dim3(blocks), dim3(256), 0, st, w, static_cast<__bf16*>(out),
-                           cout, cin, ksize, cout_pad, k_total);
+                           cout, cin, ksize, cout_pad, k_total, k_order, k_step);
     else
         return ppn::fail(PPN_E_INVALID, "bad dtype %d", dtype);
     PPN_LAUNCH_CHECK();

@@ -4,21 +4,39 @@
 //
 // Why a second kernel: on gfx950 a CU's global->LDS fill path moves ~64 B/clk while its four SIMDs retire
 // 4 x 1024 bf16 FLOP/clk, so a 128x128x64 tile (64 FLOP per staged byte) is fill-bound at ~1/3 of the MFMA
-// peak.  A (BP x 256) tile with 8 waves doubles the FLOPs per staged byte:
-//   workgroup  512 threads = 8 waves as WC x WP (channels x pixels), one workgroup per CU
+// peak, and two waves per SIMD running the same barrier-paced program contend for the VALU/MFMA issue in
+// lockstep.  This kernel therefore gives every SIMD exactly ONE wave with the whole 512-register file:
+//   workgroup  256 threads = 4 waves as 2 (channels) x 2 (pixels), one workgroup per CU
 //   tile       BP in {128,192,256} pixels x BC in {128,256} channels x 64 (bf16) / 32 (f32) deep
+//   wave       (BC/2) x (BP/2) outputs = up to 8x8 MFMA 16x16 tiles (256 accumulator registers)
 //   LDS        2 stages x (BP+BC) x 128 B (<= 128 KiB), rows XOR-swizzled through the SOURCE address
-//   wave       (BC/WC) x (BP/WP) outputs in 16x16 MFMA tiles, weights = A operand, pixels = B operand
-// BP is picked per layer so that the number of workgroups is close to a multiple of the 256 CUs
-// (e.g. 192 px x 256 ch on the 48x48x512 layers at batch 32: 768 workgroups = 3 full rounds).
-// Epilogue straight from the accumulators: each lane owns 4 consecutive channels of one pixel.
+//   loads      buffer_load ... lds (LDS-DMA) through raw buffer descriptors: per-lane 32-bit offsets, the
+//              K-step offset of the weight stream in SGPRs, and padded taps expressed as an OUT-OF-RANGE
+//              offset, which the hardware range check turns into zeros in LDS (tools/probes/buf_lds_oob.hip)
+// BP is picked per layer so that the number of workgroups is close to a multiple of the 256 CUs.
+// K loop: two named fragment sets; the MFMAs of one set cover the LDS reads of the other and the DMA issue
+// of the next stage, so the matrix pipe restarts immediately after the per-step barrier.
+// Epilogue through LDS in 64-pixel (NHWC) / 64-channel (NCHW head) chunks: 16-byte coalesced stores.
 #include <type_traits>
+#include <utility>
 
 #include "conv_common.h"
 
 namespace {
 
 using namespace ppnconv;
+
+constexpr unsigned kOOB = 0x80000000u;   // byte offset beyond any tensor this kernel accepts (< 2 GiB)
+
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>)
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
 
 template <typename T>
 __device__ __forceinline__ void load4(const char* p, float* v);
@@ -48,20 +66,27 @@ __device__ __forceinline__ void store4<__bf16>(char* p, const float* v) {
     *reinterpret_cast<bf16x4*>(p) = o;
 }
 
-template <typename T, int BP, int BC, int WP, int WC>
-__global__ void __launch_bounds__(512, 2) conv_igemm_big_kernel(ConvKArgs a) {
+__device__ __forceinline__ void bufload_lds16(__amdgpu_buffer_rsrc_t rsrc, char* lds_wave_base, unsigned voff,
+                                              unsigned soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (void __attribute__((address_space(3)))*)lds_wave_base, 16, voff,
+                                             soff, 0, 0);
+}
+
+template <typename T, int BP, int BC>
+__global__ void __launch_bounds__(256, 1) conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
     constexpr int EPC = Elem<T>::EPC;
     constexpr int BK = 8 * EPC;
     constexpr int ES = sizeof(T);
-    constexpr int NXI = BP / 64, NWI = BC / 64;                    // load instructions per thread and K step
-    constexpr int TP = BP / WP / 16, TC = BC / WC / 16;
+    constexpr int NXI = BP / 32, NWI = BC / 32;                    // load instructions per thread and K step
+    constexpr int TP = BP / 2 / 16, TC = BC / 2 / 16;              // 16x16 tiles per wave
     constexpr int STAGE = (BP + BC) * 128;
-    static_assert(WP * WC == 8, "8 waves");
-    static_assert(BP % 64 == 0 && BC % 64 == 0 && (BP / WP) % 16 == 0 && (BC / WC) % 16 == 0, "tile shape");
+    static_assert(BP % 32 == 0 && BC % 32 == 0, "tile shape");
+    static_assert(TP <= 8 && TC <= 8, "accumulators must fit the register file");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wc = wave / WP, wp = wave % WP;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wc = wave >> 1, wp = wave & 1;
 
     int ptile, ctile;
     {
@@ -73,21 +98,25 @@ __global__ void __launch_bounds__(512, 2) conv_igemm_big_kernel(ConvKArgs a) {
     }
     const int m0 = ptile * BP, c0 = ctile * BC;
 
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.src, 0, src_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.wgt, 0, wgt_bytes, 0x00020000);
+
+    // ---- per-lane loader state: 32-bit byte offsets ----------------------------------------------
     const int lrow = lane >> 3;
     const int chunk = (lane & 7) ^ (((lane >> 4) & 3) | ((wave & 1) << 2));
     const int ntaps = a.ks * a.ks;
-    int xbase[NXI];
+    int xbase[NXI];          // byte offset of (pixel row, tap 0, ci 0, this lane's chunk); may be negative
     unsigned xmask[NXI];
 #pragma unroll
     for (int j = 0; j < NXI; ++j) {
-        const int row = (j * 8 + wave) * 8 + lrow;
+        const int row = (j * 4 + wave) * 8 + lrow;
         const int m = m0 + row;
         const bool vm = m < a.M;
         const int mm = vm ? m : 0;
         const int b = mm / a.HoWo, rem = mm - b * a.HoWo;
         const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
         const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
-        xbase[j] = ((b * a.H + iy0) * a.W + ix0) * a.Cin + chunk * EPC;
+        xbase[j] = (((b * a.H + iy0) * a.W + ix0) * a.Cin + chunk * EPC) * ES;
         unsigned mk = 0;
         for (int t = 0; t < ntaps; ++t) {
             const int dy = t / a.ks, dx = t - dy * a.ks;
@@ -96,41 +125,62 @@ __global__ void __launch_bounds__(512, 2) conv_igemm_big_kernel(ConvKArgs a) {
         }
         xmask[j] = mk;
     }
-    const char* wptr[NWI];
+    unsigned woff[NWI];
 #pragma unroll
     for (int j = 0; j < NWI; ++j) {
-        const int row = (j * 8 + wave) * 8 + lrow;
-        wptr[j] = a.wgt + ((size_t)(c0 + row) * a.Ktot + chunk * EPC) * ES;
+        const int row = (j * 4 + wave) * 8 + lrow;
+        woff[j] = (unsigned)(((size_t)(c0 + row) * a.Ktot + chunk * EPC) * ES);
     }
 
     const int nsteps = a.Ktot / BK;
-    int u_tap = 0, u_ci0 = 0, u_dy = 0, u_dx = 0;
-    auto issue_loads = [&](int step, int buf) {
+    // Wave-uniform K iteration state, advanced incrementally so the loop keeps only a handful of SGPRs live
+    // (depth order 1 of ppn_conv_tiling: taps innermost, then the next BK-channel slab).
+    const int dx_bytes = a.dil * a.Cin * ES;                        // one tap to the right
+    const int dy_bytes = a.dil * a.W * a.Cin * ES - a.ks * dx_bytes; // next tap row, back to dx = 0
+    const int ksz = a.ks;
+    int u_tap = 0, u_dx = 0, u_slab = 0, tapoff = 0;
+    unsigned tapbit = 1u;                                           // 0 once past the last K step
+    unsigned ksoff = 0;
+    bool live = true;
+    int ld_step = 0;
+    auto advance = [&]() {
+        ++ld_step;
+        live = ld_step < nsteps;
+        ksoff = live ? ksoff + BK * ES : 0u;
+        ++u_tap; ++u_dx;
+        tapoff += dx_bytes;
+        const bool wrapx = u_dx == ksz;
+        u_dx = wrapx ? 0 : u_dx;
+        tapoff += wrapx ? dy_bytes : 0;
+        const bool wrapt = u_tap == ntaps;
+        u_tap = wrapt ? 0 : u_tap;
+        u_slab += wrapt ? BK * ES : 0;
+        tapoff = wrapt ? u_slab : tapoff;
+        tapbit = live ? (1u << u_tap) : 0u;
+    };
+    // one LDS-DMA instruction of the stage being loaded: g < NXI activation rows, else weight rows.
+    // Past the last K step every offset is out of range (zero fill, no memory traffic); the SGPR offset is
+    // not part of the hardware range check, so "dead" goes through the VGPR offset.
+    auto issue_one = [&](auto gc, int buf) {
+        constexpr int g = decltype(gc)::value;
         char* xs = smem + buf * STAGE;
-        char* ws = xs + BP * 128;
-        const int tapoff = (u_dy * a.dil * a.W + u_dx * a.dil) * a.Cin + u_ci0;
-#pragma unroll
-        for (int j = 0; j < NXI; ++j) {
-            const bool ok = (xmask[j] >> u_tap) & 1u;
-            const char* g = ok ? a.src + (ptrdiff_t)(xbase[j] + tapoff) * ES : a.zero;
-            glds16(g, xs + (j * 8 + wave) * 1024);
-        }
-#pragma unroll
-        for (int j = 0; j < NWI; ++j) glds16(wptr[j] + (size_t)step * BK * ES, ws + (j * 8 + wave) * 1024);
-        u_ci0 += BK;
-        if (u_ci0 >= a.Cin) {
-            u_ci0 = 0; ++u_tap; ++u_dx;
-            if (u_dx == a.ks) { u_dx = 0; ++u_dy; }
+        if constexpr (g < NXI) {
+            const unsigned voff = (xmask[g] & tapbit) ? (unsigned)(xbase[g] + tapoff) : kOOB;
+            bufload_lds16(xrs, xs + (g * 4 + wave) * 1024, voff, 0);
+        } else {
+            constexpr int j = g - NXI;
+            bufload_lds16(wrs, xs + BP * 128 + (j * 4 + wave) * 1024, live ? woff[j] : kOOB, ksoff);
         }
     };
+    constexpr int NL = NXI + NWI;                                    // LDS-DMA instructions per stage and thread
 
     const int frow = lane & 15, fq = lane >> 4;
     const int fswz = (frow >> 1) & 7;
     int foff[2];
     foff[0] = frow * 128 + (((0 + fq) ^ fswz) << 4);
     foff[1] = frow * 128 + (((4 + fq) ^ fswz) << 4);
-    const int x_tile_off = wp * (BP / WP) * 128;
-    const int w_tile_off = BP * 128 + wc * (BC / WC) * 128;
+    const int x_tile_off = wp * (BP / 2) * 128;
+    const int w_tile_off = BP * 128 + wc * (BC / 2) * 128;
 
     f32x4 acc[TC][TP];
 #pragma unroll
@@ -138,110 +188,214 @@ __global__ void __launch_bounds__(512, 2) conv_igemm_big_kernel(ConvKArgs a) {
 #pragma unroll
         for (int j = 0; j < TP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    issue_loads(0, 0);
+    // Two named fragment sets (A, B): while the MFMAs of one set issue, the other set is being read.
+    f32x4 wA[TC], xA[TP], wB[TC], xB[TP];
+    constexpr int NRD = TC + TP;                                     // ds_read_b128 per fragment set
+    auto read_one = [&](auto rc, f32x4 (&wf)[TC], f32x4 (&xf)[TP], int buf, int ks) {
+        constexpr int r = decltype(rc)::value;
+        if constexpr (r < TP)
+            xf[r] = *reinterpret_cast<const f32x4*>(smem + buf * STAGE + x_tile_off + foff[ks] + r * 16 * 128);
+        else
+            wf[r - TP] = *reinterpret_cast<const f32x4*>(smem + buf * STAGE + w_tile_off + foff[ks] + (r - TP) * 16 * 128);
+    };
+    // MFMA group: 4 consecutive output tiles of the wave (flat index = i*TP + j)
+    constexpr int NG = TC * TP / 4;
+    auto mma_group = [&](auto gc, const f32x4 (&wf)[TC], const f32x4 (&xf)[TP]) {
+        constexpr int g = decltype(gc)::value;
+        static_for<4>([&](auto tc) {
+            constexpr int idx = g * 4 + decltype(tc)::value;
+            mma_step(acc[idx / TP][idx % TP], wf[idx / TP], xf[idx % TP], (T*)nullptr);
+        });
+    };
+    constexpr int RPG = (NRD + NG - 1) / NG;                         // LDS reads per MFMA group
+    constexpr int LPG = (NL + NG - 1) / NG;                          // DMA issues per MFMA group
+
+    // ---- prologue: stage 0 -> LDS, both fragment sets of stage 0, stage 1 in flight --------------
+    static_for<NL>([&](auto gc) { issue_one(gc, 0); });
+    advance();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (int s = 0; s < nsteps; ++s) {
+    static_for<NRD>([&](auto rc) { read_one(rc, wA, xA, 0, 0); });
+    static_for<NRD>([&](auto rc) { read_one(rc, wB, xB, 0, 1); });
+    static_for<NL>([&](auto gc) { issue_one(gc, 1); });
+    advance();
+    static_for<NG>([&](auto gc) { mma_group(gc, wA, xA); });
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // ---- steady state -----------------------------------------------------------------------------
+    // entering step s: set B holds (s-1, second half); stage s is complete in buffer s&1; the other buffer
+    // is free.  The MFMAs of set B start right after the barrier; between groups of 4 MFMAs the wave issues
+    // the DMA of stage s+1 and the LDS reads of set A (order pinned with sched_barrier so neither clusters);
+    // then the MFMAs of set A cover the reads of the new set B and the scalar bookkeeping of the next step.
+    for (int s = 1; s < nsteps; ++s) {
         const int buf = s & 1;
-        if (s + 1 < nsteps) issue_loads(s + 1, buf ^ 1);
-        const char* xs = smem + buf * STAGE + x_tile_off;
-        const char* ws = smem + buf * STAGE + w_tile_off;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            f32x4 wf[TC], xf[TP];
-#pragma unroll
-            for (int j = 0; j < TP; ++j) xf[j] = *reinterpret_cast<const f32x4*>(xs + j * 16 * 128 + foff[ks]);
-#pragma unroll
-            for (int i = 0; i < TC; ++i) wf[i] = *reinterpret_cast<const f32x4*>(ws + i * 16 * 128 + foff[ks]);
-#pragma unroll
-            for (int i = 0; i < TC; ++i)
-#pragma unroll
-                for (int j = 0; j < TP; ++j) mma_step(acc[i][j], wf[i], xf[j], (T*)nullptr);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        static_for<NG>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            mma_group(gc, wB, xB);
+            static_for<LPG>([&](auto lc) {
+                constexpr int l = g * LPG + decltype(lc)::value;
+                if constexpr (l < NL) issue_one(std::integral_constant<int, l>{}, buf ^ 1);
+            });
+            static_for<RPG>([&](auto rc) {
+                constexpr int r = g * RPG + decltype(rc)::value;
+                if constexpr (r < NRD) read_one(std::integral_constant<int, r>{}, wA, xA, buf, 0);
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        advance();
+        static_for<NG>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            mma_group(gc, wA, xA);
+            static_for<RPG>([&](auto rc) {
+                constexpr int r = g * RPG + decltype(rc)::value;
+                if constexpr (r < NRD) read_one(std::integral_constant<int, r>{}, wB, xB, buf, 1);
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __syncthreads();
     }
+    static_for<NG>([&](auto gc) { mma_group(gc, wB, xB); });
+    __syncthreads();                                                 // LDS is reused by the epilogue
 
-    // ---- epilogue straight from the accumulators -------------------------------------------------
-    // lane: pixel = tile column frow, channels 4*fq .. 4*fq+3 of channel tile i
-    // (generic lambda over a compile-time pixel-tile index keeps every acc[][] access static: a runtime j
-    //  would push the accumulators through scratch memory)
-    auto epilogue_col = [&](auto jc) {
-        constexpr int j = decltype(jc)::value;
-        const int m = m0 + wp * (BP / WP) + j * 16 + frow;
-        const bool mvalid = m < a.M;
-        int nb = 0, np = 0;
-        if (a.nchw) { nb = m / a.HoWo; np = m - nb * a.HoWo; }
+    // ---- epilogue through LDS chunks of 64 pixels (NHWC) / 64 channels (NCHW head) -------------------
+    float* ct = reinterpret_cast<float*>(smem);
+    if (!a.nchw) {
+        constexpr int LD = BC + 4;                                   // [pixel][channel] f32, 64 pixels per chunk
+        constexpr int JC = 2;                                        // pixel tiles per wave and chunk
+        constexpr int TPP = BC / 8, PPP = 256 / TPP;                 // threads per pixel, pixels per pass
+        static_assert(TP % JC == 0, "pixel tiles per wave must be even");
+        const int cg = tid % TPP, prow = tid / TPP;
+        const int c = c0 + cg * 8;
+        float s1[8], b1[8], s2[8], b2[8];
 #pragma unroll
-        for (int i = 0; i < TC; ++i) {
-            const int c = c0 + wc * (BC / WC) + i * 16 + 4 * fq;
-            float v[4] = {acc[i][j].x, acc[i][j].y, acc[i][j].z, acc[i][j].w};
-            if (!mvalid || c >= a.Cout) {
-                // nothing to store for this fragment
-            } else if (!a.nchw) {
-                // NHWC: cout % 8 == 0, so the 4 channels are all valid
-                if (a.scale1) {
-                    const float4 s = *reinterpret_cast<const float4*>(a.scale1 + c);
-                    v[0] *= s.x; v[1] *= s.y; v[2] *= s.z; v[3] *= s.w;
+        for (int i = 0; i < 8; ++i) {
+            const bool cv = c + i < a.Cout;
+            s1[i] = (a.scale1 && cv) ? a.scale1[c + i] : 1.f;
+            b1[i] = (a.shift1 && cv) ? a.shift1[c + i] : 0.f;
+            s2[i] = (a.scale2 && cv) ? a.scale2[c + i] : 1.f;
+            b2[i] = (a.shift2 && cv) ? a.shift2[c + i] : 0.f;
+        }
+        auto chunk = [&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+#pragma unroll
+            for (int jj = 0; jj < JC; ++jj)
+#pragma unroll
+                for (int i = 0; i < TC; ++i) {
+                    const int px = (wp * JC + jj) * 16 + frow;
+                    const int ch = wc * (BC / 2) + i * 16 + 4 * fq;
+                    *reinterpret_cast<f32x4*>(ct + px * LD + ch) = acc[i][q * JC + jj];
                 }
-                if (a.shift1) {
-                    const float4 s = *reinterpret_cast<const float4*>(a.shift1 + c);
-                    v[0] += s.x; v[1] += s.y; v[2] += s.z; v[3] += s.w;
-                }
+            __syncthreads();
+            if (c < a.Cout) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], a.act1);
-                const size_t off = ((size_t)m * a.Cout + c) * ES;
-                if (a.residual) {
-                    float rr[4];
-                    load4<T>(a.residual + off, rr);
+                for (int pass = 0; pass < (2 * JC * 16) / PPP; ++pass) {
+                    const int px = pass * PPP + prow;                // 0 .. 2*JC*16-1
+                    const int pw = px / (JC * 16), pj = (px / 16) % JC, pr = px % 16;
+                    const int m = m0 + pw * (BP / 2) + (q * JC + pj) * 16 + pr;
+                    if (m < a.M) {
+                        float v[8];
+                        const f32x4 lo = *reinterpret_cast<const f32x4*>(ct + px * LD + cg * 8);
+                        const f32x4 hi = *reinterpret_cast<const f32x4*>(ct + px * LD + cg * 8 + 4);
+                        v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w;
+                        v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+                        const size_t off = ((size_t)m * a.Cout + c) * ES;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += rr[r];
-                }
-                if (a.out_raw) store4<T>(a.out_raw + off, v);
-                if (a.out_act) {
-                    float u[4] = {v[0], v[1], v[2], v[3]};
-                    if (a.scale2) {
-                        const float4 s = *reinterpret_cast<const float4*>(a.scale2 + c);
-                        const float4 t = *reinterpret_cast<const float4*>(a.shift2 + c);
-                        u[0] = u[0] * s.x + t.x; u[1] = u[1] * s.y + t.y; u[2] = u[2] * s.z + t.z; u[3] = u[3] * s.w + t.w;
-                    }
+                        for (int i = 0; i < 8; ++i) v[i] = apply_act(v[i] * s1[i] + b1[i], a.act1);
+                        if (a.residual) {
+                            float r[8];
+                            load8<T>(a.residual + off, r);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) u[r] = apply_act(u[r], a.act2);
-                    store4<T>(a.out_act + off, u);
-                }
-            } else {
-                // head: f32 NCHW, per channel 16 lanes write 16 consecutive pixels (64 B)
-                float* out = reinterpret_cast<float*>(a.out_raw);
+                            for (int i = 0; i < 8; ++i) v[i] += r[i];
+                        }
+                        if (a.out_raw) store8<T>(a.out_raw + off, v);
+                        if (a.out_act) {
+                            float u[8];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int cc = c + r;
-                    if (cc < a.Cout) {
-                        const float s1 = a.scale1 ? a.scale1[cc] : 1.f, b1 = a.shift1 ? a.shift1[cc] : 0.f;
-                        out[((size_t)nb * a.Cout + cc) * a.HoWo + np] = apply_act(v[r] * s1 + b1, a.act1);
+                            for (int i = 0; i < 8; ++i) u[i] = apply_act(v[i] * s2[i] + b2[i], a.act2);
+                            store8<T>(a.out_act + off, u);
+                        }
                     }
                 }
             }
-        }
-    };
-    epilogue_col(std::integral_constant<int, 0>{});
-    if constexpr (TP > 1) epilogue_col(std::integral_constant<int, 1>{});
-    if constexpr (TP > 2) epilogue_col(std::integral_constant<int, 2>{});
-    if constexpr (TP > 3) epilogue_col(std::integral_constant<int, 3>{});
-    static_assert(TP <= 4, "epilogue handles up to 4 pixel tiles per wave");
+            __syncthreads();
+        };
+        chunk(std::integral_constant<int, 0>{});
+        if constexpr (TP / JC > 1) chunk(std::integral_constant<int, 1>{});
+        if constexpr (TP / JC > 2) chunk(std::integral_constant<int, 2>{});
+        if constexpr (TP / JC > 3) chunk(std::integral_constant<int, 3>{});
+    } else {
+        // head: f32 NCHW [B, Cout, Ho*Wo] (model.py:136): 64 channels per chunk, pixel-contiguous rows
+        constexpr int LD = BP + 4;                                   // [channel][pixel] f32
+        constexpr int IC = 2;                                        // channel tiles per wave and chunk
+        constexpr int TPC = BP / 4;                                  // threads per channel row (4 pixels each)
+        constexpr int NITEM = 2 * IC * 16 * TPC;                     // (channel row, pixel quad) items per chunk
+        static_assert(TC % IC == 0, "channel tiles per wave must be even");
+        float* out = reinterpret_cast<float*>(a.out_raw);
+        const bool vec = (a.HoWo & 3) == 0;
+        auto chunk = [&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+#pragma unroll
+            for (int ii = 0; ii < IC; ++ii)
+#pragma unroll
+                for (int j = 0; j < TP; ++j) {
+                    const int px = wp * (BP / 2) + j * 16 + frow;
+                    const int ch = (wc * IC + ii) * 16 + 4 * fq;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ct[(ch + r) * LD + px] = acc[q * IC + ii][j][r];
+                }
+            __syncthreads();
+            for (int item = tid; item < NITEM; item += 256) {
+                const int chl = item / TPC, pq = item - chl * TPC;   // 0 .. 2*IC*16-1
+                const int cw = chl / (IC * 16), ci = (chl / 16) % IC, cr = chl % 16;
+                const int c = c0 + cw * (BC / 2) + (q * IC + ci) * 16 + cr;
+                const int m = m0 + 4 * pq;
+                if (c < a.Cout && m < a.M) {
+                    const float s1 = a.scale1 ? a.scale1[c] : 1.f, b1 = a.shift1 ? a.shift1[c] : 0.f;
+                    const f32x4 t4 = *reinterpret_cast<const f32x4*>(ct + chl * LD + 4 * pq);
+                    float v[4] = {t4.x, t4.y, t4.z, t4.w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = apply_act(v[i] * s1 + b1, a.act1);
+                    if (vec) {
+                        const int nb = m / a.HoWo, np = m - nb * a.HoWo;
+                        *reinterpret_cast<float4*>(out + ((size_t)nb * a.Cout + c) * a.HoWo + np) =
+                            make_float4(v[0], v[1], v[2], v[3]);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int mi = m + i;
+                            if (mi < a.M) {
+                                const int bi = mi / a.HoWo, pi = mi - bi * a.HoWo;
+                                out[((size_t)bi * a.Cout + c) * a.HoWo + pi] = v[i];
+                            }
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        };
+        chunk(std::integral_constant<int, 0>{});
+        if constexpr (TC / IC > 1) chunk(std::integral_constant<int, 1>{});
+        if constexpr (TC / IC > 2) chunk(std::integral_constant<int, 2>{});
+        if constexpr (TC / IC > 3) chunk(std::integral_constant<int, 3>{});
+    }
 }
 
-template <typename T, int BP, int BC, int WP, int WC>
+template <typename T, int BP, int BC>
 int launch_one(const ConvKArgs& a, hipStream_t st, const char** kname) {
     constexpr size_t lds = 2 * (size_t)(BP + BC) * 128;
     static char name[96];
     if (!name[0])
-        snprintf(name, sizeof(name), "conv_igemm_big_kernel<%s, %d, %d, %d, %d>", sizeof(T) == 4 ? "float" : "__bf16",
-                 BP, BC, WP, WC);
+        snprintf(name, sizeof(name), "conv_igemm_big_kernel<%s, %d, %d>", sizeof(T) == 4 ? "float" : "__bf16", BP, BC);
     if (kname) *kname = name;
-    auto k = conv_igemm_big_kernel<T, BP, BC, WP, WC>;
+    const size_t src_bytes = (size_t)a.B * a.H * a.W * a.Cin * sizeof(T);
+    const size_t wgt_bytes = (size_t)a.n_ctiles * BC * a.Ktot * sizeof(T);
+    auto k = conv_igemm_big_kernel<T, BP, BC>;
     PPN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)lds));
-    hipLaunchKernelGGL(k, dim3(a.n_ctiles * a.n_ptiles), dim3(512), lds, st, a);
+    hipLaunchKernelGGL(k, dim3(a.n_ctiles * a.n_ptiles), dim3(256), lds, st, a, (unsigned)src_bytes,
+                       (unsigned)wgt_bytes);
     PPN_LAUNCH_CHECK();
     return PPN_OK;
 }
@@ -249,13 +403,13 @@ int launch_one(const ConvKArgs& a, hipStream_t st, const char** kname) {
 template <typename T>
 int launch_T(const ConvKArgs& a, BigTile t, hipStream_t st, const char** kname) {
     if (t.bc == 256) {
-        if (t.bp == 256) return launch_one<T, 256, 256, 4, 2>(a, st, kname);
-        if (t.bp == 192) return launch_one<T, 192, 256, 4, 2>(a, st, kname);
-        return launch_one<T, 128, 256, 4, 2>(a, st, kname);
+        if (t.bp == 256) return launch_one<T, 256, 256>(a, st, kname);
+        if (t.bp == 192) return launch_one<T, 192, 256>(a, st, kname);
+        return launch_one<T, 128, 256>(a, st, kname);
     }
-    if (t.bp == 256) return launch_one<T, 256, 128, 4, 2>(a, st, kname);
-    if (t.bp == 192) return launch_one<T, 192, 128, 4, 2>(a, st, kname);
-    return launch_one<T, 128, 128, 4, 2>(a, st, kname);
+    if (t.bp == 256) return launch_one<T, 256, 128>(a, st, kname);
+    if (t.bp == 192) return launch_one<T, 192, 128>(a, st, kname);
+    return launch_one<T, 128, 128>(a, st, kname);
 }
 
 }  // namespace
@@ -272,7 +426,7 @@ bool big_tile_for(int cout, long long m, BigTile* out) {
     for (int bp : {256, 192, 128}) {
         const long long tiles = ((m + bp - 1) / bp) * nct;
         const long long rounds = (tiles + 255) / 256;
-        // time ~ rounds * (work per tile + fixed cost per K loop pass); smaller tiles stage more bytes per FLOP
+        // time ~ rounds * (work per tile); smaller tiles stage more bytes per FLOP
         const double eff = bp == 256 ? 1.0 : (bp == 192 ? 0.95 : 0.85);
         const double cost = (double)rounds * bp / eff;
         if (cost < best) { best = cost; best_bp = bp; }
@@ -283,6 +437,10 @@ bool big_tile_for(int cout, long long m, BigTile* out) {
 }
 
 int launch_big(const ConvKArgs& a, int dtype, BigTile t, hipStream_t st, const char** kname) {
+    // buffer descriptors address up to 2 GiB with the out-of-range marker used for padding
+    const size_t es = dtype == PPN_F32 ? 4 : 2;
+    if ((size_t)a.B * a.H * a.W * a.Cin * es >= 0x7fffff00ull || (size_t)a.n_ctiles * t.bc * a.Ktot * es >= 0x7fffff00ull)
+        return ppn::fail(PPN_E_UNSUPPORTED, "tensor too large for the buffer-addressed conv kernel");
     if (dtype == PPN_F32) return launch_T<float>(a, t, st, kname);
     return launch_T<__bf16>(a, t, st, kname);
 }

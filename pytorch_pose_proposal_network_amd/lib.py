@@ -52,7 +52,7 @@ _SIGNATURES = {
     "ppn_nms": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_int32, C.c_void_p, C.c_void_p,
                           C.c_void_p]),
     "ppn_conv_tiling": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32),
-                                  C.POINTER(C.c_int32)]),
+                                  C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "ppn_conv2d_fused": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     "ppn_stem7x7": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32] +
                     [C.c_void_p] * 3 + [C.POINTER(C.c_float)] * 2 + [C.c_void_p, C.c_void_p]),
@@ -67,7 +67,7 @@ _SIGNATURES = {
     "ppn_plan_kernel_name": (C.c_char_p, [C.c_void_p, C.c_int32]),
     "ppn_plan_destroy": (C.c_int, [C.c_void_p]),
     "ppn_pack_weight": (C.c_int, [C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
-                                  C.c_void_p, C.c_void_p]),
+                                  C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
 }
 
 EXPORTS = tuple(_SIGNATURES)
@@ -102,6 +102,16 @@ def check(rc: int, what: str = ""):
     if rc != 0:
         msg = load().ppn_last_error()
         raise PPNError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+
+def conv_tiling(dtype: int, cin: int, cout: int, ksize: int):
+    """(k_step, cout_tile, k_order, k_total, cout_pad) for a conv of this shape."""
+    ks, ct, ko = C.c_int32(), C.c_int32(), C.c_int32()
+    check(load().ppn_conv_tiling(dtype, cin, cout, ksize, C.byref(ks), C.byref(ct), C.byref(ko)), "ppn_conv_tiling")
+    kreal = ksize * ksize * cin
+    ktot = (kreal + ks.value - 1) // ks.value * ks.value
+    cpad = (cout + ct.value - 1) // ct.value * ct.value
+    return ks.value, ct.value, ko.value, ktot, cpad
 
 
 def current_stream_ptr() -> int:

@@ -159,16 +159,11 @@ class PoseProposalNet:
             if op.k == 7:                                     # stem keeps the reference layout in f32
                 self._dev[op.name + ".w"] = w.to(dev)
                 continue
-            kstep, ctile = C.c_int32(), C.c_int32()
-            L.check(lib.ppn_conv_tiling(self.compute_dtype, op.cin, op.cout, op.k, C.byref(kstep), C.byref(ctile)),
-                    "ppn_conv_tiling")
-            kreal = op.k * op.k * op.cin
-            ktot = (kreal + kstep.value - 1) // kstep.value * kstep.value
-            cpad = (op.cout + ctile.value - 1) // ctile.value * ctile.value
+            kstep, _, korder, ktot, cpad = L.conv_tiling(self.compute_dtype, op.cin, op.cout, op.k)
             wd = w.to(dev)
             packed = torch.empty(cpad, ktot, dtype=tdt, device=dev)
             L.check(lib.ppn_pack_weight(self.compute_dtype, wd.data_ptr(), op.cout, op.cin, op.k, cpad, ktot,
-                                        packed.data_ptr(), stream), "ppn_pack_weight")
+                                        korder, kstep, packed.data_ptr(), stream), "ppn_pack_weight")
             self._dev[op.name + ".w"] = packed
             self._dev[op.name + ".geom"] = (ktot, cpad)
         torch.cuda.synchronize(dev)

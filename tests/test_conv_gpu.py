@@ -29,14 +29,11 @@ def run_conv(x, w, dtype, stride=1, dil=1, pad=0, s1=None, b1=None, act1=0, resi
     Cout, _, k, _ = w.shape
     eff = dil * (k - 1) + 1
     Ho, Wo = (H + 2 * pad - eff) // stride + 1, (W + 2 * pad - eff) // stride + 1
-    kstep, ctile = C.c_int32(), C.c_int32()
-    L.check(lib.ppn_conv_tiling(dtype, Cin, Cout, k, C.byref(kstep), C.byref(ctile)))
-    ktot = (k * k * Cin + kstep.value - 1) // kstep.value * kstep.value
-    cpad = (Cout + ctile.value - 1) // ctile.value * ctile.value
+    kstep, _, korder, ktot, cpad = L.conv_tiling(dtype, Cin, Cout, k)
     st = torch.cuda.current_stream().cuda_stream
     wd = w.contiguous().to(dev)
     packed = torch.empty(cpad, ktot, dtype=tdt, device=dev)
-    L.check(lib.ppn_pack_weight(dtype, wd.data_ptr(), Cout, Cin, k, cpad, ktot, packed.data_ptr(), st))
+    L.check(lib.ppn_pack_weight(dtype, wd.data_ptr(), Cout, Cin, k, cpad, ktot, korder, kstep, packed.data_ptr(), st))
     xs = x.permute(0, 2, 3, 1).contiguous().to(dev, tdt)
     zero = torch.zeros(64, device=dev)
     keep = [wd, packed, xs, zero]

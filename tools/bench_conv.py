@@ -35,10 +35,7 @@ def main():
             continue
         pad = d * (k - 1) // 2
         Ho = (H + 2 * pad - d * (k - 1) - 1) // s + 1
-        kstep, ctile = C.c_int32(), C.c_int32()
-        L.check(lib.ppn_conv_tiling(dtype, cin, cout, k, C.byref(kstep), C.byref(ctile)))
-        ktot = (k * k * cin + kstep.value - 1) // kstep.value * kstep.value
-        cpad = (cout + ctile.value - 1) // ctile.value * ctile.value
+        kstep, _, korder, ktot, cpad = L.conv_tiling(dtype, cin, cout, k)
         x = torch.randn(B, H, H, cin, device=dev).to(tdt)
         w = (torch.randn(cpad, ktot, device=dev) * 0.02).to(tdt)
         nchw = cout == 7605
