@@ -17,6 +17,7 @@
 // K loop: two named fragment sets; the MFMAs of one set cover the LDS reads of the other and the DMA issue
 // of the next stage, so the matrix pipe restarts immediately after the per-step barrier.
 // Epilogue through LDS in 64-pixel (NHWC) / 64-channel (NCHW head) chunks: 16-byte coalesced stores.
+#include <cstdlib>
 #include <type_traits>
 #include <utility>
 
@@ -72,21 +73,26 @@ __device__ __forceinline__ void bufload_lds16(__amdgpu_buffer_rsrc_t rsrc, char*
                                              soff, 0, 0);
 }
 
-template <typename T, int BP, int BC>
-__global__ void __launch_bounds__(256, 1) conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
+// NW waves per workgroup as 2 (channels) x NW/2 (pixels): NW = 4 -> one wave per SIMD with 8x8 MFMA tiles,
+// NW = 8 -> two waves per SIMD (each hides the other's LDS-DMA issue stalls) with 8 x TP<=4 tiles.
+template <typename T, int BP, int BC, int NW>
+__global__ void __launch_bounds__(64 * NW, NW / 4)
+conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
     constexpr int EPC = Elem<T>::EPC;
     constexpr int BK = 8 * EPC;
     constexpr int ES = sizeof(T);
-    constexpr int NXI = BP / 32, NWI = BC / 32;                    // load instructions per thread and K step
-    constexpr int TP = BP / 2 / 16, TC = BC / 2 / 16;              // 16x16 tiles per wave
+    constexpr int NT = 64 * NW;
+    constexpr int WP = NW / 2;                                      // waves along the pixel dimension
+    constexpr int NXI = BP / (8 * NW), NWI = BC / (8 * NW);        // load instructions per thread and K step
+    constexpr int TP = BP / WP / 16, TC = BC / 2 / 16;             // 16x16 tiles per wave
     constexpr int STAGE = (BP + BC) * 128;
-    static_assert(BP % 32 == 0 && BC % 32 == 0, "tile shape");
-    static_assert(TP <= 8 && TC <= 8, "accumulators must fit the register file");
+    static_assert(BP % (8 * NW) == 0 && BC % (8 * NW) == 0 && (BP / WP) % 16 == 0, "tile shape");
+    static_assert(TP <= 8 && TC <= 8 && TC * TP % 4 == 0, "accumulators must fit the register file");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wc = wave >> 1, wp = wave & 1;
+    const int wc = wave / WP, wp = wave % WP;
 
     int ptile, ctile;
     {
@@ -109,7 +115,7 @@ __global__ void __launch_bounds__(256, 1) conv_igemm_big_kernel(ConvKArgs a, uns
     unsigned xmask[NXI];
 #pragma unroll
     for (int j = 0; j < NXI; ++j) {
-        const int row = (j * 4 + wave) * 8 + lrow;
+        const int row = (j * NW + wave) * 8 + lrow;
         const int m = m0 + row;
         const bool vm = m < a.M;
         const int mm = vm ? m : 0;
@@ -128,7 +134,7 @@ __global__ void __launch_bounds__(256, 1) conv_igemm_big_kernel(ConvKArgs a, uns
     unsigned woff[NWI];
 #pragma unroll
     for (int j = 0; j < NWI; ++j) {
-        const int row = (j * 4 + wave) * 8 + lrow;
+        const int row = (j * NW + wave) * 8 + lrow;
         woff[j] = (unsigned)(((size_t)(c0 + row) * a.Ktot + chunk * EPC) * ES);
     }
 
@@ -166,10 +172,10 @@ __global__ void __launch_bounds__(256, 1) conv_igemm_big_kernel(ConvKArgs a, uns
         char* xs = smem + buf * STAGE;
         if constexpr (g < NXI) {
             const unsigned voff = (xmask[g] & tapbit) ? (unsigned)(xbase[g] + tapoff) : kOOB;
-            bufload_lds16(xrs, xs + (g * 4 + wave) * 1024, voff, 0);
+            bufload_lds16(xrs, xs + (g * NW + wave) * 1024, voff, 0);
         } else {
             constexpr int j = g - NXI;
-            bufload_lds16(wrs, xs + BP * 128 + (j * 4 + wave) * 1024, live ? woff[j] : kOOB, ksoff);
+            bufload_lds16(wrs, xs + BP * 128 + (j * NW + wave) * 1024, live ? woff[j] : kOOB, ksoff);
         }
     };
     constexpr int NL = NXI + NWI;                                    // LDS-DMA instructions per stage and thread
@@ -179,7 +185,7 @@ __global__ void __launch_bounds__(256, 1) conv_igemm_big_kernel(ConvKArgs a, uns
     int foff[2];
     foff[0] = frow * 128 + (((0 + fq) ^ fswz) << 4);
     foff[1] = frow * 128 + (((4 + fq) ^ fswz) << 4);
-    const int x_tile_off = wp * (BP / 2) * 128;
+    const int x_tile_off = wp * (BP / WP) * 128;
     const int w_tile_off = BP * 128 + wc * (BC / 2) * 128;
 
     f32x4 acc[TC][TP];
@@ -262,10 +268,12 @@ __global__ void __launch_bounds__(256, 1) conv_igemm_big_kernel(ConvKArgs a, uns
     // ---- epilogue through LDS chunks of 64 pixels (NHWC) / 64 channels (NCHW head) -------------------
     float* ct = reinterpret_cast<float*>(smem);
     if (!a.nchw) {
-        constexpr int LD = BC + 4;                                   // [pixel][channel] f32, 64 pixels per chunk
-        constexpr int JC = 2;                                        // pixel tiles per wave and chunk
-        constexpr int TPP = BC / 8, PPP = 256 / TPP;                 // threads per pixel, pixels per pass
-        static_assert(TP % JC == 0, "pixel tiles per wave must be even");
+        constexpr int LD = BC + 4;                                   // [pixel][channel] f32
+        constexpr int JC = (TP % 2 == 0 && WP == 2) ? 2 : 1;         // pixel tiles per wave and chunk
+        constexpr int CPX = WP * JC * 16;                            // pixels per chunk (64)
+        constexpr int TPP = BC / 8, PPP = NT / TPP;                  // threads per pixel, pixels per pass
+        static_assert(TP % JC == 0 && CPX % PPP == 0, "epilogue chunking");
+        static_assert((size_t)CPX * LD * 4 <= 2 * (size_t)STAGE, "epilogue chunk must fit the staging LDS");
         const int cg = tid % TPP, prow = tid / TPP;
         const int c = c0 + cg * 8;
         float s1[8], b1[8], s2[8], b2[8];
@@ -290,10 +298,10 @@ __global__ void __launch_bounds__(256, 1) conv_igemm_big_kernel(ConvKArgs a, uns
             __syncthreads();
             if (c < a.Cout) {
 #pragma unroll
-                for (int pass = 0; pass < (2 * JC * 16) / PPP; ++pass) {
-                    const int px = pass * PPP + prow;                // 0 .. 2*JC*16-1
+                for (int pass = 0; pass < CPX / PPP; ++pass) {
+                    const int px = pass * PPP + prow;                // 0 .. CPX-1
                     const int pw = px / (JC * 16), pj = (px / 16) % JC, pr = px % 16;
-                    const int m = m0 + pw * (BP / 2) + (q * JC + pj) * 16 + pr;
+                    const int m = m0 + pw * (BP / WP) + (q * JC + pj) * 16 + pr;
                     if (m < a.M) {
                         float v[8];
                         const f32x4 lo = *reinterpret_cast<const f32x4*>(ct + px * LD + cg * 8);
@@ -321,10 +329,7 @@ __global__ void __launch_bounds__(256, 1) conv_igemm_big_kernel(ConvKArgs a, uns
             }
             __syncthreads();
         };
-        chunk(std::integral_constant<int, 0>{});
-        if constexpr (TP / JC > 1) chunk(std::integral_constant<int, 1>{});
-        if constexpr (TP / JC > 2) chunk(std::integral_constant<int, 2>{});
-        if constexpr (TP / JC > 3) chunk(std::integral_constant<int, 3>{});
+        static_for<TP / JC>(chunk);
     } else {
         // head: f32 NCHW [B, Cout, Ho*Wo] (model.py:136): 64 channels per chunk, pixel-contiguous rows
         constexpr int LD = BP + 4;                                   // [channel][pixel] f32
@@ -332,6 +337,7 @@ __global__ void __launch_bounds__(256, 1) conv_igemm_big_kernel(ConvKArgs a, uns
         constexpr int TPC = BP / 4;                                  // threads per channel row (4 pixels each)
         constexpr int NITEM = 2 * IC * 16 * TPC;                     // (channel row, pixel quad) items per chunk
         static_assert(TC % IC == 0, "channel tiles per wave must be even");
+        static_assert((size_t)2 * IC * 16 * LD * 4 <= 2 * (size_t)STAGE, "epilogue chunk must fit the staging LDS");
         float* out = reinterpret_cast<float*>(a.out_raw);
         const bool vec = (a.HoWo & 3) == 0;
         auto chunk = [&](auto qc) {
@@ -340,13 +346,13 @@ __global__ void __launch_bounds__(256, 1) conv_igemm_big_kernel(ConvKArgs a, uns
             for (int ii = 0; ii < IC; ++ii)
 #pragma unroll
                 for (int j = 0; j < TP; ++j) {
-                    const int px = wp * (BP / 2) + j * 16 + frow;
+                    const int px = wp * (BP / WP) + j * 16 + frow;
                     const int ch = (wc * IC + ii) * 16 + 4 * fq;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) ct[(ch + r) * LD + px] = acc[q * IC + ii][j][r];
                 }
             __syncthreads();
-            for (int item = tid; item < NITEM; item += 256) {
+            for (int item = tid; item < NITEM; item += NT) {
                 const int chl = item / TPC, pq = item - chl * TPC;   // 0 .. 2*IC*16-1
                 const int cw = chl / (IC * 16), ci = (chl / 16) % IC, cr = chl % 16;
                 const int c = c0 + cw * (BC / 2) + (q * IC + ci) * 16 + cr;
@@ -375,26 +381,24 @@ __global__ void __launch_bounds__(256, 1) conv_igemm_big_kernel(ConvKArgs a, uns
             }
             __syncthreads();
         };
-        chunk(std::integral_constant<int, 0>{});
-        if constexpr (TC / IC > 1) chunk(std::integral_constant<int, 1>{});
-        if constexpr (TC / IC > 2) chunk(std::integral_constant<int, 2>{});
-        if constexpr (TC / IC > 3) chunk(std::integral_constant<int, 3>{});
+        static_for<TC / IC>(chunk);
     }
 }
 
-template <typename T, int BP, int BC>
+template <typename T, int BP, int BC, int NW>
 int launch_one(const ConvKArgs& a, hipStream_t st, const char** kname) {
     constexpr size_t lds = 2 * (size_t)(BP + BC) * 128;
     static char name[96];
     if (!name[0])
-        snprintf(name, sizeof(name), "conv_igemm_big_kernel<%s, %d, %d>", sizeof(T) == 4 ? "float" : "__bf16", BP, BC);
+        snprintf(name, sizeof(name), "conv_igemm_big_kernel<%s, %d, %d, %d>", sizeof(T) == 4 ? "float" : "__bf16", BP,
+                 BC, NW);
     if (kname) *kname = name;
     const size_t src_bytes = (size_t)a.B * a.H * a.W * a.Cin * sizeof(T);
     const size_t wgt_bytes = (size_t)a.n_ctiles * BC * a.Ktot * sizeof(T);
-    auto k = conv_igemm_big_kernel<T, BP, BC>;
+    auto k = conv_igemm_big_kernel<T, BP, BC, NW>;
     PPN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)lds));
-    hipLaunchKernelGGL(k, dim3(a.n_ctiles * a.n_ptiles), dim3(256), lds, st, a, (unsigned)src_bytes,
+    hipLaunchKernelGGL(k, dim3(a.n_ctiles * a.n_ptiles), dim3(64 * NW), lds, st, a, (unsigned)src_bytes,
                        (unsigned)wgt_bytes);
     PPN_LAUNCH_CHECK();
     return PPN_OK;
@@ -402,14 +406,25 @@ int launch_one(const ConvKArgs& a, hipStream_t st, const char** kname) {
 
 template <typename T>
 int launch_T(const ConvKArgs& a, BigTile t, hipStream_t st, const char** kname) {
-    if (t.bc == 256) {
-        if (t.bp == 256) return launch_one<T, 256, 256>(a, st, kname);
-        if (t.bp == 192) return launch_one<T, 192, 256>(a, st, kname);
-        return launch_one<T, 128, 256>(a, st, kname);
+    static const int nw = getenv("PPN_CONV_WAVES") ? atoi(getenv("PPN_CONV_WAVES")) : 8;   // tuning knob
+    if (nw == 4) {
+        if (t.bc == 256) {
+            if (t.bp == 256) return launch_one<T, 256, 256, 4>(a, st, kname);
+            if (t.bp == 192) return launch_one<T, 192, 256, 4>(a, st, kname);
+            return launch_one<T, 128, 256, 4>(a, st, kname);
+        }
+        if (t.bp == 256) return launch_one<T, 256, 128, 4>(a, st, kname);
+        if (t.bp == 192) return launch_one<T, 192, 128, 4>(a, st, kname);
+        return launch_one<T, 128, 128, 4>(a, st, kname);
     }
-    if (t.bp == 256) return launch_one<T, 256, 128>(a, st, kname);
-    if (t.bp == 192) return launch_one<T, 192, 128>(a, st, kname);
-    return launch_one<T, 128, 128>(a, st, kname);
+    if (t.bc == 256) {
+        if (t.bp == 256) return launch_one<T, 256, 256, 8>(a, st, kname);
+        if (t.bp == 192) return launch_one<T, 192, 256, 8>(a, st, kname);
+        return launch_one<T, 128, 256, 8>(a, st, kname);
+    }
+    if (t.bp == 256) return launch_one<T, 256, 128, 8>(a, st, kname);
+    if (t.bp == 192) return launch_one<T, 192, 128, 8>(a, st, kname);
+    return launch_one<T, 128, 128, 8>(a, st, kname);
 }
 
 }  // namespace
