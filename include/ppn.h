@@ -126,7 +126,9 @@ typedef struct ppn_conv_desc {
  *   k_order 0:  k = (ky*ksize + kx)*cin + ci                      (tap-major)
  *   k_order 1:  k = ((ci / k_step)*ksize*ksize + ky*ksize + kx)*k_step + ci % k_step
  *               (channel-chunk-major: the 9 taps of one 64-channel slab are consecutive K steps, so the
- *                shifted re-reads of an input row hit L2 instead of the Infinity Cache)                    */
+ *                shifted re-reads of an input row hit L2 instead of the Infinity Cache)
+ *   k_order 2:  direct small-channel kernel (Cin 16, 3x3): the weight stays in the reference layout
+ *               [cout][cin][3][3] as f32 for either dtype; k_step = k_total = 144, cout_tile = cout        */
 int ppn_conv_tiling(int32_t dtype, int32_t cin, int32_t cout, int32_t ksize, int32_t* k_step, int32_t* cout_tile,
                     int32_t* k_order);
 

@@ -22,6 +22,7 @@ SOURCES = [
     ("conv.hip", []),
     ("conv_big.hip", []),
     ("stem.hip", []),
+    ("stem3x3.hip", []),
     ("plan.hip", []),
 ]
 

@@ -355,6 +355,10 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ 
 
 namespace ppn {
 int conv_launch(const ppn_conv_desc* d, hipStream_t st, const char** kname);
+bool stem3x3_supported(int cin, int cout, int ksize, int stride, int dilation, int pad);
+int stem3x3_launch(int dtype, const void* src, int batch, int h, int w, int cout, int stride, const float* weight,
+                   const float* scale1, const float* shift1, const float* scale2, const float* shift2, void* out_raw,
+                   void* out_act, hipStream_t st, const char** kname);
 }
 
 extern "C" int ppn_conv_tiling(int32_t dtype, int32_t cin, int32_t cout, int32_t ksize, int32_t* k_step,
@@ -362,6 +366,13 @@ extern "C" int ppn_conv_tiling(int32_t dtype, int32_t cin, int32_t cout, int32_t
     if (dtype != PPN_F32 && dtype != PPN_BF16) return ppn::fail(PPN_E_INVALID, "bad dtype %d", dtype);
     if (cin < 1 || cout < 1 || ksize < 1) return ppn::fail(PPN_E_INVALID, "bad conv shape");
     const int bk = dtype == PPN_F32 ? 32 : 64;
+    if (cin == 16 && (cout == 16 || cout == 32) && ksize == 3) {
+        // direct small-channel kernel (stem3x3.hip): weights stay in the reference layout, f32, unpadded
+        if (k_step) *k_step = 144;
+        if (cout_tile) *cout_tile = cout;
+        if (k_order) *k_order = 2;
+        return PPN_OK;
+    }
     if (k_step) *k_step = bk;
     BigTile bt;
     const bool big = (cin % bk == 0) && big_tile_for(cout, 1, &bt);
@@ -382,6 +393,15 @@ int ppn::conv_launch(const ppn_conv_desc* d, hipStream_t st, const char** kname)
     const int oh = (d->in_h + 2 * d->pad - eff) / d->stride + 1, ow = (d->in_w + 2 * d->pad - eff) / d->stride + 1;
     if (oh != d->out_h || ow != d->out_w)
         return ppn::fail(PPN_E_INVALID, "out size %dx%d inconsistent with %dx%d", d->out_h, d->out_w, oh, ow);
+    if (ppn::stem3x3_supported(d->cin, d->cout, d->ksize, d->stride, d->dilation, d->pad) && d->k_total == 144 &&
+        d->cout_pad == d->cout && !d->residual && !d->out_nchw_f32 && d->act1 == PPN_ACT_RELU &&
+        (!d->out_act || d->act2 == PPN_ACT_RELU)) {
+        if (!d->src || !d->weight || !d->scale1 || !d->shift1) return ppn::fail(PPN_E_INVALID, "NULL src/weight/scale");
+        if (oh != d->out_h || ow != d->out_w) return ppn::fail(PPN_E_INVALID, "inconsistent output size");
+        return ppn::stem3x3_launch(d->dtype, d->src, d->batch, d->in_h, d->in_w, d->cout, d->stride,
+                                   static_cast<const float*>(d->weight), d->scale1, d->shift1, d->scale2, d->shift2,
+                                   d->out_raw, d->out_act, st, kname);
+    }
     const bool smallc = (d->cin % bk) != 0;
     const int log2c = ilog2_exact(d->cin);
     if (smallc && log2c < 0) return ppn::fail(PPN_E_UNSUPPORTED, "cin %d < K step must be a power of two", d->cin);
@@ -435,6 +455,12 @@ extern "C" int ppn_pack_weight(int32_t dtype, const float* w, int32_t cout, int3
                                void* stream) {
     if (!w || !out || cout < 1 || cin < 1 || ksize < 1 || cout_pad < cout || k_total < ksize * ksize * cin)
         return ppn::fail(PPN_E_INVALID, "ppn_pack_weight: bad arguments");
+    hipStream_t st0 = static_cast<hipStream_t>(stream);
+    if (k_order == 2) {   // reference layout, f32, as is
+        PPN_HIP_CHECK(hipMemcpyAsync(out, w, sizeof(float) * (size_t)cout * cin * ksize * ksize,
+                                     hipMemcpyDeviceToDevice, st0));
+        return PPN_OK;
+    }
     if (k_order != 0 && (k_order != 1 || k_step < 1 || cin % k_step != 0))
         return ppn::fail(PPN_E_INVALID, "ppn_pack_weight: k_order %d needs cin %% k_step == 0", k_order);
     const size_t n = (size_t)cout_pad * k_total;

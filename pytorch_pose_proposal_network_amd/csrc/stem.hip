@@ -57,24 +57,33 @@ __global__ void __launch_bounds__(256) stem7x7_kernel(StemArgs a) {
     const int y0 = ty * TH, x0 = tx * TW;
 
     // ---- stage the normalised patch ---------------------------------------------------------
-    for (int i = tid; i < PH * PW; i += 256) {
+    // (all global loads are issued before the first LDS store so that their latencies overlap)
+    constexpr int NPIX = PH * PW, NIT = (NPIX + 255) / 256;
+    float sv[NIT][3];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int i = it * 256 + tid;
         const int py = i / PW, px = i - py * PW;
         const int gy = y0 + py - 3, gx = x0 + px - 3;
-        float v0 = 0.f, v1 = 0.f, v2 = 0.f;
-        if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+        sv[it][0] = sv[it][1] = sv[it][2] = 0.f;
+        if (i < NPIX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
             if (a.src_is_u8) {
                 const unsigned char* s = static_cast<const unsigned char*>(a.src) + (((size_t)b * a.H + gy) * a.W + gx) * 3;
                 // image.float().sub_(mean).div_(std)  (rt_test.py:99-101)
-                v0 = ((float)s[0] - a.mean[0]) / a.stdv[0];
-                v1 = ((float)s[1] - a.mean[1]) / a.stdv[1];
-                v2 = ((float)s[2] - a.mean[2]) / a.stdv[2];
+                sv[it][0] = ((float)s[0] - a.mean[0]) / a.stdv[0];
+                sv[it][1] = ((float)s[1] - a.mean[1]) / a.stdv[1];
+                sv[it][2] = ((float)s[2] - a.mean[2]) / a.stdv[2];
             } else {
                 const float* s = static_cast<const float*>(a.src) + ((size_t)b * 3 * a.H + gy) * a.W + gx;
                 const size_t plane = (size_t)a.H * a.W;
-                v0 = s[0]; v1 = s[plane]; v2 = s[2 * plane];
+                sv[it][0] = s[0]; sv[it][1] = s[plane]; sv[it][2] = s[2 * plane];
             }
         }
-        patch_store<T>(patch + (size_t)i * 4, v0, v1, v2);
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int i = it * 256 + tid;
+        if (i < NPIX) patch_store<T>(patch + (size_t)i * 4, sv[it][0], sv[it][1], sv[it][2]);
     }
 
     // ---- weights as A fragments (rows = output channels) ---------------------------------------

@@ -161,7 +161,7 @@ class PoseProposalNet:
                 continue
             kstep, _, korder, ktot, cpad = L.conv_tiling(self.compute_dtype, op.cin, op.cout, op.k)
             wd = w.to(dev)
-            packed = torch.empty(cpad, ktot, dtype=tdt, device=dev)
+            packed = torch.empty(cpad, ktot, dtype=torch.float32 if korder == 2 else tdt, device=dev)
             L.check(lib.ppn_pack_weight(self.compute_dtype, wd.data_ptr(), op.cout, op.cin, op.k, cpad, ktot,
                                         korder, kstep, packed.data_ptr(), stream), "ppn_pack_weight")
             self._dev[op.name + ".w"] = packed

@@ -37,7 +37,7 @@ def main():
         Ho = (H + 2 * pad - d * (k - 1) - 1) // s + 1
         kstep, _, korder, ktot, cpad = L.conv_tiling(dtype, cin, cout, k)
         x = torch.randn(B, H, H, cin, device=dev).to(tdt)
-        w = (torch.randn(cpad, ktot, device=dev) * 0.02).to(tdt)
+        w = (torch.randn(cpad, ktot, device=dev) * 0.02).to(torch.float32 if korder == 2 else tdt)
         nchw = cout == 7605
         out = torch.empty(B, cout, Ho, Ho, device=dev) if nchw else torch.empty(B, Ho, Ho, cout, device=dev, dtype=tdt)
         sc = torch.ones(cout, device=dev); sh = torch.zeros(cout, device=dev)
