@@ -44,7 +44,8 @@ def load_bn_stats(arch, seed=0):
 def cpu_baseline(arch, sample, size):
     """The oracle timed on this host's cores on `sample` frames of the same workload (reported, not a target)."""
     from oracle import decode_ref as D, forward_ref as Fr
-    torch.set_num_threads(os.cpu_count() or 1)
+    # a 1-GPU box owns a 16-core share of its host; more threads than that only oversubscribe it
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
     sd = synth.make_state_dict(arch, 0, bn_stats=load_bn_stats(arch))
     u8 = prng.u8_frames(1234, sample, (size, size))
     x = Fr.normalize_u8(u8)

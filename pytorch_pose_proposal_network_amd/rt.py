@@ -1,0 +1,73 @@
+"""Mirror of the reference's realtime driver entry points (rt_test.py:52-147) over the HIP path.
+
+    model, outsize, local_grid_size = network(resume="PPN_model_best.pth.tar", image_size=384)
+    humans, scores = inference(image_u8_hwc, model, outsize, local_grid_size)
+
+``inference`` keeps the reference's argument list; what it does differently is *where* things run: the
+uint8 frame is uploaded once (442 KB), normalisation + the whole conv stack + head run as HIP kernels, the
+head tensor never leaves the device (the reference copies all 17.5 MB of it to the host in seven slices,
+rt_test.py:109-120) and only the compact people list (<= 80 KB) comes back.  Webcam capture, matplotlib
+animation and drawing (rt_test.py:150-205, datatest.py:162-232) are out of scope: ``inference`` returns the
+reference's ``(humans, scores)`` instead of a PIL image; pass ``draw=callable`` to post-process on the host.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional
+
+import numpy as np
+import torch
+
+from . import config as cfg
+from . import decode as D
+from . import drn
+from .model import PoseProposalNet
+
+
+def network(resume: Optional[str] = None, image_size: int = 384, arch: str = "drn_d_22",
+            compute_dtype: str = "float32", state_dict=None):
+    """rt_test.py:52-85: build D-22 PPN, derive ``outsize`` and load ``checkpoint['state_dict']``.
+
+    The reference discovers ``outsize`` with a dummy forward (rt_test.py:65-68); the network is fully
+    convolutional with total stride 16, so it is ``image_size // 16`` here."""
+    local_grid_size = (21, 21)
+    outsize = (image_size // 16, image_size // 16)
+    model = PoseProposalNet(getattr(drn, arch)(), insize=(image_size, image_size), outsize=outsize,
+                            local_grid_size=local_grid_size, compute_dtype=compute_dtype).cuda()
+    if resume is not None:
+        ckpt = torch.load(resume, map_location="cpu")
+        state_dict = ckpt["state_dict"] if "state_dict" in ckpt else ckpt
+    if state_dict is not None:
+        model.load_state_dict(state_dict)
+    return model, outsize, local_grid_size
+
+
+def inference(image, model: PoseProposalNet, outsize, local_grid_size, detection_thresh: float = 0.15,
+              draw: Optional[Callable] = None):
+    """rt_test.py:87-147 for one RGB frame (u8 [S,S,3] array / PIL image / tensor).
+
+    Returns ``(humans, scores)`` exactly as datatest.get_humans_by_feature does (lists of dicts
+    keypoint -> [ymin,xmin,ymax,xmax] / keypoint -> delta), or ``draw(image, humans, scores)`` if given."""
+    model.eval()
+    img = np.asarray(image)
+    if img.dtype != np.uint8 or img.ndim != 3 or img.shape[2] != 3:
+        raise ValueError("inference expects a uint8 HxWx3 RGB frame")
+    frames = torch.from_numpy(np.ascontiguousarray(img)).unsqueeze(0).cuda(non_blocking=True)
+    head = model.forward_u8(frames)
+    outW, outH = outsize
+    res = D.decode_heads(head, insize_hw=(img.shape[0], img.shape[1]), local_grid=local_grid_size,
+                         detection_thresh=detection_thresh)
+    humans, scores = res.to_humans()[0]
+    if draw is not None:
+        return draw(image, humans, scores)
+    return humans, scores
+
+
+def inference_batch(frames_u8: torch.Tensor, model: PoseProposalNet, decoder: Optional[D.Decoder] = None,
+                    detection_thresh: float = 0.15) -> D.DecodeResult:
+    """Batched device-side inference: u8 [B,S,S,3] CUDA tensor -> compact people lists on the device."""
+    head = model.forward_u8(frames_u8)
+    if decoder is None:
+        b, _, h, w = head.shape
+        decoder = D.Decoder(b, (h, w), (frames_u8.shape[1], frames_u8.shape[2]), model.local_grid_size,
+                            detection_thresh, device=head.device)
+    return decoder(head)

@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 F32_TOL = 1e-4
 # bf16 mode (bf16 weights + stored activations, f32 accumulate/epilogue/head) on the synthetic checkpoint:
 BF16_MAX_TOL, BF16_MEAN_TOL = 0.15, 0.02            # vs the fp32 reference head (quantisation noise included)
-BF16_EMU_MAX_TOL, BF16_EMU_MEAN_TOL = 0.06, 0.004   # vs the oracle with bf16 storage emulated
+BF16_EMU_MAX_TOL, BF16_EMU_MEAN_TOL = 0.06, 0.006   # vs the oracle with bf16 storage emulated
 
 
 def _model(arch, g, dtype):

@@ -1,0 +1,116 @@
+"""CPU-only checks of the host side: the C-ABI library exports every symbol include/ppn.h declares, the ctypes
+structs match the C structs, rejects bad arguments without a GPU, and frame sharding over 2 gloo ranks
+reproduces the single-process result."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _lib():
+    from pytorch_pose_proposal_network_amd import build, lib
+    if not os.path.exists(lib.LIB_PATH):
+        build.build(verbose=False)
+    return lib
+
+
+def test_header_symbols_exported():
+    lib = _lib()
+    hdr = open(os.path.join(ROOT, "include", "ppn.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(ppn_[a-z0-9_]+)\s*\(", hdr))
+    out = subprocess.check_output(["nm", "-D", "--defined-only", lib.LIB_PATH], text=True)
+    exported = set(re.findall(r"\bT (ppn_[a-z0-9_]+)", out))
+    assert declared, "no declarations parsed"
+    assert declared <= exported, f"declared but not exported: {sorted(declared - exported)}"
+    assert set(lib.EXPORTS) == declared, (sorted(set(lib.EXPORTS) ^ declared))
+
+
+def test_library_loads_and_reports_errors_without_gpu():
+    lib = _lib()
+    l = lib.load()
+    assert l.ppn_version() >= 1
+    # argument validation happens before any device work
+    assert l.ppn_conv2d_fused(None, None) != 0
+    assert b"NULL" in l.ppn_last_error()
+    cfg = lib.DecodeCfg()
+    assert l.ppn_decode(C.byref(cfg), None, 1, None, None, None, None, None, None, None) != 0
+    k, c, o = C.c_int32(), C.c_int32(), C.c_int32()
+    assert l.ppn_conv_tiling(lib.PPN_BF16, 512, 512, 3, C.byref(k), C.byref(c), C.byref(o)) == 0
+    assert (k.value, c.value, o.value) == (64, 256, 1)
+    assert l.ppn_conv_tiling(lib.PPN_F32, 512, 7605, 1, C.byref(k), C.byref(c), C.byref(o)) == 0
+    assert (k.value, c.value) == (32, 256)
+    assert l.ppn_conv_tiling(lib.PPN_BF16, 16, 32, 3, C.byref(k), C.byref(c), C.byref(o)) == 0
+    assert o.value == 2 and k.value == 144
+    assert l.ppn_conv_tiling(7, 16, 32, 3, None, None, None) != 0
+
+
+def test_ctypes_structs_match_header():
+    """sizeof of the ctypes mirrors == sizeof of the C structs (compiled with gcc from include/ppn.h)."""
+    lib = _lib()
+    src = '#include <stdio.h>\n#include "ppn.h"\nint main(){printf("%zu %zu\\n", sizeof(ppn_decode_cfg), sizeof(ppn_conv_desc));return 0;}\n'
+    exe = os.path.join("/tmp", "ppn_sizeof")
+    subprocess.run(["gcc", "-x", "c", "-", "-I", os.path.join(ROOT, "include"), "-o", exe], input=src.encode(), check=True)
+    a, b = map(int, subprocess.check_output([exe]).split())
+    assert a == C.sizeof(lib.DecodeCfg) and b == C.sizeof(lib.ConvDesc)
+
+
+def test_decode_cfg_tables():
+    from pytorch_pose_proposal_network_amd import config as cfg, decode
+    c = decode.make_cfg()
+    assert (c.K, c.E, c.sH, c.sW, c.H, c.W, c.max_humans) == (18, 17, 21, 21, 24, 24, 576)
+    order = [c.edge_order[i] for i in range(c.E)]
+    assert sorted(order) == list(range(17))
+    seen = {0}
+    for e in order:                       # parent-before-child
+        assert c.edge_src[e] in seen
+        seen.add(c.edge_dst[e])
+
+
+def test_frame_shard_roundtrip():
+    from pytorch_pose_proposal_network_amd import shard
+    for n in (0, 1, 7, 32):
+        for world in (1, 2, 3, 8):
+            parts = [[f"f{i}" for i in shard.frame_shard(n, r, world)] for r in range(world)]
+            assert shard.merge_shards(parts, n) == [f"f{i}" for i in range(n)]
+    with pytest.raises(ValueError):
+        shard.frame_shard(4, 2, 2)
+
+
+_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch.distributed as dist
+from oracle import decode_ref as D
+from pytorch_pose_proposal_network_amd import shard, synth
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+n = 6
+mine = [int(D.decode_ref(synth.planted_crowd_head(7 + i))["n"]) for i in shard.frame_shard(n, rank, world)]
+allr = shard.gather_results(mine, n)
+if rank == 0:
+    print("RESULT", allr)
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def test_two_rank_gloo_sharding_matches_single_process(tmp_path):
+    """world_size-2 rehearsal of the N>1 inference path on CPU (gloo): shard, decode locally, gather."""
+    from oracle import decode_ref as D
+    from pytorch_pose_proposal_network_amd import synth
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29617", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    line = [l for l in outs[0].splitlines() if l.startswith("RESULT")][0]
+    expected = [int(D.decode_ref(synth.planted_crowd_head(7 + i))["n"]) for i in range(6)]
+    assert eval(line[len("RESULT "):]) == expected
