@@ -29,4 +29,14 @@ inline int fail(int code, const char* fmt, ...) {
 
 #define PPN_LAUNCH_CHECK() PPN_HIP_CHECK(hipGetLastError())
 
+// Raise a kernel's dynamic-LDS limit only when it grows (the attribute is sticky; a hipFuncSetAttribute per
+// launch costs host time on the launch path).  One process drives one GPU in this design.
+#define PPN_LDS_ONCE(var, fn, attr, bytes)                              \
+    do {                                                                \
+        if ((bytes) > (var)) {                                          \
+            PPN_HIP_CHECK(hipFuncSetAttribute(fn, attr, bytes));        \
+            (var) = (bytes);                                            \
+        }                                                               \
+    } while (0)
+
 }  // namespace ppn

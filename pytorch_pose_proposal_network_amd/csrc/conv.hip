@@ -300,14 +300,20 @@ int launch_tile(const ConvKArgs& a, bool smallc, hipStream_t st, const char** kn
     if (smallc) {
         auto k = conv_igemm_kernel<T, BP, BC, WP, WC, true>;
         if (kname) *kname = names[1];
-        PPN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int)lds));
+        {
+            static int max_lds_set = 0;   // the attribute sticks to the function: set it when it grows
+            PPN_LDS_ONCE(max_lds_set, reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)lds);
+        }
         hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, a);
     } else {
         auto k = conv_igemm_kernel<T, BP, BC, WP, WC, false>;
         if (kname) *kname = names[0];
-        PPN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int)lds));
+        {
+            static int max_lds_set = 0;   // the attribute sticks to the function: set it when it grows
+            PPN_LDS_ONCE(max_lds_set, reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)lds);
+        }
         hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, a);
     }
     PPN_LAUNCH_CHECK();

@@ -17,6 +17,7 @@
 // K loop: two named fragment sets; the MFMAs of one set cover the LDS reads of the other and the DMA issue
 // of the next stage, so the matrix pipe restarts immediately after the per-step barrier.
 // Epilogue through LDS in 64-pixel (NHWC) / 64-channel (NCHW head) chunks: 16-byte coalesced stores.
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 #include <utility>
@@ -234,8 +235,17 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
     // is free.  The MFMAs of set B start right after the barrier; between groups of 4 MFMAs the wave issues
     // the DMA of stage s+1 and the LDS reads of set A (order pinned with sched_barrier so neither clusters);
     // then the MFMAs of set A cover the reads of the new set B and the scalar bookkeeping of the next step.
+#ifdef PPN_STAMP
+    unsigned long long st_b1 = 0, st_b2 = 0, st_wait = 0, st_bar = 0, tq0, tq1;
+#define PPN_T(var) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define PPN_T(var) do { } while (0)
+#endif
     for (int s = 1; s < nsteps; ++s) {
         const int buf = s & 1;
+#ifdef PPN_STAMP
+        PPN_T(tq0);
+#endif
         static_for<NG>([&](auto gc) {
             constexpr int g = decltype(gc)::value;
             mma_group(gc, wB, xB);
@@ -250,6 +260,9 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
             __builtin_amdgcn_sched_barrier(0);
         });
         advance();
+#ifdef PPN_STAMP
+        PPN_T(tq1); st_b1 += tq1 - tq0;
+#endif
         static_for<NG>([&](auto gc) {
             constexpr int g = decltype(gc)::value;
             mma_group(gc, wA, xA);
@@ -259,9 +272,24 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
             });
             __builtin_amdgcn_sched_barrier(0);
         });
+#ifdef PPN_STAMP
+        PPN_T(tq0); st_b2 += tq0 - tq1;
+#endif
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#ifdef PPN_STAMP
+        PPN_T(tq1); st_wait += tq1 - tq0;
+#endif
         __syncthreads();
+#ifdef PPN_STAMP
+        PPN_T(tq0); st_bar += tq0 - tq1;
+#endif
     }
+#ifdef PPN_STAMP
+    if (lane == 0 && a.scale2 == nullptr && a.shift2 != nullptr) {   // diagnostic channel: shift2 = u64 buffer
+        unsigned long long* dbg = (unsigned long long*)a.shift2 + ((size_t)blockIdx.x * NW + wave) * 4;
+        dbg[0] = st_b1; dbg[1] = st_b2; dbg[2] = st_wait; dbg[3] = st_bar;
+    }
+#endif
     static_for<NG>([&](auto gc) { mma_group(gc, wB, xB); });
     __syncthreads();                                                 // LDS is reused by the epilogue
 
@@ -396,8 +424,11 @@ int launch_one(const ConvKArgs& a, hipStream_t st, const char** kname) {
     const size_t src_bytes = (size_t)a.B * a.H * a.W * a.Cin * sizeof(T);
     const size_t wgt_bytes = (size_t)a.n_ctiles * BC * a.Ktot * sizeof(T);
     auto k = conv_igemm_big_kernel<T, BP, BC, NW>;
-    PPN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)lds));
+    {
+        static int max_lds_set = 0;   // the attribute sticks to the function: set it when it grows
+        PPN_LDS_ONCE(max_lds_set, reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)lds);
+    }
     hipLaunchKernelGGL(k, dim3(a.n_ctiles * a.n_ptiles), dim3(64 * NW), lds, st, a, (unsigned)src_bytes,
                        (unsigned)wgt_bytes);
     PPN_LAUNCH_CHECK();
@@ -422,25 +453,48 @@ int launch_T(const ConvKArgs& a, BigTile t, hipStream_t st, const char** kname) 
         if (t.bp == 192) return launch_one<T, 192, 256, 8>(a, st, kname);
         return launch_one<T, 128, 256, 8>(a, st, kname);
     }
-    if (t.bp == 256) return launch_one<T, 256, 128, 8>(a, st, kname);
-    if (t.bp == 192) return launch_one<T, 192, 128, 8>(a, st, kname);
-    return launch_one<T, 128, 128, 8>(a, st, kname);
+    if (t.bc == 128) {
+        if (t.bp == 256) return launch_one<T, 256, 128, 8>(a, st, kname);
+        if (t.bp == 192) return launch_one<T, 192, 128, 8>(a, st, kname);
+        return launch_one<T, 128, 128, 8>(a, st, kname);
+    }
+    if (t.bp == 256) return launch_one<T, 256, 64, 8>(a, st, kname);
+    return launch_one<T, 128, 64, 8>(a, st, kname);
 }
 
 }  // namespace
 
 namespace ppnconv {
 
-// Pick the pixel-tile height that wastes the fewest CU-rounds (one workgroup per CU, 256 CUs).
+// Pick the tile: channels 256 / 128 / 64 by Cout, pixel height so that the fewest CU-rounds are wasted
+// (256 CUs; one workgroup per CU, two for the 64-channel tile whose LDS footprint is 80 KB).
+// PPN_CONV_TILE="bp,bc" overrides the choice for every eligible layer (tuning knob).
 bool big_tile_for(int cout, long long m, BigTile* out) {
-    if (cout < 128) return false;
-    const int bc = cout >= 256 ? 256 : 128;
+    if (cout < 64) return false;
+    static const char* ov = getenv("PPN_CONV_TILE");
+    if (ov) {
+        int bp = 0, bc = 0;
+        if (sscanf(ov, "%d,%d", &bp, &bc) == 2 && (bp == 128 || bp == 192 || bp == 256) &&
+            (bc == 64 || bc == 128 || bc == 256) && !(bc == 64 && bp == 192) && bc <= ((cout + 63) / 64) * 64) {
+            out->bp = bp; out->bc = bc;
+            return true;
+        }
+    }
+    if (cout >= 4096) {
+        // the head conv (512 -> 7605, K = 512) writes 17.5 MB/image and is store-bound: a 192x128 tile keeps
+        // two workgroups per CU so one's epilogue stores overlap the other's main loop (measured 322 vs 399 us)
+        out->bp = 192; out->bc = 128;
+        return true;
+    }
+    const int bc = cout >= 256 ? 256 : (cout >= 128 ? 128 : 64);
     const long long nct = (cout + bc - 1) / bc;
+    const long long slots = bc == 64 ? 512 : 256;
     double best = 1e30;
     int best_bp = 256;
     for (int bp : {256, 192, 128}) {
+        if (bc == 64 && bp == 192) continue;                         // 2x3 MFMA tiles per wave do not group by 4
         const long long tiles = ((m + bp - 1) / bp) * nct;
-        const long long rounds = (tiles + 255) / 256;
+        const long long rounds = (tiles + slots - 1) / slots;
         // time ~ rounds * (work per tile); smaller tiles stage more bytes per FLOP
         const double eff = bp == 256 ? 1.0 : (bp == 192 ? 0.95 : 0.85);
         const double cost = (double)rounds * bp / eff;

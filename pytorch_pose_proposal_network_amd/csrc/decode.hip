@@ -150,18 +150,20 @@ __device__ __forceinline__ void greedy_nms(int n, int nwords, const float4* s_bo
                                            int limit) {
     const int t = threadIdx.x;
     // pairwise suppression bits: row i holds, for every higher-priority j < i, [iou(i,j) >= thr]
-    for (int i = t; i < n; i += blockDim.x) {
-        const float4 bi = s_box[i];
-        const float ai = s_area[i];
-        for (int w = 0; w < nwords; ++w) {
-            unsigned long long bits = 0ull;
-            const int j0 = w * 64;
-            const int j1 = min(j0 + 64, i);
+    // (work item = one 64-bit word of one row, dealt round-robin so the triangular matrix is load balanced)
+    for (int q = t; q < n * nwords; q += blockDim.x) {
+        const int i = q / nwords, w = q - i * nwords;
+        const int j0 = w * 64;
+        const int j1 = min(j0 + 64, i);
+        unsigned long long bits = 0ull;
+        if (j0 < j1) {
+            const float4 bi = s_box[i];
+            const float ai = s_area[i];
             for (int j = j0; j < j1; ++j) {
                 if (iou_ge(bi, ai, s_box[j], s_area[j], thr)) bits |= (1ull << (j - j0));
             }
-            s_mask[(size_t)i * nwords + w] = bits;
         }
+        s_mask[q] = bits;
     }
     __syncthreads();
     // one wave resolves the greedy order: lane w owns keep-word w
@@ -201,12 +203,19 @@ parse_kernel(DecodeParams p, const float* __restrict__ head, const int* __restri
     float4* s_box = reinterpret_cast<float4*>(carve(sizeof(float4) * ncell));
     unsigned long long* s_key = reinterpret_cast<unsigned long long*>(carve(8 * ncell));
     unsigned long long* s_mask = reinterpret_cast<unsigned long long*>(carve(8 * (size_t)ncell * nwords));
+    {   // the first region doubles as the delta map [K][ncell] f32 after the NMS: make sure it is large enough
+        const size_t need = ((size_t)4 * K * ncell + 15) & ~size_t(15);
+        if (off < need) off = need;
+    }
     float* s_area = reinterpret_cast<float*>(carve(4 * ncell));
     int* s_cell = reinterpret_cast<int*>(carve(4 * ncell));          // sorted position -> cell
     int* s_sel = reinterpret_cast<int*>(carve(4 * ncell));
     unsigned short* s_kp = reinterpret_cast<unsigned short*>(carve(2 * (size_t)ncell * K));
     unsigned short* s_la = reinterpret_cast<unsigned short*>(carve(2 * (size_t)ncell * E));
+    unsigned short* s_am = reinterpret_cast<unsigned short*>(carve(2 * (size_t)ncell * E));   // arg-max map of this image
     int* s_misc = reinterpret_cast<int*>(carve(4 * (32 + 4)));      // wave counts [32], n, nsel, nkept
+    // after the NMS the box/key/mask region is dead: it is reused for the delta map [K][ncell] f32
+    float* s_delta = reinterpret_cast<float*>(smem);
 
     const float* img = head + (size_t)b * p.C * ncell;
     const float gridW = (float)(c.inW / W), gridH = (float)(c.inH / H);
@@ -258,28 +267,67 @@ parse_kernel(DecodeParams p, const float* __restrict__ head, const int* __restri
     greedy_nms(n, nwords, s_box, s_area, s_mask, s_sel, s_misc + 33, c.nms_thr, 0);
     const int nsel = s_misc[33];
 
-    // 5. one lane per surviving root: tree walk through the arg-max map (datatest.py:103-127)
-    bool keep_h = false;
+    // 5. one lane per surviving root: tree walk through the arg-max map (datatest.py:103-127).
+    // The walk is a chain of dependent look-ups, so the two tables it touches -- delta = resp*conf for every
+    // (keypoint, cell) and this image's arg-max map -- are first staged in LDS with coalesced loads.
     const unsigned short NONE = 0xFFFFu;
+    int root_cell = 0;
+    if (t < nsel) root_cell = s_cell[s_sel[t]];
+    __syncthreads();                                                  // everyone is done with box/key/mask
+    if (nsel > 0) {
+        // loads are issued in batches of 8 before their first use so that their latencies overlap
+        const int nd = K * ncell, stride = blockDim.x;
+        for (int i0 = t; i0 < nd; i0 += 8 * stride) {
+            float r[8], cf[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * stride;
+                r[u] = i < nd ? img[i] : 0.f;
+                cf[u] = i < nd ? img[(size_t)nd + i] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * stride;
+                if (i < nd) s_delta[i] = r[u] * cf[u];               // rt_test.py:130
+            }
+        }
+        const int* am_img = argmap + (size_t)b * E * ncell;
+        const int na = E * ncell;
+        for (int i0 = t; i0 < na; i0 += 8 * stride) {
+            int v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * stride;
+                v[u] = i < na ? am_img[i] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * stride;
+                if (i < na) s_am[i] = (unsigned short)v[u];
+            }
+        }
+    }
+    __syncthreads();
+    bool keep_h = false;
     if (t < nsel) {
         unsigned short* kp = s_kp + (size_t)t * K;
         unsigned short* la = s_la + (size_t)t * E;
         for (int k = 0; k < K; ++k) kp[k] = NONE;
         for (int e = 0; e < E; ++e) la[e] = NONE;
-        kp[0] = (unsigned short)s_cell[s_sel[t]];
+        kp[0] = (unsigned short)root_cell;
         int found = 0;
         for (int oi = 0; oi < E; ++oi) {
             const int e = c.edge_order[oi];
             const int s = c.edge_src[e], d = c.edge_dst[e];
             const unsigned short cs = kp[s];
             if (cs == NONE) continue;                                 // parent chain broke earlier
-            const int am = argmap[((size_t)b * E + e) * ncell + cs];
+            const int am = s_am[e * ncell + cs];
             la[e] = (unsigned short)am;
             const int jh = (int)cs / W + am / c.sW - c.sH / 2;
             const int jw = (int)cs % W + am % c.sW - c.sW / 2;
             if (jh < 0 || jw < 0 || jh >= H || jw >= W) continue;     // datatest.py:118
             const int cd = jh * W + jw;
-            if (delta_at(d, cd) < c.det_thr) continue;                // datatest.py:121 (== passes)
+            if (s_delta[d * ncell + cd] < c.det_thr) continue;        // datatest.py:121 (== passes)
             kp[d] = (unsigned short)cd;
             ++found;
         }
@@ -288,32 +336,39 @@ parse_kernel(DecodeParams p, const float* __restrict__ head, const int* __restri
     const int opos = block_compact(keep_h, s_misc, s_misc + 34);
     const int nkept = s_misc[34];
     if (t == 0) out_count[b] = nkept;
-    // 6. compact output rows
-    if (keep_h && opos < c.max_humans) {
-        const unsigned short* kp = s_kp + (size_t)t * K;
-        const unsigned short* la = s_la + (size_t)t * E;
-        const size_t row = (size_t)b * c.max_humans + opos;
-        for (int k = 0; k < K; ++k) {
-            const unsigned short cell = kp[k];
-            float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
-            float sc = 0.f;
-            if (cell != NONE) {
-                bb = bbox_at(k, cell);
-                sc = delta_at(k, cell);
-            }
-            out_kp_cell[row * K + k] = (cell == NONE) ? -1 : (int)cell;
-            reinterpret_cast<float4*>(out_bbox)[row * K + k] = bb;
-            out_score[row * K + k] = sc;
+    // 6. compact output rows.  The surviving humans' walk results stay in LDS; the (human, keypoint) and
+    // (human, edge) items are dealt over the whole workgroup so each thread has one short load chain.
+    if (keep_h && opos < c.max_humans) s_sel[opos] = t;             // output row -> walker thread
+    __syncthreads();
+    const int nout = min(nkept, c.max_humans);
+    for (int item = t; item < nout * K; item += blockDim.x) {
+        const int o = item / K, k = item - o * K;
+        const unsigned short cell = s_kp[(size_t)s_sel[o] * K + k];
+        float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
+        float sc = 0.f;
+        if (cell != NONE) {
+            bb = bbox_at(k, cell);
+            sc = s_delta[k * ncell + cell];
         }
-        for (int e = 0; e < E; ++e) out_limb_arg[row * E + e] = (la[e] == NONE) ? -1 : (int)la[e];
+        const size_t row = (size_t)b * c.max_humans + o;
+        out_kp_cell[row * K + k] = (cell == NONE) ? -1 : (int)cell;
+        reinterpret_cast<float4*>(out_bbox)[row * K + k] = bb;
+        out_score[row * K + k] = sc;
+    }
+    for (int item = t; item < nout * E; item += blockDim.x) {
+        const int o = item / E, e = item - o * E;
+        const unsigned short v = s_la[(size_t)s_sel[o] * E + e];
+        out_limb_arg[((size_t)b * c.max_humans + o) * E + e] = (v == NONE) ? -1 : (int)v;
     }
 }
 
 size_t parse_lds_bytes(int ncell, int K, int E) {
     const int nwords = (ncell + 63) / 64;
     auto r16 = [](size_t x) { return (x + 15) & ~size_t(15); };
-    return r16(16 * (size_t)ncell) + r16(8 * (size_t)ncell) + r16(8 * (size_t)ncell * nwords) +
-           r16(4 * (size_t)ncell) * 3 + r16(2 * (size_t)ncell * K) + r16(2 * (size_t)ncell * E) + r16(4 * 36);
+    size_t first = r16(16 * (size_t)ncell) + r16(8 * (size_t)ncell) + r16(8 * (size_t)ncell * nwords);
+    if (first < r16(4 * (size_t)K * ncell)) first = r16(4 * (size_t)K * ncell);   // reused as the delta map
+    return first + r16(4 * (size_t)ncell) * 3 + r16(2 * (size_t)ncell * K) + 2 * r16(2 * (size_t)ncell * E) +
+           r16(4 * 36);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -411,13 +466,19 @@ extern "C" int ppn_limb_argmax(const ppn_decode_cfg* cfg, const float* head, int
     dim3 grid(cfg->E, batch);
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (V == 4) {
-        PPN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(limb_argmax_kernel<4>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        {
+            static int max_lds_set = 0;   // the attribute sticks to the function: set it when it grows
+            PPN_LDS_ONCE(max_lds_set, reinterpret_cast<const void*>(limb_argmax_kernel<4>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        }
         hipLaunchKernelGGL(limb_argmax_kernel<4>, grid, dim3(threads), lds, st, head, out_arg, C, 6 * cfg->K, S,
                            ncell, Q, NS, cfg->E);
     } else {
-        PPN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(limb_argmax_kernel<1>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        {
+            static int max_lds_set = 0;   // the attribute sticks to the function: set it when it grows
+            PPN_LDS_ONCE(max_lds_set, reinterpret_cast<const void*>(limb_argmax_kernel<1>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        }
         hipLaunchKernelGGL(limb_argmax_kernel<1>, grid, dim3(threads), lds, st, head, out_arg, C, 6 * cfg->K, S,
                            ncell, Q, NS, cfg->E);
     }
@@ -448,8 +509,11 @@ extern "C" int ppn_decode(const ppn_decode_cfg* cfg, const float* head, int32_t 
     p.S = cfg->sH * cfg->sW;
     p.C = 6 * cfg->K + cfg->E * p.S;
     const int threads = ((ncell + 63) / 64) * 64;
-    PPN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(parse_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    {
+        static int max_lds_set = 0;   // the attribute sticks to the function: set it when it grows
+        PPN_LDS_ONCE(max_lds_set, reinterpret_cast<const void*>(parse_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
     hipLaunchKernelGGL(parse_kernel, dim3(batch), dim3(threads), lds, static_cast<hipStream_t>(stream), p, head,
                        argmap, out_count, out_kp_cell, out_limb_arg, out_bbox, out_score);
     PPN_LAUNCH_CHECK();
@@ -470,8 +534,11 @@ extern "C" int ppn_nms(const float* bbox, const float* score, int32_t n, float t
     if (n > 1024 || lds > 160 * 1024)
         return ppn::fail(PPN_E_UNSUPPORTED, "ppn_nms: n=%d needs %zu B of LDS (max 163840)", n, lds);
     const int threads = ((n + 63) / 64) * 64;
-    PPN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(nms_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    {
+        static int max_lds_set = 0;   // the attribute sticks to the function: set it when it grows
+        PPN_LDS_ONCE(max_lds_set, reinterpret_cast<const void*>(nms_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
     hipLaunchKernelGGL(nms_kernel, dim3(1), dim3(threads), lds, st, bbox, score, n, thresh, limit, out_sel,
                        out_count);
     PPN_LAUNCH_CHECK();

@@ -183,8 +183,11 @@ template <typename T, int COUT, int S>
 int launch(const Stem3Args& a, hipStream_t st) {
     using G = Geo<T, COUT, S>;
     auto k = stem3x3_kernel<T, COUT, S>;
-    PPN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      G::LDS_BYTES));
+    {
+        static int max_lds_set = 0;   // the attribute sticks to the function: set it when it grows
+        PPN_LDS_ONCE(max_lds_set, reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      G::LDS_BYTES);
+    }
     hipLaunchKernelGGL(k, dim3((unsigned)(a.tiles_x * a.tiles_y * a.B)), dim3(256), G::LDS_BYTES, st, a);
     PPN_LAUNCH_CHECK();
     return PPN_OK;

@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libppn.so")
+LIB_PATH = os.environ.get("PPN_LIB", os.path.join(_HERE, "csrc", "libppn.so"))   # PPN_LIB: diagnostic builds
 
 PPN_MAX_EDGES = 32
 PPN_MAX_KP = 32
