@@ -21,6 +21,13 @@
 
 namespace {
 
+#ifdef PPN_STAMP
+#define PPN_DT(i) do { if (threadIdx.x == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+    reinterpret_cast<unsigned long long*>(out_bbox + ((size_t)blockIdx.x * c.max_humans + c.max_humans - 1) * c.K * 4)[i] = t_; } } while (0)
+#else
+#define PPN_DT(i) do { } while (0)
+#endif
+
 constexpr int kWave = 64;
 
 struct DecodeParams {
@@ -150,34 +157,73 @@ __device__ __forceinline__ void greedy_nms(int n, int nwords, const float4* s_bo
                                            int limit) {
     const int t = threadIdx.x;
     // pairwise suppression bits: row i holds, for every higher-priority j < i, [iou(i,j) >= thr]
-    // (work item = one 64-bit word of one row, dealt round-robin so the triangular matrix is load balanced)
+    // Work item = one 64-bit word w of one row i.  Consecutive lanes take consecutive rows of the SAME word, so
+    // every lane of a wave reads the same s_box[j] (an LDS broadcast; the transposed assignment made 9 lanes hit
+    // one bank with 9 addresses) and whole waves of the empty upper triangle exit at once.
     for (int q = t; q < n * nwords; q += blockDim.x) {
-        const int i = q / nwords, w = q - i * nwords;
+        const int w = q / n, i = q - w * n;
         const int j0 = w * 64;
         const int j1 = min(j0 + 64, i);
         unsigned long long bits = 0ull;
         if (j0 < j1) {
             const float4 bi = s_box[i];
             const float ai = s_area[i];
-            for (int j = j0; j < j1; ++j) {
+            // four independent IoU chains in flight: one evaluation is a ~300-cycle dependent chain
+            // (LDS read, min/max, IEEE division) and only ~2 waves share a SIMD here
+            int j = j0;
+            for (; j + 4 <= j1; j += 4) {
+                bool r[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) r[u] = iou_ge(bi, ai, s_box[j + u], s_area[j + u], thr);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) bits |= r[u] ? (1ull << (j + u - j0)) : 0ull;
+            }
+            for (; j < j1; ++j) {
                 if (iou_ge(bi, ai, s_box[j], s_area[j], thr)) bits |= (1ull << (j - j0));
             }
         }
-        s_mask[q] = bits;
+        s_mask[(size_t)i * nwords + w] = bits;
     }
     __syncthreads();
-    // one wave resolves the greedy order: lane w owns keep-word w
+    // One wave resolves the greedy order, 64 candidates (one per lane) at a time:
+    //   (a) in parallel, a lane drops out if any already-kept box of an EARLIER chunk suppresses it;
+    //   (b) inside the chunk the dependence is sequential, but it runs on scalar registers only: the chunk's
+    //       own 64x64 bit block is walked with readlane, ~6 SALU instructions per candidate.
+    // Lane w keeps the keep-word of chunk w.  Identical to the one-by-one loop of datatest.py:143-156.
     if (t < kWave) {
-        unsigned long long keep = 0ull;
+        unsigned long long keep_w = 0ull;                            // lane w: kept bits of chunk w
         int nsel = 0;
-        for (int i = 0; i < n; ++i) {
-            unsigned long long m = (t < nwords) ? (s_mask[(size_t)i * nwords + t] & keep) : 0ull;
-            if (__ballot(m != 0ull) == 0ull) {
-                if (t == (i >> 6)) keep |= (1ull << (i & 63));
-                if (t == 0) s_sel[nsel] = i;
-                ++nsel;
-                if (limit > 0 && nsel >= limit) break;
+        const int nchunks = (n + 63) >> 6;
+        for (int cidx = 0; cidx < nchunks; ++cidx) {
+            const int i = (cidx << 6) + t;
+            const bool valid = i < n;
+            bool alive = valid;
+            const unsigned long long* rowp = s_mask + (size_t)(valid ? i : 0) * nwords;
+            const unsigned long long intra = valid ? rowp[cidx] : 0ull;
+            for (int w = 0; w < cidx; ++w) {
+                const unsigned long long kw = __shfl(keep_w, w);     // executed by all 64 lanes (no divergence)
+                if (valid && (rowp[w] & kw)) alive = false;
             }
+            const unsigned long long cand = __ballot(alive);
+            unsigned long long keepc = 0ull;
+            const unsigned lo = (unsigned)intra, hi = (unsigned)(intra >> 32);
+            for (int bpos = 0; bpos < 64; ++bpos) {
+                if ((cand >> bpos) & 1ull) {
+                    const unsigned long long row = ((unsigned long long)__builtin_amdgcn_readlane(hi, bpos) << 32) |
+                                                   (unsigned)__builtin_amdgcn_readlane(lo, bpos);
+                    if ((row & keepc) == 0ull) keepc |= (1ull << bpos);
+                }
+            }
+            if (limit > 0 && nsel + __popcll(keepc) > limit) {        // datatest.py:157-158: stop at `limit`
+                int room = limit - nsel;
+                unsigned long long trimmed = 0ull, rest = keepc;
+                while (room-- > 0 && rest) { const unsigned long long low = rest & (0ull - rest); trimmed |= low; rest ^= low; }
+                keepc = trimmed;
+            }
+            if ((keepc >> t) & 1ull) s_sel[nsel + __popcll(keepc & ((1ull << t) - 1ull))] = i;
+            if (t == cidx) keep_w = keepc;
+            nsel += __popcll(keepc);
+            if (limit > 0 && nsel >= limit) break;
         }
         if (t == 0) *s_nsel = nsel;
     }
@@ -213,7 +259,7 @@ parse_kernel(DecodeParams p, const float* __restrict__ head, const int* __restri
     unsigned short* s_kp = reinterpret_cast<unsigned short*>(carve(2 * (size_t)ncell * K));
     unsigned short* s_la = reinterpret_cast<unsigned short*>(carve(2 * (size_t)ncell * E));
     unsigned short* s_am = reinterpret_cast<unsigned short*>(carve(2 * (size_t)ncell * E));   // arg-max map of this image
-    int* s_misc = reinterpret_cast<int*>(carve(4 * (32 + 4)));      // wave counts [32], n, nsel, nkept
+    int* s_misc = reinterpret_cast<int*>(carve(4 * (36 + PPN_MAX_EDGES)));   // wave counts [32], n, nsel, nkept, -, edge table
     // after the NMS the box/key/mask region is dead: it is reused for the delta map [K][ncell] f32
     float* s_delta = reinterpret_cast<float*>(smem);
 
@@ -238,6 +284,7 @@ parse_kernel(DecodeParams p, const float* __restrict__ head, const int* __restri
         return r;
     };
 
+    PPN_DT(0);
     // 1. candidates: delta[0] > thr, row-major (datatest.py:89)
     float d0 = 0.0f;
     bool is_c = false;
@@ -252,6 +299,7 @@ parse_kernel(DecodeParams p, const float* __restrict__ head, const int* __restri
         s_key[pos] = ((unsigned long long)(~__float_as_uint(d0)) << 32) | (unsigned)t;
     }
     __syncthreads();
+    PPN_DT(1);
     // 2. rank sort; boxes/areas stored in priority order
     if (is_c) {
         const unsigned long long my = s_key[pos];
@@ -263,9 +311,11 @@ parse_kernel(DecodeParams p, const float* __restrict__ head, const int* __restri
         s_cell[rank] = t;
     }
     __syncthreads();
+    PPN_DT(2);
     // 3./4. greedy NMS on the root boxes (datatest.py:134-160)
     greedy_nms(n, nwords, s_box, s_area, s_mask, s_sel, s_misc + 33, c.nms_thr, 0);
     const int nsel = s_misc[33];
+    PPN_DT(3);
 
     // 5. one lane per surviving root: tree walk through the arg-max map (datatest.py:103-127).
     // The walk is a chain of dependent look-ups, so the two tables it touches -- delta = resp*conf for every
@@ -308,7 +358,16 @@ parse_kernel(DecodeParams p, const float* __restrict__ head, const int* __restri
         }
     }
     __syncthreads();
+    PPN_DT(4);
+    // packed skeleton table in LDS (the kernel-argument arrays would cost a scalar-memory round trip per hop)
+    int* s_edge = s_misc + 36;
+    if (t < E) {
+        const int e = c.edge_order[t];
+        s_edge[t] = e | (c.edge_src[e] << 8) | (c.edge_dst[e] << 16);
+    }
+    __syncthreads();
     bool keep_h = false;
+    const float rcpW = 1.0f / (float)W, rcpS = 1.0f / (float)c.sW;
     if (t < nsel) {
         unsigned short* kp = s_kp + (size_t)t * K;
         unsigned short* la = s_la + (size_t)t * E;
@@ -317,14 +376,17 @@ parse_kernel(DecodeParams p, const float* __restrict__ head, const int* __restri
         kp[0] = (unsigned short)root_cell;
         int found = 0;
         for (int oi = 0; oi < E; ++oi) {
-            const int e = c.edge_order[oi];
-            const int s = c.edge_src[e], d = c.edge_dst[e];
+            const int pk = s_edge[oi];
+            const int e = pk & 0xff, s = (pk >> 8) & 0xff, d = (pk >> 16) & 0xff;
             const unsigned short cs = kp[s];
             if (cs == NONE) continue;                                 // parent chain broke earlier
             const int am = s_am[e * ncell + cs];
             la[e] = (unsigned short)am;
-            const int jh = (int)cs / W + am / c.sW - c.sH / 2;
-            const int jw = (int)cs % W + am % c.sW - c.sW / 2;
+            // exact small-integer division through a float reciprocal ((x+0.5)/d is >= 0.5/d from an integer)
+            const int ch_ = (int)(((float)cs + 0.5f) * rcpW), cw_ = (int)cs - ch_ * W;
+            const int ah_ = (int)(((float)am + 0.5f) * rcpS), aw_ = am - ah_ * c.sW;
+            const int jh = ch_ + ah_ - c.sH / 2;
+            const int jw = cw_ + aw_ - c.sW / 2;
             if (jh < 0 || jw < 0 || jh >= H || jw >= W) continue;     // datatest.py:118
             const int cd = jh * W + jw;
             if (s_delta[d * ncell + cd] < c.det_thr) continue;        // datatest.py:121 (== passes)
@@ -333,6 +395,7 @@ parse_kernel(DecodeParams p, const float* __restrict__ head, const int* __restri
         }
         keep_h = c.min_kp <= found;                                   // datatest.py:129
     }
+    PPN_DT(5);
     const int opos = block_compact(keep_h, s_misc, s_misc + 34);
     const int nkept = s_misc[34];
     if (t == 0) out_count[b] = nkept;
@@ -360,6 +423,8 @@ parse_kernel(DecodeParams p, const float* __restrict__ head, const int* __restri
         const unsigned short v = s_la[(size_t)s_sel[o] * E + e];
         out_limb_arg[((size_t)b * c.max_humans + o) * E + e] = (v == NONE) ? -1 : (int)v;
     }
+    __syncthreads();
+    PPN_DT(6);
 }
 
 size_t parse_lds_bytes(int ncell, int K, int E) {
@@ -368,7 +433,7 @@ size_t parse_lds_bytes(int ncell, int K, int E) {
     size_t first = r16(16 * (size_t)ncell) + r16(8 * (size_t)ncell) + r16(8 * (size_t)ncell * nwords);
     if (first < r16(4 * (size_t)K * ncell)) first = r16(4 * (size_t)K * ncell);   // reused as the delta map
     return first + r16(4 * (size_t)ncell) * 3 + r16(2 * (size_t)ncell * K) + 2 * r16(2 * (size_t)ncell * E) +
-           r16(4 * 36);
+           r16(4 * (36 + PPN_MAX_EDGES));
 }
 
 // ------------------------------------------------------------------------------------------
