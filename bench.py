@@ -57,7 +57,7 @@ def cpu_baseline(arch, sample, size):
         for i in range(sample):
             D.decode_ref(head[i], insize=(size, size))
         reps += 1
-        if time.perf_counter() - t0 > 10.0 or reps >= 5:
+        if time.perf_counter() - t0 > 10.0 or reps >= 200:
             break
     dt = time.perf_counter() - t0
     return {"value": round(sample * reps / dt, 3), "unit": "images/sec", "cores": torch.get_num_threads(),
@@ -134,7 +134,7 @@ def main():
         agg, table = {}, []
         reps = 5
         for r in range(reps):
-            for name, kern, ms, fl in net.profile_layers(frames, src_is_u8=True):
+            for name, kern, ms, fl in net.profile_layers(frames, src_is_u8=True, repeats=4):
                 a = agg.setdefault(kern, [0.0, 0.0, 0])
                 a[0] += ms; a[1] += fl; a[2] += 1
                 if r == 0:

@@ -157,8 +157,11 @@ int ppn_plan_add_stem(ppn_plan* p, int32_t dtype, int32_t src_is_u8, const void*
 /* Re-point the first layer's input (same shape/dtype as at ppn_plan_add_stem) before a run. */
 int ppn_plan_set_input(ppn_plan* p, const void* src);
 int ppn_plan_run(ppn_plan* p, void* stream);
-/* Same as ppn_plan_run but brackets every launch with HIP events on `stream`; ms[i] = duration of launch i. */
-int ppn_plan_run_timed(ppn_plan* p, void* stream, float* ms, int32_t n_ms);
+/* Same as ppn_plan_run but brackets every launch with HIP events on `stream`; ms[i] = duration of launch i.
+ * Each launch is issued `repeats` (>= 1) times back to back between its two events and the elapsed time is
+ * divided by `repeats`, which amortises the event/launch gap (launches are idempotent: no output aliases an
+ * input).  Synchronises on the last event. */
+int ppn_plan_run_timed(ppn_plan* p, void* stream, float* ms, int32_t n_ms, int32_t repeats);
 int ppn_plan_size(const ppn_plan* p);
 /* Name of the kernel launch i dispatches (as it appears in rocprofv3 --kernel-trace). */
 const char* ppn_plan_kernel_name(const ppn_plan* p, int32_t i);

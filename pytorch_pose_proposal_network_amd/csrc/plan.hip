@@ -83,7 +83,7 @@ extern "C" int ppn_plan_run(ppn_plan* p, void* stream) {
     return PPN_OK;
 }
 
-extern "C" int ppn_plan_run_timed(ppn_plan* p, void* stream, float* ms, int32_t n_ms) {
+extern "C" int ppn_plan_run_timed(ppn_plan* p, void* stream, float* ms, int32_t n_ms, int32_t repeats) {
     if (!p || !ms) return ppn::fail(PPN_E_INVALID, "ppn_plan_run_timed: NULL argument");
     const size_t n = p->ops.size();
     if ((size_t)n_ms < n) return ppn::fail(PPN_E_INVALID, "ms buffer too small (%d < %zu)", n_ms, n);
@@ -94,12 +94,17 @@ extern "C" int ppn_plan_run_timed(ppn_plan* p, void* stream, float* ms, int32_t 
         p->events.push_back(e);
     }
     PPN_HIP_CHECK(hipEventRecord(p->events[0], st));
+    if (repeats < 1) repeats = 1;
     for (size_t i = 0; i < n; ++i) {
-        if (int rc = run_op(p->ops[i], st)) return rc;
+        for (int r = 0; r < repeats; ++r)
+            if (int rc = run_op(p->ops[i], st)) return rc;
         PPN_HIP_CHECK(hipEventRecord(p->events[i + 1], st));
     }
     PPN_HIP_CHECK(hipEventSynchronize(p->events[n]));
-    for (size_t i = 0; i < n; ++i) PPN_HIP_CHECK(hipEventElapsedTime(&ms[i], p->events[i], p->events[i + 1]));
+    for (size_t i = 0; i < n; ++i) {
+        PPN_HIP_CHECK(hipEventElapsedTime(&ms[i], p->events[i], p->events[i + 1]));
+        ms[i] /= (float)repeats;
+    }
     return PPN_OK;
 }
 

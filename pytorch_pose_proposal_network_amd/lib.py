@@ -62,7 +62,7 @@ _SIGNATURES = {
                           [C.c_void_p] * 3 + [C.POINTER(C.c_float)] * 2 + [C.c_void_p]),
     "ppn_plan_set_input": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ppn_plan_run": (C.c_int, [C.c_void_p, C.c_void_p]),
-    "ppn_plan_run_timed": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.c_int32]),
+    "ppn_plan_run_timed": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.c_int32, C.c_int32]),
     "ppn_plan_size": (C.c_int, [C.c_void_p]),
     "ppn_plan_kernel_name": (C.c_char_p, [C.c_void_p, C.c_int32]),
     "ppn_plan_destroy": (C.c_int, [C.c_void_p]),

@@ -256,11 +256,13 @@ class PoseProposalNet:
         L.check(self._lib.ppn_plan_run(plan.handle, L.current_stream_ptr()), "ppn_plan_run")
         return plan.head
 
-    def profile_layers(self, x: torch.Tensor, src_is_u8: bool = False):
-        """Per-launch durations (ms) measured with HIP events on the launch stream: [(op name, kernel, ms, flops)]."""
+    def profile_layers(self, x: torch.Tensor, src_is_u8: bool = False, repeats: int = 1):
+        """Per-launch durations (ms) measured with HIP events on the launch stream: [(op name, kernel, ms, flops)].
+        `repeats` launches of each op are issued back to back between its events (amortises the event gap)."""
         plan = self._plan_for(x.contiguous(), src_is_u8)
         ms = (C.c_float * plan.n_ops)()
-        L.check(self._lib.ppn_plan_run_timed(plan.handle, L.current_stream_ptr(), ms, plan.n_ops), "ppn_plan_run_timed")
+        L.check(self._lib.ppn_plan_run_timed(plan.handle, L.current_stream_ptr(), ms, plan.n_ops, repeats),
+                "ppn_plan_run_timed")
         b = x.shape[0]
         h, w = (x.shape[1], x.shape[2]) if src_is_u8 else (x.shape[2], x.shape[3])
         shapes = A.tensor_shapes(self._ops, h, w)
