@@ -41,6 +41,27 @@ def load_bn_stats(arch, seed=0):
     return {k: g[k] for k in g.files}
 
 
+def pmc_traffic(kernel_name):
+    """HBM bytes per launch of `kernel_name` from the committed rocprofv3 PMC passes (tools/pmc_bench.sh ->
+    profiles/*_pmc_traffic.json: FETCH_SIZE x2 (gfx950 wide-read correction) + WRITE_SIZE, separate passes).
+    bench.py cannot run the profiler itself; returns None when no measurement of this kernel is committed."""
+    import glob
+    import re
+    m = re.match(r"(\w+)<(.*)>", kernel_name)
+    if not m:
+        return None
+    parts = [a.strip() for a in m.group(2).split(",")]
+    frag = m.group(1) + "I" + "".join(("DF16b" if a == "__bf16" else "f" if a == "float" else
+                                       ("Lb1E" if a == "true" else "Lb0E" if a == "false" else f"Li{a}E"))
+                                      for a in parts)
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
+        table = json.load(open(path))
+        for k, v in table.items():
+            if frag in k:
+                return {"bytes_per_launch": v["hbm_bytes_per_launch"], "source": os.path.basename(path)}
+    return None
+
+
 def cpu_baseline(arch, sample, size):
     """The oracle timed on this host's cores on `sample` frames of the same workload (reported, not a target)."""
     from oracle import decode_ref as D, forward_ref as Fr
@@ -167,7 +188,9 @@ def main():
                        "parallelism": f"frames sharded over {world} GPU(s), no data-path collective"},
             "roofline": {"bound": "mfma", "kernel": dk, "launches_per_step": dn // reps,
                          "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(achieved / peak, 4), "traffic": None,
+                         "frac": round(achieved / peak, 4),
+                         "traffic": (pmc_traffic(dk) or {}).get("bytes_per_launch"),
+                         "traffic_source": (pmc_traffic(dk) or {}).get("source"),
                          "avg_launch_us": round(dms / dn * 1e3, 2),
                          "flops_per_launch_avg": round(dfl / dn)},
             "conv_stack": {"ms": round(fwd_ms, 4), "tflops": round(fwd_flops / fwd_ms / 1e9, 2),

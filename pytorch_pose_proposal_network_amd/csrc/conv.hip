@@ -382,7 +382,8 @@ extern "C" int ppn_conv_tiling(int32_t dtype, int32_t cin, int32_t cout, int32_t
     if (k_step) *k_step = bk;
     BigTile bt;
     const bool big = (cin % bk == 0) && big_tile_for(cout, 1, &bt);
-    if (cout_tile) *cout_tile = big ? bt.bc : choose_tile(cout).bc;
+    // pad granularity = the LARGEST channel tile the launcher may pick for this Cout (it chooses per problem size)
+    if (cout_tile) *cout_tile = big ? (cout >= 256 ? 256 : (cout >= 128 ? 128 : 64)) : choose_tile(cout).bc;
     if (k_order) *k_order = big ? 1 : 0;
     return PPN_OK;
 }

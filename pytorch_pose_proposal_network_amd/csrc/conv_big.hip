@@ -486,22 +486,22 @@ bool big_tile_for(int cout, long long m, BigTile* out) {
         out->bp = 192; out->bc = 128;
         return true;
     }
-    const int bc = cout >= 256 ? 256 : (cout >= 128 ? 128 : 64);
-    const long long nct = (cout + bc - 1) / bc;
-    const long long slots = bc == 64 ? 512 : 256;
+    // time ~ ceil(tiles / 256 CUs) * tile area / eff(tile); eff = relative throughput of a tile shape measured on
+    // the 48x48x512 3x3 layers at batch 32 (tools/bench_conv.py with PPN_CONV_TILE), i.e. how well its FLOPs per
+    // staged byte feed the MFMA pipe.  For Cout = 256 the 128-channel tile wins through quantisation
+    // (768 workgroups = 3 full rounds instead of 384 = 1.5).
+    struct Cand { int bp, bc; double eff; };
+    static const Cand cands[] = {{256, 256, 1.27}, {192, 256, 1.10}, {128, 256, 0.92}, {256, 128, 0.90},
+                                 {192, 128, 0.95}, {128, 128, 0.87}, {256, 64, 0.60},  {128, 64, 0.55}};
+    const int bc_max = cout >= 256 ? 256 : (cout >= 128 ? 128 : 64);
+    const int bc_min = cout >= 256 ? 128 : bc_max;
     double best = 1e30;
-    int best_bp = 256;
-    for (int bp : {256, 192, 128}) {
-        if (bc == 64 && bp == 192) continue;                         // 2x3 MFMA tiles per wave do not group by 4
-        const long long tiles = ((m + bp - 1) / bp) * nct;
-        const long long rounds = (tiles + slots - 1) / slots;
-        // time ~ rounds * (work per tile); smaller tiles stage more bytes per FLOP
-        const double eff = bp == 256 ? 1.0 : (bp == 192 ? 0.95 : 0.85);
-        const double cost = (double)rounds * bp / eff;
-        if (cost < best) { best = cost; best_bp = bp; }
+    for (const Cand& cd : cands) {
+        if (cd.bc > bc_max || cd.bc < bc_min) continue;
+        const long long tiles = ((m + cd.bp - 1) / cd.bp) * ((cout + cd.bc - 1) / cd.bc);
+        const double cost = (double)((tiles + 255) / 256) * cd.bp * cd.bc / cd.eff;
+        if (cost < best) { best = cost; out->bp = cd.bp; out->bc = cd.bc; }
     }
-    out->bp = best_bp;
-    out->bc = bc;
     return true;
 }
 

@@ -45,7 +45,7 @@ def test_library_loads_and_reports_errors_without_gpu():
     assert l.ppn_conv_tiling(lib.PPN_BF16, 512, 512, 3, C.byref(k), C.byref(c), C.byref(o)) == 0
     assert (k.value, c.value, o.value) == (64, 256, 1)
     assert l.ppn_conv_tiling(lib.PPN_F32, 512, 7605, 1, C.byref(k), C.byref(c), C.byref(o)) == 0
-    assert (k.value, c.value) == (32, 128)      # the store-bound head conv uses the 192x128 tile
+    assert (k.value, c.value) == (32, 256)      # pad granularity = largest channel tile for this Cout
     assert l.ppn_conv_tiling(lib.PPN_BF16, 16, 32, 3, C.byref(k), C.byref(c), C.byref(o)) == 0
     assert o.value == 2 and k.value == 144
     assert l.ppn_conv_tiling(7, 16, 32, 3, None, None, None) != 0
