@@ -75,6 +75,12 @@ int ppn_decode(const ppn_decode_cfg* cfg, const float* head, int32_t batch, void
                int32_t* out_count, int32_t* out_kp_cell, int32_t* out_limb_arg, float* out_bbox,
                float* out_score, void* stream);
 
+/* ppn_decode for the fused head conv: `unary` f32 [batch, 6K, H, W] and `keys` u64 [batch, E, H, W] as written
+ * by ppn_conv2d_fused with argmax_keys set.  Same outputs, bit-identical to ppn_decode on the full head. */
+int ppn_decode_fused(const ppn_decode_cfg* cfg, const float* unary, const uint64_t* keys, int32_t batch,
+                     int32_t* out_count, int32_t* out_kp_cell, int32_t* out_limb_arg, float* out_bbox,
+                     float* out_score, void* stream);
+
 /* First half of ppn_decode on its own (the HBM-bound kernel): dense first-index arg-max over the
  * sH*sW limb window for every (image, edge, cell).  out_arg i32 [batch, E, H, W]. */
 int ppn_limb_argmax(const ppn_decode_cfg* cfg, const float* head, int32_t batch, int32_t* out_arg,
@@ -119,6 +125,16 @@ typedef struct ppn_conv_desc {
     const float* shift2;         /* [cout] or NULL                                                    */
     void* out_act;               /* NHWC dtype or NULL                                                */
     const void* zero_page;       /* >= 256 B of zeros on device (padding source)                      */
+    /* Fused decode front end for the head conv (out_nchw_f32 = 1): when argmax_keys != NULL the epilogue also
+     * writes the first `unary_channels` (= 6K) sigmoid outputs to `unary_out` f32 [B,unary_channels,H,W] and folds
+     * every limb channel into `argmax_keys` u64 [B,E,H,W] (key = value bits << 32 | ~window index; the caller
+     * zeroes the buffer before the launch, see ppn_plan_add_memset).  out_raw may then be NULL: the 17.5 MB/image
+     * head tensor is never written (rt_test.py:109-120 copies it to the host instead).  ppn_decode_fused consumes
+     * the two buffers. */
+    float* unary_out;
+    uint64_t* argmax_keys;
+    int32_t unary_channels;      /* 6K = 108                                                          */
+    int32_t limb_window;         /* sH*sW = 441                                                       */
 } ppn_conv_desc;
 
 /* GEMM-depth step / channel tile the packer must pad to for a conv of this shape and dtype, and the order of
@@ -151,6 +167,8 @@ int ppn_stem7x7(int32_t dtype, int32_t src_is_u8, const void* src, int32_t batch
 typedef struct ppn_plan ppn_plan;
 int ppn_plan_create(ppn_plan** out);
 int ppn_plan_add_conv(ppn_plan* p, const ppn_conv_desc* d);
+/* hipMemsetAsync(ptr, 0, bytes) as a step of the plan (zeroes the arg-max keys of the fused head conv). */
+int ppn_plan_add_memset(ppn_plan* p, void* ptr, size_t bytes);
 int ppn_plan_add_stem(ppn_plan* p, int32_t dtype, int32_t src_is_u8, const void* src, int32_t batch, int32_t h,
                       int32_t w, const float* weight, const float* scale, const float* shift, const float* mean,
                       const float* std_, void* out);

@@ -423,10 +423,15 @@ int ppn::conv_launch(const ppn_conv_desc* d, hipStream_t st, const char** kname)
     if (d->cout_pad % bc != 0 || d->cout_pad < d->cout)
         return ppn::fail(PPN_E_INVALID, "cout_pad %d must be a multiple of %d and >= cout", d->cout_pad, bc);
     if (!d->src || !d->weight || !d->zero_page) return ppn::fail(PPN_E_INVALID, "NULL src/weight/zero_page");
-    if (!d->out_raw && !d->out_act) return ppn::fail(PPN_E_INVALID, "conv has no output");
+    if (!d->out_raw && !d->out_act && !d->argmax_keys) return ppn::fail(PPN_E_INVALID, "conv has no output");
+    if (d->argmax_keys && (!d->out_nchw_f32 || !d->unary_out || d->unary_channels < 0 || d->limb_window < 1 ||
+                           d->unary_channels > d->cout || (d->cout - d->unary_channels) % d->limb_window != 0))
+        return ppn::fail(PPN_E_INVALID, "fused arg-max needs the NCHW head mode, unary_out and cout = unary + E*window");
+    if (d->argmax_keys && d->act1 != PPN_ACT_SIGMOID)
+        return ppn::fail(PPN_E_INVALID, "fused arg-max keys assume non-negative (sigmoid) outputs");
     if (d->out_nchw_f32) {
-        if (d->residual || d->out_act || !d->out_raw)
-            return ppn::fail(PPN_E_UNSUPPORTED, "NCHW head output supports out_raw only");
+        if (d->residual || d->out_act || (!d->out_raw && !d->argmax_keys))
+            return ppn::fail(PPN_E_UNSUPPORTED, "NCHW head output supports out_raw / fused arg-max only");
     } else if (d->cout % 8 != 0) {
         return ppn::fail(PPN_E_UNSUPPORTED, "NHWC output needs cout %% 8 == 0 (got %d)", d->cout);
     }
@@ -448,7 +453,12 @@ int ppn::conv_launch(const ppn_conv_desc* d, hipStream_t st, const char** kname)
     a.log2Cin = log2c < 0 ? 0 : log2c;
     a.n_ctiles = d->cout_pad / bc;
     a.n_ptiles = (int)((m + bp - 1) / bp);
+    a.unary_out = d->unary_out;
+    a.amax_keys = reinterpret_cast<unsigned long long*>(d->argmax_keys);
+    a.unary_ch = d->unary_channels;
+    a.window = d->limb_window;
     if (big) return launch_big(a, d->dtype, bt, st, kname);
+    if (d->argmax_keys) return ppn::fail(PPN_E_UNSUPPORTED, "fused arg-max is implemented by the large-tile kernel only");
     if (d->dtype == PPN_F32) return launch_dtype<float>(a, smallc, tc, st, kname);
     return launch_dtype<__bf16>(a, smallc, tc, st, kname);
 }

@@ -16,7 +16,8 @@
 // BP is picked per layer so that the number of workgroups is close to a multiple of the 256 CUs.
 // K loop: two named fragment sets; the MFMAs of one set cover the LDS reads of the other and the DMA issue
 // of the next stage, so the matrix pipe restarts immediately after the per-step barrier.
-// Epilogue through LDS in 64-pixel (NHWC) / 64-channel (NCHW head) chunks: 16-byte coalesced stores.
+// Epilogue through LDS in 64-pixel (NHWC) / 64-channel (NCHW head) chunks: 16-byte coalesced stores.  The head
+// conv can additionally (or instead) run the decode's limb arg-max in its epilogue (ppn_conv_desc.argmax_keys).
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
@@ -380,6 +381,47 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
                     for (int r = 0; r < 4; ++r) ct[(ch + r) * LD + px] = acc[q * IC + ii][j][r];
                 }
             __syncthreads();
+            if (a.amax_keys) {
+                // Fused decode front end: one thread per (pixel, 32-channel run).  Channels < unary_ch (resp, conf,
+                // x, y, w, h) go to the compact tensor; every limb channel competes in its (image, edge, cell)
+                // arg-max through one 64-bit atomicMax per run and edge:  key = value bits << 32 | ~s  (sigmoid
+                // outputs are >= 0 so the bit pattern is monotonic; ~s makes the LOWEST window index win ties,
+                // np.argmax semantics of datatest.py:113).
+                const int nedges = (a.Cout - a.unary_ch) / a.window;
+                for (int item = tid; item < 2 * BP; item += NT) {
+                    const int cw = item / BP, px = item - cw * BP;
+                    const int m = m0 + px;
+                    if (m >= a.M) continue;
+                    const int nb = m / a.HoWo, np = m - nb * a.HoWo;
+                    int c = c0 + cw * (BC / 2) + q * IC * 16;        // first channel of this 32-row run
+                    int e = -1, sidx = 0;
+                    if (c >= a.unary_ch) { e = (c - a.unary_ch) / a.window; sidx = (c - a.unary_ch) - e * a.window; }
+                    float best = -1.f;
+                    int best_s = 0;
+                    auto flush = [&]() {
+                        if (best >= 0.f && e >= 0 && e < nedges) {
+                            const unsigned long long key = ((unsigned long long)__float_as_uint(best) << 32) |
+                                                           (unsigned)(0xFFFFFFFFu - (unsigned)best_s);
+                            atomicMax(a.amax_keys + ((size_t)nb * nedges + e) * a.HoWo + np, key);
+                        }
+                        best = -1.f;
+                    };
+                    for (int r = 0; r < IC * 16; ++r, ++c) {
+                        if (c >= a.Cout) break;
+                        const float s1 = a.scale1 ? a.scale1[c] : 1.f, b1 = a.shift1 ? a.shift1[c] : 0.f;
+                        const float v = apply_act(ct[(cw * IC * 16 + r) * LD + px] * s1 + b1, a.act1);
+                        if (c < a.unary_ch) {
+                            a.unary_out[((size_t)nb * a.unary_ch + c) * a.HoWo + np] = v;
+                            if (c + 1 == a.unary_ch) { e = 0; sidx = 0; }
+                            continue;
+                        }
+                        if (v > best) { best = v; best_s = sidx; }   // strict: first maximum of the run
+                        if (++sidx == a.window) { flush(); sidx = 0; ++e; }
+                    }
+                    flush();
+                }
+            }
+            if (out)
             for (int item = tid; item < NITEM; item += NT) {
                 const int chl = item / TPC, pq = item - chl * TPC;   // 0 .. 2*IC*16-1
                 const int cw = chl / (IC * 16), ci = (chl / 16) % IC, cr = chl % 16;

@@ -28,6 +28,10 @@ struct ConvKArgs {
     int act1, act2, nchw;
     int log2Cin;
     int n_ctiles, n_ptiles;
+    // fused head mode (ppn_conv_desc.argmax_keys): unary channels -> compact tensor, limb windows -> arg-max keys
+    float* unary_out;                 // f32 [B][unary_ch][HoWo]
+    unsigned long long* amax_keys;    // u64 [B][n_edges][HoWo], zeroed by the caller
+    int unary_ch, window;             // 6K (108), sH*sW (441)
 };
 
 template <typename T>

@@ -32,9 +32,10 @@ constexpr int kWave = 64;
 
 struct DecodeParams {
     ppn_decode_cfg c;
-    int C;       // channels per image = 6K + E*sH*sW
+    int C;       // channels per image of `head` = 6K + E*sH*sW (6K for the compact unary tensor of the fused path)
     int ncell;   // H*W
     int S;       // sH*sW
+    const unsigned long long* keys;   // fused path: arg-max keys u64 [B][E][ncell] instead of the int arg-max map
 };
 
 // ------------------------------------------------------------------------------------------
@@ -342,13 +343,15 @@ parse_kernel(DecodeParams p, const float* __restrict__ head, const int* __restri
             }
         }
         const int* am_img = argmap + (size_t)b * E * ncell;
+        const unsigned long long* key_img = p.keys + (size_t)b * E * ncell;
         const int na = E * ncell;
         for (int i0 = t; i0 < na; i0 += 8 * stride) {
             int v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int i = i0 + u * stride;
-                v[u] = i < na ? am_img[i] : 0;
+                if (p.keys) v[u] = i < na ? (int)(0xFFFFFFFFu - (unsigned)key_img[i]) : 0;   // key = value<<32 | ~s
+                else v[u] = i < na ? am_img[i] : 0;
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -573,6 +576,7 @@ extern "C" int ppn_decode(const ppn_decode_cfg* cfg, const float* head, int32_t 
     p.ncell = ncell;
     p.S = cfg->sH * cfg->sW;
     p.C = 6 * cfg->K + cfg->E * p.S;
+    p.keys = nullptr;
     const int threads = ((ncell + 63) / 64) * 64;
     {
         static int max_lds_set = 0;   // the attribute sticks to the function: set it when it grows
@@ -581,6 +585,39 @@ extern "C" int ppn_decode(const ppn_decode_cfg* cfg, const float* head, int32_t 
     }
     hipLaunchKernelGGL(parse_kernel, dim3(batch), dim3(threads), lds, static_cast<hipStream_t>(stream), p, head,
                        argmap, out_count, out_kp_cell, out_limb_arg, out_bbox, out_score);
+    PPN_LAUNCH_CHECK();
+    return PPN_OK;
+}
+
+extern "C" int ppn_decode_fused(const ppn_decode_cfg* cfg, const float* unary, const uint64_t* keys, int32_t batch,
+                                int32_t* out_count, int32_t* out_kp_cell, int32_t* out_limb_arg, float* out_bbox,
+                                float* out_score, void* stream) {
+    if (int rc = check_cfg(cfg)) return rc;
+    if (batch < 0) return ppn::fail(PPN_E_INVALID, "ppn_decode_fused: batch < 0");
+    if (batch == 0) return PPN_OK;
+    if (!unary || !keys || !out_count || !out_kp_cell || !out_limb_arg || !out_bbox || !out_score)
+        return ppn::fail(PPN_E_INVALID, "ppn_decode_fused: NULL pointer");
+    if (cfg->max_humans < 1) return ppn::fail(PPN_E_INVALID, "ppn_decode_fused: max_humans < 1");
+    if (reinterpret_cast<uintptr_t>(out_bbox) % 16 != 0)
+        return ppn::fail(PPN_E_INVALID, "ppn_decode_fused: out_bbox must be 16-byte aligned");
+    const int ncell = cfg->H * cfg->W;
+    const size_t lds = parse_lds_bytes(ncell, cfg->K, cfg->E);
+    if (ncell > 1024 || lds > 160 * 1024)
+        return ppn::fail(PPN_E_UNSUPPORTED, "grid of %d cells needs %zu B of LDS (max 163840)", ncell, lds);
+    DecodeParams p;
+    p.c = *cfg;
+    p.ncell = ncell;
+    p.S = cfg->sH * cfg->sW;
+    p.C = 6 * cfg->K;                                                 // compact unary tensor
+    p.keys = reinterpret_cast<const unsigned long long*>(keys);
+    const int threads = ((ncell + 63) / 64) * 64;
+    {
+        static int max_lds_set = 0;
+        PPN_LDS_ONCE(max_lds_set, reinterpret_cast<const void*>(parse_kernel),
+                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
+    hipLaunchKernelGGL(parse_kernel, dim3(batch), dim3(threads), lds, static_cast<hipStream_t>(stream), p, unary,
+                       static_cast<const int*>(nullptr), out_count, out_kp_cell, out_limb_arg, out_bbox, out_score);
     PPN_LAUNCH_CHECK();
     return PPN_OK;
 }

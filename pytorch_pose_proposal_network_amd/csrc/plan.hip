@@ -15,7 +15,9 @@ int stem_launch(int dtype, int src_is_u8, const void* src, int batch, int h, int
 
 struct ppn_plan {
     struct Op {
-        int kind;  // 0 conv, 1 stem
+        int kind;  // 0 conv, 1 stem, 2 memset
+        void* ms_ptr = nullptr;
+        size_t ms_bytes = 0;
         ppn_conv_desc conv;
         int dtype, src_is_u8, batch, h, w;
         const void* src;
@@ -29,6 +31,11 @@ struct ppn_plan {
 };
 
 static int run_op(ppn_plan::Op& op, hipStream_t st) {
+    if (op.kind == 2) {
+        if (op.kname.empty()) op.kname = "hipMemsetAsync";
+        PPN_HIP_CHECK(hipMemsetAsync(op.ms_ptr, 0, op.ms_bytes, st));
+        return PPN_OK;
+    }
     if (op.kind == 0) {
         const char* kn = nullptr;
         int rc = ppn::conv_launch(&op.conv, st, &kn);
@@ -51,6 +58,16 @@ extern "C" int ppn_plan_add_conv(ppn_plan* p, const ppn_conv_desc* d) {
     ppn_plan::Op op{};
     op.kind = 0;
     op.conv = *d;
+    p->ops.push_back(op);
+    return PPN_OK;
+}
+
+extern "C" int ppn_plan_add_memset(ppn_plan* p, void* ptr, size_t bytes) {
+    if (!p || !ptr) return ppn::fail(PPN_E_INVALID, "ppn_plan_add_memset: NULL argument");
+    ppn_plan::Op op{};
+    op.kind = 2;
+    op.ms_ptr = ptr;
+    op.ms_bytes = bytes;
     p->ops.push_back(op);
     return PPN_OK;
 }

@@ -113,6 +113,20 @@ class Decoder:
                                     o.bbox.data_ptr(), o.score.data_ptr(), L.current_stream_ptr()), "ppn_decode")
         return o
 
+    def decode_fused(self, unary: torch.Tensor, keys: torch.Tensor) -> DecodeResult:
+        """Decode from the fused head conv's outputs (PoseProposalNet.forward_u8(..., fused_decode=True))."""
+        c = self.cfg
+        if tuple(unary.shape) != (self.batch, 6 * c.K, c.H, c.W) or unary.dtype != torch.float32:
+            raise ValueError(f"unary must be f32 {(self.batch, 6 * c.K, c.H, c.W)}")
+        if tuple(keys.shape) != (self.batch, c.E, c.H, c.W) or keys.dtype != torch.int64:
+            raise ValueError(f"keys must be i64 {(self.batch, c.E, c.H, c.W)}")
+        o = self.out
+        L.check(self.lib.ppn_decode_fused(C.byref(c), unary.data_ptr(), keys.data_ptr(), self.batch,
+                                          o.count.data_ptr(), o.kp_cell.data_ptr(), o.limb_arg.data_ptr(),
+                                          o.bbox.data_ptr(), o.score.data_ptr(), L.current_stream_ptr()),
+                "ppn_decode_fused")
+        return o
+
     def limb_argmax(self, head: torch.Tensor) -> torch.Tensor:
         c = self.cfg
         out = self.workspace[: self.batch * c.E * c.H * c.W].view(self.batch, c.E, c.H, c.W)

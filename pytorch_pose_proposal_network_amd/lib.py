@@ -33,6 +33,8 @@ class ConvDesc(C.Structure):
         ("src", C.c_void_p), ("weight", C.c_void_p), ("scale1", C.c_void_p), ("shift1", C.c_void_p),
         ("residual", C.c_void_p), ("out_raw", C.c_void_p), ("scale2", C.c_void_p), ("shift2", C.c_void_p),
         ("out_act", C.c_void_p), ("zero_page", C.c_void_p),
+        ("unary_out", C.c_void_p), ("argmax_keys", C.c_void_p), ("unary_channels", C.c_int32),
+        ("limb_window", C.c_int32),
     ]
 
 
@@ -48,6 +50,8 @@ _SIGNATURES = {
     "ppn_decode_workspace_bytes": (C.c_size_t, [C.POINTER(DecodeCfg), C.c_int32]),
     "ppn_decode": (C.c_int, [C.POINTER(DecodeCfg), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ppn_decode_fused": (C.c_int, [C.POINTER(DecodeCfg), C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ppn_limb_argmax": (C.c_int, [C.POINTER(DecodeCfg), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "ppn_nms": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_int32, C.c_void_p, C.c_void_p,
                           C.c_void_p]),
@@ -58,6 +62,7 @@ _SIGNATURES = {
                     [C.c_void_p] * 3 + [C.POINTER(C.c_float)] * 2 + [C.c_void_p, C.c_void_p]),
     "ppn_plan_create": (C.c_int, [C.POINTER(C.c_void_p)]),
     "ppn_plan_add_conv": (C.c_int, [C.c_void_p, C.POINTER(ConvDesc)]),
+    "ppn_plan_add_memset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "ppn_plan_add_stem": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32] +
                           [C.c_void_p] * 3 + [C.POINTER(C.c_float)] * 2 + [C.c_void_p]),
     "ppn_plan_set_input": (C.c_int, [C.c_void_p, C.c_void_p]),

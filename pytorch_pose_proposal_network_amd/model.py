@@ -49,8 +49,10 @@ def _arch_of(backbone) -> str:
 
 
 class _Plan:
-    def __init__(self, handle, buffers, head, n_ops, flops):
-        self.handle, self.buffers, self.head, self.n_ops, self.flops = handle, buffers, head, n_ops, flops
+    def __init__(self, handle, buffers, head, entries, flops):
+        self.handle, self.buffers, self.head, self.flops = handle, buffers, head, flops
+        self.entries = entries          # [(name, flops)] aligned with the plan's launches
+        self.n_ops = len(entries)
 
 
 class PoseProposalNet:
@@ -173,7 +175,7 @@ class PoseProposalNet:
         t = self._dev.get(key) if key else None
         return t.data_ptr() if t is not None else None
 
-    def _build_plan(self, batch: int, h: int, w: int, src: torch.Tensor, src_is_u8: bool) -> _Plan:
+    def _build_plan(self, batch: int, h: int, w: int, src: torch.Tensor, src_is_u8: bool, fused: bool = False) -> _Plan:
         lib = self._lib
         dev = self.device
         tdt = torch.float32 if self.compute_dtype == L.PPN_F32 else torch.bfloat16
@@ -188,9 +190,18 @@ class PoseProposalNet:
                 bufs[name] = torch.empty(batch, th, tw, tc, dtype=tdt, device=dev)
         handle = C.c_void_p()
         L.check(lib.ppn_plan_create(C.byref(handle)), "ppn_plan_create")
+        entries = []
+        if fused:
+            # decode front end fused into the head conv: the head tensor is never materialised
+            th, tw, _ = shapes["head"]
+            n_unary = 6 * len(self.keypoint_names)
+            del bufs["head"]
+            bufs["unary"] = torch.empty(batch, n_unary, th, tw, dtype=torch.float32, device=dev)
+            bufs["keys"] = torch.empty(batch, len(self.edges), th, tw, dtype=torch.int64, device=dev)
         for op in self._ops:
             ih, iw, _ = shapes[op.src]
             oh, ow = A.out_hw(op, ih, iw)
+            entries.append((op.name, 2 * op.cin * op.cout * op.k * op.k * oh * ow * batch))
             if op.k == 7:
                 assert op.src == "input" and op.out_act is None
                 L.check(lib.ppn_plan_add_stem(handle, self.compute_dtype, 1 if src_is_u8 else 0, src.data_ptr(),
@@ -210,24 +221,32 @@ class PoseProposalNet:
             d.weight = self._ptr(op.name + ".w")
             d.scale1, d.shift1 = self._ptr(op.name + ".s1"), self._ptr(op.name + ".b1")
             d.residual = bufs[op.residual].data_ptr() if op.residual else None
-            d.out_raw = bufs[op.out_raw].data_ptr() if op.out_raw else None
+            d.out_raw = bufs[op.out_raw].data_ptr() if (op.out_raw and op.out_raw in bufs) else None
+            if fused and op.nchw_f32_out:
+                keys = bufs["keys"]
+                L.check(lib.ppn_plan_add_memset(handle, keys.data_ptr(), keys.numel() * 8), "ppn_plan_add_memset")
+                entries.insert(len(entries) - 1, ("zero arg-max keys", 0))
+                d.unary_out, d.argmax_keys = bufs["unary"].data_ptr(), keys.data_ptr()
+                d.unary_channels = bufs["unary"].shape[1]
+                d.limb_window = self.local_grid_size[0] * self.local_grid_size[1]
             d.scale2, d.shift2 = self._ptr(op.name + ".s2"), self._ptr(op.name + ".b2")
             d.out_act = bufs[op.out_act].data_ptr() if op.out_act else None
             d.zero_page = self._dev["zero"].data_ptr()
             L.check(lib.ppn_plan_add_conv(handle, C.byref(d)), f"ppn_plan_add_conv({op.name})")
-        return _Plan(handle, bufs, bufs["head"], len(self._ops), A.conv_flops(self._ops, h, w) * batch)
+        head = (bufs["unary"], bufs["keys"]) if fused else bufs["head"]
+        return _Plan(handle, bufs, head, entries, A.conv_flops(self._ops, h, w) * batch)
 
-    def _plan_for(self, x: torch.Tensor, src_is_u8: bool) -> _Plan:
+    def _plan_for(self, x: torch.Tensor, src_is_u8: bool, fused: bool = False) -> _Plan:
         if not self._dev:
             raise RuntimeError("PoseProposalNet: call load_state_dict() first")
         if src_is_u8:
             b, h, w, _ = x.shape
         else:
             b, _, h, w = x.shape
-        key = (b, h, w, src_is_u8)
+        key = (b, h, w, src_is_u8, fused)
         plan = self._plans.get(key)
         if plan is None:
-            plan = self._plans[key] = self._build_plan(b, h, w, x, src_is_u8)
+            plan = self._plans[key] = self._build_plan(b, h, w, x, src_is_u8, fused)
         L.check(self._lib.ppn_plan_set_input(plan.handle, x.data_ptr()), "ppn_plan_set_input")
         plan.keepalive = x
         return plan
@@ -247,31 +266,28 @@ class PoseProposalNet:
 
     __call__ = forward
 
-    def forward_u8(self, frames: torch.Tensor) -> torch.Tensor:
-        """Fused rt_test.py:97-101 + forward: u8 [B,H,W,3] RGB frames on the device -> head."""
+    def forward_u8(self, frames: torch.Tensor, fused_decode: bool = False):
+        """Fused rt_test.py:97-101 + forward: u8 [B,H,W,3] RGB frames on the device -> head.
+
+        With ``fused_decode=True`` the head conv's epilogue runs the decode's limb arg-max itself and the
+        17.5 MB/image head is never written: returns ``(unary f32 [B,6K,H,W], keys i64 [B,E,H,W])`` for
+        ``Decoder.decode_fused`` (results bit-identical to decoding the materialised head)."""
         if not (frames.is_cuda and frames.dtype == torch.uint8 and frames.dim() == 4 and frames.shape[3] == 3):
             raise ValueError("forward_u8 expects a uint8 CUDA tensor [B,H,W,3]")
         x = frames.contiguous()
-        plan = self._plan_for(x, True)
+        plan = self._plan_for(x, True, fused_decode)
         L.check(self._lib.ppn_plan_run(plan.handle, L.current_stream_ptr()), "ppn_plan_run")
         return plan.head
 
-    def profile_layers(self, x: torch.Tensor, src_is_u8: bool = False, repeats: int = 1):
+    def profile_layers(self, x: torch.Tensor, src_is_u8: bool = False, repeats: int = 1, fused_decode: bool = False):
         """Per-launch durations (ms) measured with HIP events on the launch stream: [(op name, kernel, ms, flops)].
         `repeats` launches of each op are issued back to back between its events (amortises the event gap)."""
-        plan = self._plan_for(x.contiguous(), src_is_u8)
+        plan = self._plan_for(x.contiguous(), src_is_u8, fused_decode)
         ms = (C.c_float * plan.n_ops)()
         L.check(self._lib.ppn_plan_run_timed(plan.handle, L.current_stream_ptr(), ms, plan.n_ops, repeats),
                 "ppn_plan_run_timed")
-        b = x.shape[0]
-        h, w = (x.shape[1], x.shape[2]) if src_is_u8 else (x.shape[2], x.shape[3])
-        shapes = A.tensor_shapes(self._ops, h, w)
-        out = []
-        for i, op in enumerate(self._ops):
-            oh, ow, _ = shapes[op.out_raw or op.out_act]
-            fl = 2 * op.cin * op.cout * op.k * op.k * oh * ow * b
-            out.append((op.name, self._lib.ppn_plan_kernel_name(plan.handle, i).decode(), float(ms[i]), fl))
-        return out
+        return [(name, self._lib.ppn_plan_kernel_name(plan.handle, i).decode(), float(ms[i]), fl)
+                for i, (name, fl) in enumerate(plan.entries)]
 
     def __del__(self):
         try:

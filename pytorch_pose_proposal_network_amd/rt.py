@@ -65,9 +65,9 @@ def inference(image, model: PoseProposalNet, outsize, local_grid_size, detection
 def inference_batch(frames_u8: torch.Tensor, model: PoseProposalNet, decoder: Optional[D.Decoder] = None,
                     detection_thresh: float = 0.15) -> D.DecodeResult:
     """Batched device-side inference: u8 [B,S,S,3] CUDA tensor -> compact people lists on the device."""
-    head = model.forward_u8(frames_u8)
+    unary, keys = model.forward_u8(frames_u8, fused_decode=True)     # the head tensor is never materialised
     if decoder is None:
-        b, _, h, w = head.shape
+        b, _, h, w = unary.shape
         decoder = D.Decoder(b, (h, w), (frames_u8.shape[1], frames_u8.shape[2]), model.local_grid_size,
-                            detection_thresh, device=head.device)
-    return decoder(head)
+                            detection_thresh, device=unary.device)
+    return decoder.decode_fused(unary, keys)

@@ -132,3 +132,31 @@ def test_state_dict_validation():
     m.load_state_dict(ddp)
     with pytest.raises(NotImplementedError):
         m.train()
+
+
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
+def test_fused_decode_equals_decode_of_materialised_head(golden_dir, dtype):
+    """forward_u8(fused_decode=True): unary channels bit-equal to head[:, :108] and the arg-max keys decode to
+    exactly the people that decoding the materialised head gives (dense random-network heads: many ties/edges)."""
+    from pytorch_pose_proposal_network_amd import decode
+    g = np.load(os.path.join(golden_dir, "forward_d22_384.npz"))
+    m = _model("drn_d_22", g, dtype)
+    u8 = torch.from_numpy(prng.u8_frames(4242, 3, (384, 384))).cuda()
+    head = m.forward_u8(u8).clone()
+    unary, keys = m.forward_u8(u8, fused_decode=True)
+    assert torch.equal(unary, head[:, :108])
+    # keys -> (value, window index) must be the first-index arg-max of the sigmoid outputs
+    e = head[:, 108:].reshape(3, 17, 441, 24, 24)
+    val, idx = e.max(dim=2)
+    first = (e == val.unsqueeze(2)).float().argmax(dim=2)             # lowest index among ties
+    s_from_keys = (0xFFFFFFFF - (keys & 0xFFFFFFFF)).to(torch.int64)
+    assert torch.equal(s_from_keys, first)
+    assert torch.equal(((keys >> 32) & 0xFFFFFFFF).to(torch.int32).view(torch.float32), val)
+    dec = decode.Decoder(3)
+    a = dec(head).to_host()
+    a = [{k: (v.copy() if hasattr(v, "copy") else v) for k, v in r.items()} for r in a]
+    b = dec.decode_fused(unary, keys).to_host()
+    for ra, rb in zip(a, b):
+        assert ra["n"] == rb["n"] > 0
+        for k in ("kp_cell", "limb_arg", "bbox", "score"):
+            assert np.array_equal(ra[k], rb[k]), k
