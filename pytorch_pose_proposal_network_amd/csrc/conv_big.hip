@@ -286,8 +286,10 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
 #endif
     }
 #ifdef PPN_STAMP
+    unsigned long long t_epi0;
+    PPN_T(t_epi0);
     if (lane == 0 && a.scale2 == nullptr && a.shift2 != nullptr) {   // diagnostic channel: shift2 = u64 buffer
-        unsigned long long* dbg = (unsigned long long*)a.shift2 + ((size_t)blockIdx.x * NW + wave) * 4;
+        unsigned long long* dbg = (unsigned long long*)a.shift2 + ((size_t)blockIdx.x * NW + wave) * 8;
         dbg[0] = st_b1; dbg[1] = st_b2; dbg[2] = st_wait; dbg[3] = st_bar;
     }
 #endif
@@ -366,7 +368,7 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
         constexpr int TPC = BP / 4;                                  // threads per channel row (4 pixels each)
         constexpr int NITEM = 2 * IC * 16 * TPC;                     // (channel row, pixel quad) items per chunk
         static_assert(TC % IC == 0, "channel tiles per wave must be even");
-        static_assert((size_t)2 * IC * 16 * LD * 4 <= 2 * (size_t)STAGE, "epilogue chunk must fit the staging LDS");
+        static_assert((size_t)(2 * IC * 16 * LD + 4 * IC * 16) * 4 <= 2 * (size_t)STAGE, "epilogue chunk must fit the staging LDS");
         float* out = reinterpret_cast<float*>(a.out_raw);
         const bool vec = (a.HoWo & 3) == 0;
         auto chunk = [&](auto qc) {
@@ -380,45 +382,59 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) ct[(ch + r) * LD + px] = acc[q * IC + ii][j][r];
                 }
+            float* ct_affine = ct + 2 * IC * 16 * LD;                // [scale x 64][shift x 64] of this chunk's channels
+            if (a.amax_keys && tid < 2 * IC * 16) {
+                const int cw = tid / (IC * 16), r = tid % (IC * 16);
+                const int c = c0 + cw * (BC / 2) + q * IC * 16 + r;
+                ct_affine[tid] = (a.scale1 && c < a.Cout) ? a.scale1[c] : 1.f;
+                ct_affine[2 * IC * 16 + tid] = (a.shift1 && c < a.Cout) ? a.shift1[c] : 0.f;
+            }
             __syncthreads();
             if (a.amax_keys) {
                 // Fused decode front end: one thread per (pixel, 32-channel run).  Channels < unary_ch (resp, conf,
                 // x, y, w, h) go to the compact tensor; every limb channel competes in its (image, edge, cell)
                 // arg-max through one 64-bit atomicMax per run and edge:  key = value bits << 32 | ~s  (sigmoid
                 // outputs are >= 0 so the bit pattern is monotonic; ~s makes the LOWEST window index win ties,
-                // np.argmax semantics of datatest.py:113).
+                // np.argmax semantics of datatest.py:113).  A 32-channel run crosses at most one edge boundary
+                // (window >= 32), so it is processed as two branch-free segments.
+                constexpr int RUN = IC * 16;
                 const int nedges = (a.Cout - a.unary_ch) / a.window;
                 for (int item = tid; item < 2 * BP; item += NT) {
                     const int cw = item / BP, px = item - cw * BP;
                     const int m = m0 + px;
                     if (m >= a.M) continue;
                     const int nb = m / a.HoWo, np = m - nb * a.HoWo;
-                    int c = c0 + cw * (BC / 2) + q * IC * 16;        // first channel of this 32-row run
-                    int e = -1, sidx = 0;
-                    if (c >= a.unary_ch) { e = (c - a.unary_ch) / a.window; sidx = (c - a.unary_ch) - e * a.window; }
-                    float best = -1.f;
-                    int best_s = 0;
-                    auto flush = [&]() {
-                        if (best >= 0.f && e >= 0 && e < nedges) {
-                            const unsigned long long key = ((unsigned long long)__float_as_uint(best) << 32) |
-                                                           (unsigned)(0xFFFFFFFFu - (unsigned)best_s);
-                            atomicMax(a.amax_keys + ((size_t)nb * nedges + e) * a.HoWo + np, key);
+                    const int cb = c0 + cw * (BC / 2) + q * RUN;     // first channel of this run
+                    const float* row = ct + (cw * RUN) * LD + px;
+                    const float* aff = ct_affine + cw * RUN;
+                    auto value = [&](int r) { return sigmoid_fast(row[r * LD] * aff[r] + aff[2 * RUN + r]); };
+                    int r = 0;
+                    // unary part of the run (only the first channel tile of the layer has one)
+                    for (; r < RUN && cb + r < a.unary_ch; ++r)
+                        a.unary_out[((size_t)nb * a.unary_ch + cb + r) * a.HoWo + np] = value(r);
+                    const int rend = min(RUN, a.Cout - cb);           // padded channels past Cout do not compete
+                    if (r < rend) {
+                        const int l0 = cb + r - a.unary_ch;           // limb channel index of element r
+                        int e = l0 / a.window, sidx = l0 - e * a.window;
+                        while (r < rend) {
+                            const int seg = min(rend - r, a.window - sidx);   // elements left in this edge's window
+                            float best = -1.f;
+                            int best_k = 0;
+#pragma unroll 8
+                            for (int k = 0; k < seg; ++k) {
+                                const float v = value(r + k);
+                                const bool gt = v > best;              // strict: first maximum of the segment
+                                best = gt ? v : best;
+                                best_k = gt ? k : best_k;
+                            }
+                            if (e < nedges) {
+                                const unsigned long long key = ((unsigned long long)__float_as_uint(best) << 32) |
+                                                               (unsigned)(0xFFFFFFFFu - (unsigned)(sidx + best_k));
+                                atomicMax(a.amax_keys + ((size_t)nb * nedges + e) * a.HoWo + np, key);
+                            }
+                            r += seg; sidx = 0; ++e;
                         }
-                        best = -1.f;
-                    };
-                    for (int r = 0; r < IC * 16; ++r, ++c) {
-                        if (c >= a.Cout) break;
-                        const float s1 = a.scale1 ? a.scale1[c] : 1.f, b1 = a.shift1 ? a.shift1[c] : 0.f;
-                        const float v = apply_act(ct[(cw * IC * 16 + r) * LD + px] * s1 + b1, a.act1);
-                        if (c < a.unary_ch) {
-                            a.unary_out[((size_t)nb * a.unary_ch + c) * a.HoWo + np] = v;
-                            if (c + 1 == a.unary_ch) { e = 0; sidx = 0; }
-                            continue;
-                        }
-                        if (v > best) { best = v; best_s = sidx; }   // strict: first maximum of the run
-                        if (++sidx == a.window) { flush(); sidx = 0; ++e; }
                     }
-                    flush();
                 }
             }
             if (out)
@@ -453,6 +469,16 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
         };
         static_for<TC / IC>(chunk);
     }
+#ifdef PPN_STAMP
+    {
+        unsigned long long t_epi1;
+        PPN_T(t_epi1);
+        if (lane == 0 && a.scale2 == nullptr && a.shift2 != nullptr) {
+            unsigned long long* dbg = (unsigned long long*)a.shift2 + ((size_t)blockIdx.x * NW + wave) * 8;
+            dbg[4] = t_epi1 - t_epi0;
+        }
+    }
+#endif
 }
 
 template <typename T, int BP, int BC, int NW>

@@ -45,11 +45,15 @@ struct Elem<__bf16> {
     static constexpr int EPC = 8;
 };
 
+// sigmoid as exp + reciprocal instructions (v_exp_f32, v_rcp_f32: ~1 ulp each, far inside the 1e-4 head tolerance);
+// every head value -- materialised or folded into arg-max keys -- goes through this one function.
+__device__ __forceinline__ float sigmoid_fast(float v) { return __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
+
 __device__ __forceinline__ float apply_act(float v, int act) {
     switch (act) {
         case PPN_ACT_RELU: return v > 0.f ? v : 0.f;
         case PPN_ACT_LRELU: return v > 0.f ? v : v * 0.1f;      // nn.LeakyReLU(0.1), model.py:88
-        case PPN_ACT_SIGMOID: return 1.0f / (1.0f + __expf(-v));
+        case PPN_ACT_SIGMOID: return sigmoid_fast(v);
         default: return v;
     }
 }
