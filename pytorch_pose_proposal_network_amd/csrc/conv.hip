@@ -429,6 +429,8 @@ int ppn::conv_launch(const ppn_conv_desc* d, hipStream_t st, const char** kname)
         return ppn::fail(PPN_E_INVALID, "fused arg-max needs the NCHW head mode, unary_out and cout = unary + E*window");
     if (d->argmax_keys && d->act1 != PPN_ACT_SIGMOID)
         return ppn::fail(PPN_E_INVALID, "fused arg-max keys assume non-negative (sigmoid) outputs");
+    if (!d->out_nchw_f32 && (d->act1 == PPN_ACT_SIGMOID || d->act2 == PPN_ACT_SIGMOID))
+        return ppn::fail(PPN_E_UNSUPPORTED, "sigmoid is only implemented for the NCHW head output");
     if (d->out_nchw_f32) {
         if (d->residual || d->out_act || (!d->out_raw && !d->argmax_keys))
             return ppn::fail(PPN_E_UNSUPPORTED, "NCHW head output supports out_raw / fused arg-max only");

@@ -307,6 +307,9 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
         static_assert((size_t)CPX * LD * 4 <= 2 * (size_t)STAGE, "epilogue chunk must fit the staging LDS");
         const int cg = tid % TPP, prow = tid / TPP;
         const int c = c0 + cg * 8;
+        // NHWC layers only use none / ReLU / LeakyReLU(0.1): all three are  t > 0 ? t : t * slope  (branch-free)
+        const float slope1 = a.act1 == PPN_ACT_RELU ? 0.f : (a.act1 == PPN_ACT_LRELU ? 0.1f : 1.f);
+        const float slope2 = a.act2 == PPN_ACT_RELU ? 0.f : (a.act2 == PPN_ACT_LRELU ? 0.1f : 1.f);
         float s1[8], b1[8], s2[8], b2[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -328,31 +331,43 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
                 }
             __syncthreads();
             if (c < a.Cout) {
+                constexpr int NPASS = CPX / PPP;
+                int mrow[NPASS];
+                float res[NPASS][8];
+                // residual rows of ALL passes are requested first: one memory latency per chunk, not per pass
 #pragma unroll
-                for (int pass = 0; pass < CPX / PPP; ++pass) {
+                for (int pass = 0; pass < NPASS; ++pass) {
                     const int px = pass * PPP + prow;                // 0 .. CPX-1
                     const int pw = px / (JC * 16), pj = (px / 16) % JC, pr = px % 16;
                     const int m = m0 + pw * (BP / WP) + (q * JC + pj) * 16 + pr;
-                    if (m < a.M) {
+                    mrow[pass] = m < a.M ? m : -1;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) res[pass][i] = 0.f;
+                    if (a.residual && m < a.M) load8<T>(a.residual + ((size_t)m * a.Cout + c) * ES, res[pass]);
+                }
+#pragma unroll
+                for (int pass = 0; pass < NPASS; ++pass) {
+                    const int px = pass * PPP + prow;
+                    if (mrow[pass] >= 0) {
                         float v[8];
                         const f32x4 lo = *reinterpret_cast<const f32x4*>(ct + px * LD + cg * 8);
                         const f32x4 hi = *reinterpret_cast<const f32x4*>(ct + px * LD + cg * 8 + 4);
                         v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w;
                         v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
-                        const size_t off = ((size_t)m * a.Cout + c) * ES;
+                        const size_t off = ((size_t)mrow[pass] * a.Cout + c) * ES;
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) v[i] = apply_act(v[i] * s1[i] + b1[i], a.act1);
-                        if (a.residual) {
-                            float r[8];
-                            load8<T>(a.residual + off, r);
-#pragma unroll
-                            for (int i = 0; i < 8; ++i) v[i] += r[i];
+                        for (int i = 0; i < 8; ++i) {
+                            const float t1 = v[i] * s1[i] + b1[i];
+                            v[i] = (t1 > 0.f ? t1 : t1 * slope1) + res[pass][i];
                         }
                         if (a.out_raw) store8<T>(a.out_raw + off, v);
                         if (a.out_act) {
                             float u[8];
 #pragma unroll
-                            for (int i = 0; i < 8; ++i) u[i] = apply_act(v[i] * s2[i] + b2[i], a.act2);
+                            for (int i = 0; i < 8; ++i) {
+                                const float t2 = v[i] * s2[i] + b2[i];
+                                u[i] = t2 > 0.f ? t2 : t2 * slope2;
+                            }
                             store8<T>(a.out_act + off, u);
                         }
                     }
