@@ -95,6 +95,30 @@ int ppn_nms(const float* bbox, const float* score, int32_t n, float thresh, int3
             int32_t* out_count, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Training loss (forward + backward), replaces PPNLoss.forward + autograd through it (main.py:125-216, 664-683).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct ppn_loss_cfg {
+    int32_t K, E, sH, sW, H, W, inH, inW;   /* as in ppn_decode_cfg */
+} ppn_loss_cfg;
+
+size_t ppn_loss_workspace_bytes(const ppn_loss_cfg* cfg, int32_t batch);
+
+/*
+ * head        f32 [B, 6K+E*sH*sW, H, W]   feature_map (sigmoid outputs)
+ * delta, weight, tx_half, ty_half, tx, ty, tw, th   f32 [B,K,H,W];  weight_ij, te  f32 [B,E,sH,sW,H,W]
+ *             (the CustomBatch fields of dataset.py:233-248, argument order of main.py:180)
+ * coeff       HOST pointer to 5 floats c_i (read at call time); may be NULL when grad_head is NULL
+ * losses      f32 [5] device: loss_resp, loss_iou, loss_coor, loss_size, loss_limb (each summed over the
+ *             non-batch dims, then mean over the batch -- main.py:199-214); bitwise reproducible
+ * grad_head   f32 like head or NULL: d(sum_i c_i L_i)/d(head); with c_i = w_i/5 this is the backward of
+ *             main.py:668-683, with a one-hot c the per-loss gradient the GradNorm step needs (main.py:704-708)
+ */
+int ppn_loss_fwd_bwd(const ppn_loss_cfg* cfg, const float* head, int32_t batch, const float* delta,
+                     const float* weight, const float* weight_ij, const float* tx_half, const float* ty_half,
+                     const float* tx, const float* ty, const float* tw, const float* th, const float* te,
+                     const float* coeff, float* losses, float* grad_head, void* workspace, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Convolution stack: one fused launch per convolution of PoseProposalNet.forward
  * (model.py:104-136, drn.py:42-57,77-97,192-202).
  *   acc  = conv(src, weight)                        implicit GEMM on MFMA, NHWC activations

@@ -24,6 +24,7 @@ SOURCES = [
     ("stem.hip", []),
     ("stem3x3.hip", []),
     ("plan.hip", []),
+    ("loss.hip", []),
 ]
 
 

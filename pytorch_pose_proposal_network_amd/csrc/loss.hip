@@ -1,0 +1,228 @@
+// PPN training loss, forward + backward in one pass (reference main.py:125-216).
+//
+//   L_resp = mean_b sum (resp - delta)^2                         L_coor = mean_b sum weight ((x-tx_half)^2 + (y-ty_half)^2)
+//   L_iou  = mean_b sum delta (conf - iou(pred, target))^2       L_size = mean_b sum weight ((sqrt(w+e)-sqrt(tw+e))^2 + (..h..)^2)
+//   L_limb = mean_b sum weight_ij (e - te)^2                     iou on centre-format boxes with ReLU-clamped overlaps,
+//                                                                inter / (a0 + a1 - inter + 1e-6)  (main.py:125-144)
+// and, when grad_head != NULL, d(sum_i coeff_i L_i)/d(head) for the whole head tensor -- the gradient also flows
+// through iou into x, y, w, h as in the reference (ious is not detached).
+//
+// The limb term is the memory-bound part: per sample it streams e (in the head), te and weight_ij (17.3 MB each)
+// and writes 17.3 MB of gradient.  limb_kernel does that with 16-byte coalesced accesses on a fixed grid with a
+// grid-stride loop; unary_kernel handles the 6K unary channels (one thread per (image, keypoint, cell));
+// per-workgroup partial sums are combined by finalize_kernel in a fixed order, so the five losses are bitwise
+// reproducible from run to run (no float atomics).
+#include "common.h"
+
+namespace {
+
+constexpr float kEps = 1e-6f;     // config.py:82 EPSILON
+
+struct LossArgs {
+    const float* head;
+    const float *delta, *weight, *weight_ij, *tx_half, *ty_half, *tx, *ty, *tw, *th, *te;
+    float* grad;          // may be NULL
+    float* partial;       // workspace: [nblk_unary][4] then [nblk_limb]
+    float* losses;        // [5]
+    float coeff[5];
+    int B, K, E, S, H, W, C, inW, inH;
+    int nblk_unary, nblk_limb;
+};
+
+__device__ __forceinline__ float block_sum(float v, float* s_red) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    __syncthreads();
+    if (lane == 0) s_red[wid] = v;
+    __syncthreads();
+    float t = 0.f;
+    if (threadIdx.x == 0)
+        for (int w = 0; w < nw; ++w) t += s_red[w];
+    return t;   // valid in thread 0
+}
+
+// d min(a,c)/da and d max(b,d)/db with PyTorch's tie rule (half the gradient on equality)
+__device__ __forceinline__ float pick_lt(float a, float c) { return a < c ? 1.f : (a == c ? 0.5f : 0.f); }
+__device__ __forceinline__ float pick_gt(float b, float d) { return b > d ? 1.f : (b == d ? 0.5f : 0.f); }
+
+__global__ void __launch_bounds__(256) unary_kernel(LossArgs a) {
+    __shared__ float s_red[4];
+    const int HW = a.H * a.W;
+    const long long n = (long long)a.B * a.K * HW;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    float l_resp = 0.f, l_iou = 0.f, l_coor = 0.f, l_size = 0.f;
+    if (i < n) {
+        const int cell = (int)(i % HW);
+        const int k = (int)((i / HW) % a.K);
+        const int b = (int)(i / ((long long)HW * a.K));
+        const size_t hb = (size_t)b * a.C * HW + (size_t)k * HW + cell;       // resp channel of this (b,k,cell)
+        const size_t KS = (size_t)a.K * HW;
+        const float resp = a.head[hb], conf = a.head[hb + KS];
+        const float x = a.head[hb + 2 * KS], y = a.head[hb + 3 * KS], w = a.head[hb + 4 * KS], h = a.head[hb + 5 * KS];
+        const size_t t = (size_t)i;
+        const float dl = a.delta[t], wt = a.weight[t];
+        const float txh = a.tx_half[t], tyh = a.ty_half[t], tx = a.tx[t], ty = a.ty[t], tw = a.tw[t], th = a.th[t];
+        const float invB = 1.0f / (float)a.B;
+        const float gW = (float)(a.inW / a.W), gH = (float)(a.inH / a.H), inW = (float)a.inW, inH = (float)a.inH;
+        const float X = (float)(cell % a.W), Y = (float)(cell / a.W);
+        // restore_xy / restore_size (main.py:169-178)
+        const float rx = (x + X) * gW, ry = (y + Y) * gH, rw = inW * w, rh = inH * h;
+        const float rtx = (tx + X) * gW, rty = (ty + Y) * gH, rtw = inW * tw, rth = inH * th;
+        // iou (main.py:125-144)
+        const float a1 = rx + rw / 2, c1 = rtx + rtw / 2, b1 = rx - rw / 2, d1 = rtx - rtw / 2;
+        const float a2 = ry + rh / 2, c2 = rty + rth / 2, b2 = ry - rh / 2, d2 = rty - rth / 2;
+        const float wr = fminf(a1, c1) - fmaxf(b1, d1), hr = fminf(a2, c2) - fmaxf(b2, d2);
+        const float wI = fmaxf(wr, 0.f), hI = fmaxf(hr, 0.f);
+        const float I = wI * hI;
+        const float U = rw * rh + rtw * rth - I + kEps;
+        const float iou = I / U;
+        // losses (main.py:199-208)
+        const float dr = resp - dl, dc = conf - iou, dx = x - txh, dy = y - tyh;
+        const float sw = sqrtf(w + kEps), sh = sqrtf(h + kEps);
+        const float dsw = sw - sqrtf(tw + kEps), dsh = sh - sqrtf(th + kEps);
+        l_resp = dr * dr;
+        l_iou = dl * dc * dc;
+        l_coor = wt * (dx * dx + dy * dy);
+        l_size = wt * (dsw * dsw + dsh * dsh);
+        if (a.grad) {
+            const float c0 = a.coeff[0] * invB, c1c = a.coeff[1] * invB, c2c = a.coeff[2] * invB, c3c = a.coeff[3] * invB;
+            const float g_iou = -2.f * dl * dc * c1c;                        // dL/d(iou)
+            const float gI = g_iou * (U + I) / (U * U), gA0 = -g_iou * I / (U * U);
+            const float g_wr = wr > 0.f ? gI * hI : 0.f, g_hr = hr > 0.f ? gI * wI : 0.f;
+            const float da1 = pick_lt(a1, c1), db1 = pick_gt(b1, d1), da2 = pick_lt(a2, c2), db2 = pick_gt(b2, d2);
+            const float g_rx = g_wr * (da1 - db1), g_ry = g_hr * (da2 - db2);
+            const float g_rw = g_wr * 0.5f * (da1 + db1) + gA0 * rh, g_rh = g_hr * 0.5f * (da2 + db2) + gA0 * rw;
+            a.grad[hb] = 2.f * dr * c0;
+            a.grad[hb + KS] = 2.f * dl * dc * c1c;
+            a.grad[hb + 2 * KS] = g_rx * gW + 2.f * wt * dx * c2c;
+            a.grad[hb + 3 * KS] = g_ry * gH + 2.f * wt * dy * c2c;
+            a.grad[hb + 4 * KS] = g_rw * inW + wt * dsw / sw * c3c;
+            a.grad[hb + 5 * KS] = g_rh * inH + wt * dsh / sh * c3c;
+        }
+    }
+    float* out = a.partial + (size_t)blockIdx.x * 4;
+    float s;
+    s = block_sum(l_resp, s_red); if (threadIdx.x == 0) out[0] = s;
+    s = block_sum(l_iou, s_red);  if (threadIdx.x == 0) out[1] = s;
+    s = block_sum(l_coor, s_red); if (threadIdx.x == 0) out[2] = s;
+    s = block_sum(l_size, s_red); if (threadIdx.x == 0) out[3] = s;
+}
+
+template <int V>
+__global__ void __launch_bounds__(256) limb_kernel(LossArgs a) {
+    __shared__ float s_red[4];
+    const int HW = a.H * a.W;
+    const size_t per_img = (size_t)a.E * a.S * HW;                      // limb elements per image
+    const size_t head_img = (size_t)a.C * HW, head_off = (size_t)6 * a.K * HW;
+    const size_t nvec = per_img / V;                                   // V | per_img is checked on the host
+    const float g = 2.f * a.coeff[4] / (float)a.B;
+    float acc = 0.f;
+    const size_t total = (size_t)a.B * nvec;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = i / nvec, r = (i - b * nvec) * V;
+        const float* e = a.head + b * head_img + head_off + r;
+        const float* te = a.te + b * per_img + r;
+        const float* wj = a.weight_ij + b * per_img + r;
+        float ev[V], tv[V], wv[V], gv[V];
+        if (V == 4) {
+            const float4 e4 = *reinterpret_cast<const float4*>(e), t4 = *reinterpret_cast<const float4*>(te),
+                         w4 = *reinterpret_cast<const float4*>(wj);
+            ev[0] = e4.x; ev[1] = e4.y; ev[2] = e4.z; ev[3] = e4.w;
+            tv[0] = t4.x; tv[1] = t4.y; tv[2] = t4.z; tv[3] = t4.w;
+            wv[0] = w4.x; wv[1] = w4.y; wv[2] = w4.z; wv[3] = w4.w;
+        } else {
+            ev[0] = e[0]; tv[0] = te[0]; wv[0] = wj[0];
+        }
+#pragma unroll
+        for (int u = 0; u < V; ++u) {
+            const float d = ev[u] - tv[u];
+            acc += wv[u] * d * d;                                       // main.py:208
+            gv[u] = g * wv[u] * d;
+        }
+        if (a.grad) {
+            float* go = a.grad + b * head_img + head_off + r;
+            if (V == 4) *reinterpret_cast<float4*>(go) = make_float4(gv[0], gv[1], gv[2], gv[3]);
+            else go[0] = gv[0];
+        }
+    }
+    const float s = block_sum(acc, s_red);
+    if (threadIdx.x == 0) a.partial[(size_t)a.nblk_unary * 4 + blockIdx.x] = s;
+}
+
+__global__ void __launch_bounds__(256) finalize_kernel(LossArgs a) {
+    // fixed-order, double-precision combination of the per-workgroup partial sums; mean over the batch
+    __shared__ double s_acc[256];
+    const int t = threadIdx.x;
+    for (int q = 0; q < 5; ++q) {
+        double v = 0.0;
+        if (q < 4) {
+            for (int i = t; i < a.nblk_unary; i += 256) v += (double)a.partial[(size_t)i * 4 + q];
+        } else {
+            for (int i = t; i < a.nblk_limb; i += 256) v += (double)a.partial[(size_t)a.nblk_unary * 4 + i];
+        }
+        s_acc[t] = v;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (t < o) s_acc[t] += s_acc[t + o];
+            __syncthreads();
+        }
+        if (t == 0) a.losses[q] = (float)(s_acc[0] / (double)a.B);
+        __syncthreads();
+    }
+}
+
+int fill(LossArgs& a, const ppn_loss_cfg* cfg, int batch) {
+    if (!cfg) return ppn::fail(PPN_E_INVALID, "loss cfg is NULL");
+    if (cfg->K < 1 || cfg->E < 0 || cfg->sH < 1 || cfg->sW < 1 || cfg->H < 1 || cfg->W < 1 || cfg->inH < cfg->H ||
+        cfg->inW < cfg->W || batch < 1)
+        return ppn::fail(PPN_E_INVALID, "bad loss geometry");
+    a.B = batch; a.K = cfg->K; a.E = cfg->E; a.S = cfg->sH * cfg->sW; a.H = cfg->H; a.W = cfg->W;
+    a.C = 6 * cfg->K + cfg->E * a.S; a.inW = cfg->inW; a.inH = cfg->inH;
+    const long long n_unary = (long long)batch * a.K * a.H * a.W;
+    a.nblk_unary = (int)((n_unary + 255) / 256);
+    a.nblk_limb = 2048;
+    return PPN_OK;
+}
+
+}  // namespace
+
+extern "C" size_t ppn_loss_workspace_bytes(const ppn_loss_cfg* cfg, int32_t batch) {
+    LossArgs a;
+    if (fill(a, cfg, batch)) return 0;
+    return ((size_t)a.nblk_unary * 4 + a.nblk_limb) * sizeof(float);
+}
+
+extern "C" int ppn_loss_fwd_bwd(const ppn_loss_cfg* cfg, const float* head, int32_t batch, const float* delta,
+                                const float* weight, const float* weight_ij, const float* tx_half, const float* ty_half,
+                                const float* tx, const float* ty, const float* tw, const float* th, const float* te,
+                                const float* coeff, float* losses, float* grad_head, void* workspace, void* stream) {
+    LossArgs a;
+    if (int rc = fill(a, cfg, batch)) return rc;
+    if (!head || !delta || !weight || !weight_ij || !tx_half || !ty_half || !tx || !ty || !tw || !th || !te || !losses ||
+        !workspace)
+        return ppn::fail(PPN_E_INVALID, "ppn_loss_fwd_bwd: NULL pointer");
+    if (grad_head && !coeff) return ppn::fail(PPN_E_INVALID, "ppn_loss_fwd_bwd: coeff is required with grad_head");
+    a.head = head; a.delta = delta; a.weight = weight; a.weight_ij = weight_ij; a.tx_half = tx_half; a.ty_half = ty_half;
+    a.tx = tx; a.ty = ty; a.tw = tw; a.th = th; a.te = te;
+    a.grad = grad_head; a.partial = static_cast<float*>(workspace); a.losses = losses;
+    for (int i = 0; i < 5; ++i) a.coeff[i] = coeff ? coeff[i] : 0.f;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(unary_kernel, dim3(a.nblk_unary), dim3(256), 0, st, a);
+    PPN_LAUNCH_CHECK();
+    const size_t per_img = (size_t)a.E * a.S * a.H * a.W;
+    const bool vec = per_img % 4 == 0 && ((size_t)a.C * a.H * a.W) % 4 == 0 && ((size_t)6 * a.K * a.H * a.W) % 4 == 0 &&
+                     reinterpret_cast<uintptr_t>(head) % 16 == 0 && reinterpret_cast<uintptr_t>(te) % 16 == 0 &&
+                     reinterpret_cast<uintptr_t>(weight_ij) % 16 == 0 &&
+                     (!grad_head || reinterpret_cast<uintptr_t>(grad_head) % 16 == 0);
+    if (a.E > 0) {
+        if (vec) hipLaunchKernelGGL(limb_kernel<4>, dim3(a.nblk_limb), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(limb_kernel<1>, dim3(a.nblk_limb), dim3(256), 0, st, a);
+        PPN_LAUNCH_CHECK();
+    } else {
+        PPN_HIP_CHECK(hipMemsetAsync(a.partial + (size_t)a.nblk_unary * 4, 0, sizeof(float) * a.nblk_limb, st));
+    }
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, st, a);
+    PPN_LAUNCH_CHECK();
+    return PPN_OK;
+}

@@ -1,0 +1,88 @@
+"""``PPNLoss`` with the reference's surface (main.py:147-216) over the fused HIP loss kernels.
+
+    criterion = PPNLoss(insize=(384, 384), outsize=(24, 24), local_grid_size=(21, 21))
+    l_resp, l_iou, l_coor, l_size, l_limb = criterion(image, feature_map, delta, weight, weight_ij,
+                                                      tx_half, ty_half, tx, ty, tw, th, te)   # main.py:180, 665-666
+    losses, grad = criterion.forward_backward(feature_map, targets, coeff=w / 5)              # main.py:668-683
+
+There is no autograd graph here: ``forward_backward`` returns d(sum_i coeff_i L_i)/d(feature_map) computed by the
+same pass that evaluates the losses (the reference gets it from ``loss.backward()``).  With a one-hot ``coeff``
+it yields the per-loss gradient that seeds the GradNorm partial backward passes (main.py:704-708).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Sequence
+
+import torch
+
+from . import config as cfg
+from . import lib as L
+
+TARGET_KEYS = ("delta", "weight", "weight_ij", "tx_half", "ty_half", "tx", "ty", "tw", "th", "te")
+
+
+class PPNLoss:
+    def __init__(self, insize=(384, 384), outsize=(24, 24), keypoint_names=cfg.KEYPOINT_NAMES,
+                 local_grid_size=(21, 21), edges=cfg.EDGES):
+        self.insize, self.outsize = insize, outsize
+        self.keypoint_names, self.edges, self.local_grid_size = keypoint_names, edges, local_grid_size
+        inW, inH = insize
+        outW, outH = outsize
+        self.gridsize = (int(inW / outW), int(inH / outH))
+        c = L.LossCfg()
+        c.K, c.E = len(keypoint_names), len(edges)
+        c.sW, c.sH = local_grid_size
+        c.W, c.H = outsize
+        c.inW, c.inH = insize
+        self._cfg = c
+        self._lib = None
+        self._ws: Dict[int, torch.Tensor] = {}
+
+    def _check(self, name, t, shape):
+        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32):
+            raise ValueError(f"{name} must be a float32 CUDA tensor")
+        if tuple(t.shape) != tuple(shape):
+            raise ValueError(f"{name} has shape {tuple(t.shape)}, expected {tuple(shape)}")
+        return t.contiguous()       # the reference's torch ops accept any strides; the kernels need dense tensors
+
+    def forward_backward(self, feature_map: torch.Tensor, targets: Dict[str, torch.Tensor],
+                         coeff: Optional[Sequence[float]] = None, want_grad: bool = True):
+        """-> (losses f32[5] on the device, grad like feature_map or None)."""
+        lib = self._lib = self._lib or L.load()
+        c = self._cfg
+        B = feature_map.shape[0]
+        C_ = 6 * c.K + c.E * c.sH * c.sW
+        feature_map = self._check("feature_map", feature_map, (B, C_, c.H, c.W))
+        t = {}
+        for k in TARGET_KEYS:
+            shape = (B, c.E, c.sH, c.sW, c.H, c.W) if k in ("weight_ij", "te") else (B, c.K, c.H, c.W)
+            t[k] = self._check(k, targets[k], shape)
+        dev = feature_map.device
+        ws = self._ws.get(B)
+        if ws is None or ws.device != dev:
+            n = lib.ppn_loss_workspace_bytes(C.byref(c), B)
+            ws = self._ws[B] = torch.empty(max(n, 16) // 4, dtype=torch.float32, device=dev)
+        losses = torch.empty(5, dtype=torch.float32, device=dev)
+        grad = torch.empty_like(feature_map) if want_grad else None
+        cf = None
+        if want_grad:
+            if coeff is None:
+                raise ValueError("coeff (5 floats) is required for the backward pass")
+            cf = (C.c_float * 5)(*[float(v) for v in (coeff.tolist() if isinstance(coeff, torch.Tensor) else coeff)])
+        L.check(lib.ppn_loss_fwd_bwd(C.byref(c), feature_map.data_ptr(), B, t["delta"].data_ptr(),
+                                     t["weight"].data_ptr(), t["weight_ij"].data_ptr(), t["tx_half"].data_ptr(),
+                                     t["ty_half"].data_ptr(), t["tx"].data_ptr(), t["ty"].data_ptr(),
+                                     t["tw"].data_ptr(), t["th"].data_ptr(), t["te"].data_ptr(), cf,
+                                     losses.data_ptr(), grad.data_ptr() if grad is not None else None, ws.data_ptr(),
+                                     L.current_stream_ptr()), "ppn_loss_fwd_bwd")
+        return losses, grad
+
+    def forward(self, image, feature_map, delta, weight, weight_ij, tx_half, ty_half, tx, ty, tw, th, te):
+        """Reference signature (main.py:180); `image` is only used for its batch size there and is ignored here."""
+        targets = dict(delta=delta, weight=weight, weight_ij=weight_ij, tx_half=tx_half, ty_half=ty_half, tx=tx, ty=ty,
+                       tw=tw, th=th, te=te)
+        losses, _ = self.forward_backward(feature_map, targets, want_grad=False)
+        return tuple(losses[i] for i in range(5))
+
+    __call__ = forward

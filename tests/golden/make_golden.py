@@ -1,6 +1,6 @@
 """Generate the golden fixtures by running the REFERENCE itself (this container only).
 
-Usage:  python tests/golden/make_golden.py [--only forward|decode|nms]
+Usage:  python tests/golden/make_golden.py [--only forward|decode|nms|loss]
 
 The reference (/root/reference, read-only, never copied) is imported with stub modules for
 its absent optional dependencies (recipe: SURVEY.md Appendix B).  For every fixture the
@@ -53,6 +53,27 @@ def import_reference():
     sh.geometry = stub("shapely.geometry")
     import drn, model, datatest  # noqa: E401
     return drn, model, datatest
+
+
+def import_reference_main():
+    """main.py additionally needs apex / visdom stubs and hard-codes .cuda() (main.py:173): SURVEY App. B."""
+    def stub(name, **a):
+        m = types.ModuleType(name)
+        m.__dict__.update(a)
+        sys.modules[name] = m
+        return m
+    ap = stub("apex")
+    stub("apex.parallel", DistributedDataParallel=object)
+    stub("apex.fp16_utils")
+    ap.amp = stub("apex.amp")
+    ap.optimizers = stub("apex.optimizers")
+    stub("apex.multi_tensor_apply", multi_tensor_applier=None)
+    stub("visdom", Visdom=object)
+    import torch
+    torch.Tensor.cuda = lambda s, *a, **k: s
+    torch.nn.Module.cuda = lambda s, *a, **k: s
+    import main
+    return main
 
 
 import numpy as np  # noqa: E402
@@ -239,6 +260,48 @@ def make_nms(datatest):
     np.savez_compressed(os.path.join(HERE, "nms_cases.npz"), **out)
 
 
+def make_loss():
+    """PPNLoss (main.py:125-216): forward values and d(sum c_i L_i)/d(feature_map) from the reference itself."""
+    from oracle import loss_ref as Lr, targets_ref as T
+    main_mod = import_reference_main()
+    crit = main_mod.PPNLoss()
+    out = {}
+    cases = [("a", 50, 2, [0.2, 0.2, 0.2, 0.2, 0.2]), ("b", 60, 3, [0.31, 0.07, 0.4, 0.12, 0.1]),
+             ("limb_only", 70, 1, [0, 0, 0, 0, 1.0]), ("iou_only", 71, 1, [0, 1.0, 0, 0, 0])]
+    for tag, seed, batch, coeff in cases:
+        tg = T.synthetic_batch(seed, batch)
+        head = prng.uniform(prng.stream_seed(seed, 7), batch * cfg.lastsize() * 576, 0.02, 0.98).reshape(
+            batch, cfg.lastsize(), 24, 24)
+        # make some predictions overlap their targets so that the IoU branch is exercised with gradients
+        on = tg["delta"] > 0
+        for lo, key, a, b in ((36, "tx", 0.9, 0.03), (54, "ty", 0.95, 0.02), (72, "tw", 1.2, 0.01), (90, "th", 0.8, 0.01)):
+            head[:, lo:lo + 18][on] = (tg[key][on] * a + b).astype(np.float32)
+        fm = torch.from_numpy(head).clone().requires_grad_(True)
+        tt = {k: torch.from_numpy(v) for k, v in tg.items()}
+        image = torch.zeros(batch, 3, 384, 384)
+        ref = crit(image, fm, tt["delta"], tt["weight"], tt["weight_ij"], tt["tx_half"], tt["ty_half"], tt["tx"],
+                   tt["ty"], tt["tw"], tt["th"], tt["te"])
+        total = sum(float(c) * l for c, l in zip(coeff, ref))
+        total.backward()
+        ref_l = np.array([float(l.detach()) for l in ref], np.float32)
+        ref_g = fm.grad.numpy()
+        my_l, my_g = Lr.loss_and_grad_ref(head, tg, coeff)
+        assert np.allclose(my_l, ref_l, rtol=1e-6), (my_l, ref_l)
+        assert np.abs(my_g - ref_g).max() <= 1e-7 * max(1.0, np.abs(ref_g).max()), np.abs(my_g - ref_g).max()
+        n = 30000
+        idx = (prng.raw_u64(prng.stream_seed(seed, 99), n) % np.uint64(ref_g.size)).astype(np.int64)
+        # always include every unary position (they carry the IoU / size / coordinate gradients)
+        un = np.arange(batch * cfg.lastsize() * 576).reshape(batch, cfg.lastsize(), 576)[:, :108].reshape(-1)
+        idx = np.unique(np.concatenate([idx, un]))
+        out[f"{tag}/seed"], out[f"{tag}/batch"], out[f"{tag}/coeff"] = seed, batch, np.array(coeff, np.float32)
+        out[f"{tag}/losses"] = ref_l
+        out[f"{tag}/grad_idx"], out[f"{tag}/grad_val"] = idx, ref_g.reshape(-1)[idx]
+        out[f"{tag}/grad_abs_sum"] = np.abs(ref_g.astype(np.float64)).sum(axis=(2, 3))
+        print(f"loss {tag}: losses {ref_l}, |grad| max {np.abs(ref_g).max():.4f}; oracle == reference")
+    out["cases"] = np.array([c[0] for c in cases])
+    np.savez_compressed(os.path.join(HERE, "loss_cases.npz"), **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -251,6 +314,8 @@ def main():
         make_decode(datatest)
     if args.only in (None, "forward"):
         make_forward(drn, model)
+    if args.only in (None, "loss"):
+        make_loss()
 
 
 if __name__ == "__main__":

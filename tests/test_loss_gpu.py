@@ -1,0 +1,69 @@
+"""GPU parity of the fused PPN loss (forward values + gradient w.r.t. the head) against the golden values
+produced by the reference's own PPNLoss + autograd (tests/golden/loss_cases.npz) and against the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import loss_ref as Lr, targets_ref as T
+from pytorch_pose_proposal_network_amd import config as cfg, prng
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(g, tag):
+    seed, batch = int(g[f"{tag}/seed"]), int(g[f"{tag}/batch"])
+    tg = T.synthetic_batch(seed, batch)
+    head = prng.uniform(prng.stream_seed(seed, 7), batch * cfg.lastsize() * 576, 0.02, 0.98).reshape(
+        batch, cfg.lastsize(), 24, 24)
+    on = tg["delta"] > 0
+    for lo, key, a, b in ((36, "tx", 0.9, 0.03), (54, "ty", 0.95, 0.02), (72, "tw", 1.2, 0.01), (90, "th", 0.8, 0.01)):
+        head[:, lo:lo + 18][on] = (tg[key][on] * a + b).astype(np.float32)
+    return head, tg
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "limb_only", "iou_only"])
+def test_loss_golden(golden_dir, tag):
+    from pytorch_pose_proposal_network_amd import loss
+    g = np.load(os.path.join(golden_dir, "loss_cases.npz"))
+    head, tg = _case(g, tag)
+    crit = loss.PPNLoss()
+    fm = torch.from_numpy(head).cuda()
+    tt = {k: torch.from_numpy(v).cuda() for k, v in tg.items()}
+    coeff = g[f"{tag}/coeff"]
+    losses, grad = crit.forward_backward(fm, tt, coeff)
+    losses = losses.cpu().numpy()
+    assert np.allclose(losses, g[f"{tag}/losses"], rtol=2e-5), (losses, g[f"{tag}/losses"])
+    gh = grad.cpu().numpy()
+    ref = g[f"{tag}/grad_val"]
+    got = gh.reshape(-1)[g[f"{tag}/grad_idx"]]
+    scale = max(1e-6, float(np.abs(ref).max()))
+    assert np.abs(got - ref).max() <= 2e-5 * scale, np.abs(got - ref).max()
+    assert np.allclose(np.abs(gh.astype(np.float64)).sum(axis=(2, 3)), g[f"{tag}/grad_abs_sum"], rtol=1e-4, atol=1e-6)
+    # reference-shaped forward() returns the same five scalars and is bitwise reproducible
+    five = crit(None, fm, tt["delta"], tt["weight"], tt["weight_ij"], tt["tx_half"], tt["ty_half"], tt["tx"], tt["ty"],
+                tt["tw"], tt["th"], tt["te"])
+    assert [float(v) for v in five] == [float(v) for v in losses]
+
+
+def test_loss_matches_oracle_full_gradient():
+    """Every element of the gradient (not a sample) against torch autograd on the CPU oracle."""
+    from pytorch_pose_proposal_network_amd import loss
+    tg = T.synthetic_batch(123, 2)
+    head = prng.uniform(prng.stream_seed(5, 1), 2 * cfg.lastsize() * 576, 0.01, 0.99).reshape(2, cfg.lastsize(), 24, 24)
+    coeff = [0.25, 0.15, 0.3, 0.2, 0.1]
+    ref_l, ref_g = Lr.loss_and_grad_ref(head, tg, coeff)
+    losses, grad = loss.PPNLoss().forward_backward(torch.from_numpy(head).cuda(),
+                                                   {k: torch.from_numpy(v).cuda() for k, v in tg.items()}, coeff)
+    assert np.allclose(losses.cpu().numpy(), ref_l, rtol=2e-5)
+    d = np.abs(grad.cpu().numpy() - ref_g)
+    assert d.max() <= 2e-5 * max(1.0, float(np.abs(ref_g).max())), d.max()
+
+
+def test_loss_argument_validation():
+    from pytorch_pose_proposal_network_amd import loss
+    crit = loss.PPNLoss()
+    fm = torch.zeros(1, cfg.lastsize(), 24, 24, device="cuda")
+    with pytest.raises((ValueError, KeyError)):
+        crit.forward_backward(fm, {}, [1] * 5)

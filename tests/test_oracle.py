@@ -145,3 +145,35 @@ def test_fused_program_equals_reference_order(golden_dir, name):
     out = fused_ref.fused_forward_ref(sd, x, arch_name).numpy()
     err, err64 = np.abs(out - g["head"]).max(), np.abs(out - g["head_f64"]).max()
     assert err <= 1e-4 or err64 <= 1.5 * float(g["ref_f32_noise"]), (err, err64)
+
+
+def test_loss_oracle_golden(golden_dir):
+    """oracle/loss_ref.py (PPNLoss restatement + autograd) replays the values the reference itself produced."""
+    from oracle import loss_ref as Lr, targets_ref as T
+    g = _load(golden_dir, "loss_cases.npz")
+    for tag in ("a", "iou_only"):
+        seed, batch = int(g[f"{tag}/seed"]), int(g[f"{tag}/batch"])
+        tg = T.synthetic_batch(seed, batch)
+        head = prng.uniform(prng.stream_seed(seed, 7), batch * cfg.lastsize() * 576, 0.02, 0.98).reshape(
+            batch, cfg.lastsize(), 24, 24)
+        on = tg["delta"] > 0
+        for lo, key, a, b in ((36, "tx", 0.9, 0.03), (54, "ty", 0.95, 0.02), (72, "tw", 1.2, 0.01), (90, "th", 0.8, 0.01)):
+            head[:, lo:lo + 18][on] = (tg[key][on] * a + b).astype(np.float32)
+        losses, grad = Lr.loss_and_grad_ref(head, tg, g[f"{tag}/coeff"])
+        assert np.allclose(losses, g[f"{tag}/losses"], rtol=1e-5)
+        ref = g[f"{tag}/grad_val"]
+        assert np.abs(grad.reshape(-1)[g[f"{tag}/grad_idx"]] - ref).max() <= 1e-6 * max(1.0, float(np.abs(ref).max()))
+
+
+def test_target_encoder_roundtrip():
+    """Known-answer property (idea of datatest.py:403-412): targets encoded by the dataset rules, fed to the
+    decoder as a perfect head, come back as the planted people."""
+    from oracle import targets_ref as T
+    people = T.synthetic_people(321)
+    tg = T.encode_targets(people)
+    head = np.concatenate([tg["delta"], np.ones_like(tg["delta"]), tg["tx"], tg["ty"], tg["tw"], tg["th"],
+                           tg["te"].reshape(17 * 441, 24, 24)], 0).astype(np.float32)
+    res = D.decode_ref(head)
+    roots = {(int(p["bbox"][1] // 16), int(p["bbox"][0] // 16)) for p in people}
+    got = {divmod(int(c), 24) for c in res["root_cell"]}
+    assert got <= roots and len(got) >= 1
