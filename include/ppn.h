@@ -187,6 +187,15 @@ int ppn_stem7x7(int32_t dtype, int32_t src_is_u8, const void* src, int32_t batch
                 const float* weight, const float* scale, const float* shift, const float* mean, const float* std_,
                 void* out, void* stream);
 
+/*
+ * layer0 + layer1 (drn.py:123-130) in one launch: as ppn_stem7x7, then 3x3 conv 16->16 + BN + ReLU on the tile that
+ * is still in LDS; the 16-channel tensor between the two layers never goes to HBM.
+ *   w1 f32 [16,16,3,3] (reference layout, device), scale1/shift1 f32[16] folded BN of layer1.  out NHWC [B,H,W,16].
+ */
+int ppn_stem01(int32_t dtype, int32_t src_is_u8, const void* src, int32_t batch, int32_t h, int32_t w,
+               const float* w0, const float* scale0, const float* shift0, const float* mean, const float* std_,
+               const float* w1, const float* scale1, const float* shift1, void* out, void* stream);
+
 /* A recorded sequence of launches (one forward pass): replayed in order on `stream`. */
 typedef struct ppn_plan ppn_plan;
 int ppn_plan_create(ppn_plan** out);
@@ -196,6 +205,9 @@ int ppn_plan_add_memset(ppn_plan* p, void* ptr, size_t bytes);
 int ppn_plan_add_stem(ppn_plan* p, int32_t dtype, int32_t src_is_u8, const void* src, int32_t batch, int32_t h,
                       int32_t w, const float* weight, const float* scale, const float* shift, const float* mean,
                       const float* std_, void* out);
+int ppn_plan_add_stem01(ppn_plan* p, int32_t dtype, int32_t src_is_u8, const void* src, int32_t batch, int32_t h,
+                        int32_t w, const float* w0, const float* scale0, const float* shift0, const float* mean,
+                        const float* std_, const float* w1, const float* scale1, const float* shift1, void* out);
 /* Re-point the first layer's input (same shape/dtype as at ppn_plan_add_stem) before a run. */
 int ppn_plan_set_input(ppn_plan* p, const void* src);
 int ppn_plan_run(ppn_plan* p, void* stream);

@@ -68,6 +68,12 @@ def fused_forward_ref(sd, x: torch.Tensor, arch: str = "drn_d_22", emulate_bf16:
             if b1 is not None:
                 v = v + b1.float().view(1, -1, 1, 1)
             v = _ACT[op.act1](v)
+            if op.next3x3 is not None:
+                # layer0 + layer1 in one launch: the intermediate lives in LDS in the storage dtype
+                n = op.next3x3
+                s2n, b2n = _fold(sd, n.bn1)
+                acc2 = F.conv2d(q(v), q(_t(sd[n.weight]).float()), None, n.stride, n.pad, n.dilation)
+                v = _ACT[n.act1](acc2 * s2n.float().view(1, -1, 1, 1) + b2n.float().view(1, -1, 1, 1))
             if op.residual:
                 v = v + tensors[op.residual]
             if op.out_raw:

@@ -62,6 +62,7 @@ class ConvOp:
     act2: int = ACT_NONE
     out_act: Optional[str] = None     # store act2(bn2(v))
     nchw_f32_out: bool = False        # head: sigmoid output in the reference's NCHW f32 layout
+    next3x3: Optional["ConvOp"] = None  # layer0 only: layer1 (3x3 16->16 conv+BN+ReLU) fused into the same launch
 
 
 @dataclass
@@ -171,8 +172,12 @@ def _needs(u: Optional[Unit]):
     return True, None                                    # cbr / bottleneck read raw x
 
 
-def build_program(arch: str = "drn_d_22", head_channels: Optional[int] = None) -> List[ConvOp]:
-    """Lower the module list into fused conv launches."""
+def build_program(arch: str = "drn_d_22", head_channels: Optional[int] = None, fuse_stem: bool = False) -> List[ConvOp]:
+    """Lower the module list into fused conv launches.
+
+    fuse_stem: layer0 (7x7) and the first conv of layer1 (3x3 16->16) share one launch (csrc/stem01.hip): the
+    16x384x384 tensor between them never goes to HBM.  Off by default: measured on MI355X the fused kernel is
+    instruction-bound (235 us vs 83 + 133 us for the two separate launches at batch 32), see DESIGN.md."""
     hc = head_channels or cfg.lastsize()
     units = _units(arch)
     ops: List[ConvOp] = []
@@ -204,6 +209,15 @@ def build_program(arch: str = "drn_d_22", head_channels: Optional[int] = None) -
             d = u.dil[0]
             op = ConvOp(w, raw, f"{w}.weight", u.cin, u.cout, u.k, u.stride, d,
                         pad=(3 if u.k == 7 else d), bn1=f"{u.prefix}.{u.conv_idx + 1}", act1=ACT_RELU)
+            if (fuse_stem and i == 1 and ops and ops[-1].k == 7 and ops[-1].next3x3 is None and u.cin == 16 and
+                    u.cout == 16 and u.k == 3 and u.stride == 1 and d == 1 and pre is None):
+                first = ops.pop()                      # layer0: its only consumer is this conv
+                first.next3x3 = op
+                first.name = first.name + "+" + op.name
+                first.out_raw = None
+                op.src = "(on chip)"
+                finish(first, w.replace(".", "_"))
+                continue
             finish(op, w.replace(".", "_"))
         elif u.kind == "basic":
             p = u.prefix
@@ -269,9 +283,10 @@ def tensor_shapes(ops: List[ConvOp], h: int, w: int) -> Dict[str, Tuple[int, int
         ih, iw, ic = shapes[op.src]
         assert ic == op.cin, (op.name, ic, op.cin)
         oh, ow = out_hw(op, ih, iw)
+        cout = op.next3x3.cout if op.next3x3 else op.cout
         for name in (op.out_raw, op.out_act):
             if name:
-                shapes[name] = (oh, ow, op.cout)
+                shapes[name] = (oh, ow, cout)
         if op.residual:
             assert shapes[op.residual] == (oh, ow, op.cout), (op.name, shapes[op.residual], (oh, ow, op.cout))
     return shapes
@@ -282,7 +297,15 @@ def conv_flops(ops: List[ConvOp], h: int, w: int) -> int:
     shapes = tensor_shapes(ops, h, w)
     total = 0
     for op in ops:
-        out = op.out_raw or op.out_act
-        oh, ow, _ = shapes[out]
-        total += 2 * op.cin * op.cout * op.k * op.k * oh * ow
+        total += op_flops(op, shapes)
     return total
+
+
+def op_flops(op: ConvOp, shapes) -> int:
+    """2*MACs of one launch for one image (a fused layer0+layer1 launch counts both convolutions)."""
+    oh, ow, _ = shapes[op.out_raw or op.out_act]
+    fl = 2 * op.cin * op.cout * op.k * op.k * oh * ow
+    if op.next3x3:
+        n = op.next3x3
+        fl += 2 * n.cin * n.cout * n.k * n.k * oh * ow
+    return fl

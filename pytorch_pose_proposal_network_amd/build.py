@@ -23,6 +23,7 @@ SOURCES = [
     ("conv_big.hip", []),
     ("stem.hip", []),
     ("stem3x3.hip", []),
+    ("stem01.hip", []),
     ("plan.hip", []),
     ("loss.hip", []),
 ]

@@ -11,11 +11,15 @@ int conv_launch(const ppn_conv_desc* d, hipStream_t st, const char** kname);
 int stem_launch(int dtype, int src_is_u8, const void* src, int batch, int h, int w, const float* weight,
                 const float* scale, const float* shift, const float* mean, const float* stdv, void* out,
                 hipStream_t st);
+int stem01_launch(int dtype, int src_is_u8, const void* src, int batch, int h, int w, const float* w0,
+                  const float* s0, const float* b0, const float* mean, const float* stdv, const float* w1,
+                  const float* s1, const float* b1, void* out, hipStream_t st);
 }  // namespace ppn
 
 struct ppn_plan {
     struct Op {
-        int kind;  // 0 conv, 1 stem, 2 memset
+        int kind;  // 0 conv, 1 stem, 2 memset, 3 stem01 (layer0 + layer1)
+        const float *w1 = nullptr, *scale1 = nullptr, *shift1 = nullptr;
         void* ms_ptr = nullptr;
         size_t ms_bytes = 0;
         ppn_conv_desc conv;
@@ -41,6 +45,11 @@ static int run_op(ppn_plan::Op& op, hipStream_t st) {
         int rc = ppn::conv_launch(&op.conv, st, &kn);
         if (rc == PPN_OK && kn && op.kname.empty()) op.kname = kn;
         return rc;
+    }
+    if (op.kind == 3) {
+        if (op.kname.empty()) op.kname = op.dtype == PPN_F32 ? "stem01_kernel<float>" : "stem01_kernel<__bf16>";
+        return ppn::stem01_launch(op.dtype, op.src_is_u8, op.src, op.batch, op.h, op.w, op.weight, op.scale, op.shift,
+                                  op.mean, op.stdv, op.w1, op.scale1, op.shift1, op.out, st);
     }
     if (op.kname.empty()) op.kname = op.dtype == PPN_F32 ? "stem7x7_kernel<float>" : "stem7x7_kernel<__bf16>";
     return ppn::stem_launch(op.dtype, op.src_is_u8, op.src, op.batch, op.h, op.w, op.weight, op.scale, op.shift,
@@ -85,10 +94,25 @@ extern "C" int ppn_plan_add_stem(ppn_plan* p, int32_t dtype, int32_t src_is_u8, 
     return PPN_OK;
 }
 
+extern "C" int ppn_plan_add_stem01(ppn_plan* p, int32_t dtype, int32_t src_is_u8, const void* src, int32_t batch,
+                                   int32_t h, int32_t w, const float* w0, const float* scale0, const float* shift0,
+                                   const float* mean, const float* std_, const float* w1, const float* scale1,
+                                   const float* shift1, void* out) {
+    if (!p) return ppn::fail(PPN_E_INVALID, "ppn_plan_add_stem01: NULL plan");
+    ppn_plan::Op op{};
+    op.kind = 3;
+    op.dtype = dtype; op.src_is_u8 = src_is_u8; op.src = src; op.batch = batch; op.h = h; op.w = w;
+    op.weight = w0; op.scale = scale0; op.shift = shift0; op.w1 = w1; op.scale1 = scale1; op.shift1 = shift1;
+    op.out = out;
+    for (int i = 0; i < 3; ++i) { op.mean[i] = mean ? mean[i] : 0.f; op.stdv[i] = std_ ? std_[i] : 1.f; }
+    p->ops.push_back(op);
+    return PPN_OK;
+}
+
 extern "C" int ppn_plan_set_input(ppn_plan* p, const void* src) {
     if (!p || !src) return ppn::fail(PPN_E_INVALID, "ppn_plan_set_input: NULL argument");
     for (auto& op : p->ops)
-        if (op.kind == 1) { op.src = src; return PPN_OK; }
+        if (op.kind == 1 || op.kind == 3) { op.src = src; return PPN_OK; }
     return ppn::fail(PPN_E_INVALID, "ppn_plan_set_input: plan has no input layer");
 }
 

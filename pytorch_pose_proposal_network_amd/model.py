@@ -58,7 +58,7 @@ class _Plan:
 class PoseProposalNet:
     def __init__(self, backbone="drn_d_22", insize=(384, 384), outsize=(24, 24),
                  keypoint_names=cfg.KEYPOINT_NAMES, local_grid_size=(21, 21), edges=cfg.EDGES,
-                 compute_dtype: str = "float32"):
+                 compute_dtype: str = "float32", fuse_stem: bool = False):
         self.arch = _arch_of(backbone)
         self.insize = insize
         self.outsize = outsize
@@ -74,7 +74,7 @@ class PoseProposalNet:
                               "bf16": L.PPN_BF16}[compute_dtype]
         self.training = False
         self.device = torch.device("cuda")
-        self._ops: List[A.ConvOp] = A.build_program(self.arch, self.lastsize)
+        self._ops: List[A.ConvOp] = A.build_program(self.arch, self.lastsize, fuse_stem=fuse_stem)
         self._spec = dict(A.param_spec(self.arch, self.lastsize))
         self._sd: Dict[str, torch.Tensor] = {}
         self._dev: Dict[str, torch.Tensor] = {}      # packed weights / folded BN on the device
@@ -160,6 +160,12 @@ class PoseProposalNet:
                 self._dev[op.name + ".b2"] = b2.float().to(dev)
             if op.k == 7:                                     # stem keeps the reference layout in f32
                 self._dev[op.name + ".w"] = w.to(dev)
+                if op.next3x3 is not None:                     # layer1 fused into the same launch
+                    n = op.next3x3
+                    sn, bn_ = self._fold_bn(n.bn1)
+                    self._dev[op.name + ".w1"] = self._sd[n.weight].float().contiguous().to(dev)
+                    self._dev[op.name + ".s1b"] = sn.float().to(dev)
+                    self._dev[op.name + ".b1b"] = bn_.float().to(dev)
                 continue
             kstep, _, korder, ktot, cpad = L.conv_tiling(self.compute_dtype, op.cin, op.cout, op.k)
             wd = w.to(dev)
@@ -201,7 +207,16 @@ class PoseProposalNet:
         for op in self._ops:
             ih, iw, _ = shapes[op.src]
             oh, ow = A.out_hw(op, ih, iw)
-            entries.append((op.name, 2 * op.cin * op.cout * op.k * op.k * oh * ow * batch))
+            entries.append((op.name, A.op_flops(op, shapes) * batch))
+            if op.k == 7 and op.next3x3 is not None:
+                assert op.src == "input" and op.out_act is None
+                L.check(lib.ppn_plan_add_stem01(handle, self.compute_dtype, 1 if src_is_u8 else 0, src.data_ptr(),
+                                                batch, h, w, self._ptr(op.name + ".w"), self._ptr(op.name + ".s1"),
+                                                self._ptr(op.name + ".b1"), self._mean, self._std,
+                                                self._ptr(op.name + ".w1"), self._ptr(op.name + ".s1b"),
+                                                self._ptr(op.name + ".b1b"), bufs[op.out_raw].data_ptr()),
+                        "ppn_plan_add_stem01")
+                continue
             if op.k == 7:
                 assert op.src == "input" and op.out_act is None
                 L.check(lib.ppn_plan_add_stem(handle, self.compute_dtype, 1 if src_is_u8 else 0, src.data_ptr(),

@@ -160,3 +160,23 @@ def test_fused_decode_equals_decode_of_materialised_head(golden_dir, dtype):
         assert ra["n"] == rb["n"] > 0
         for k in ("kp_cell", "limb_arg", "bbox", "score"):
             assert np.array_equal(ra[k], rb[k]), k
+
+
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
+def test_fused_stem_variant(golden_dir, dtype):
+    """PoseProposalNet(fuse_stem=True): layer0+layer1 in one launch (csrc/stem01.hip) gives the same head."""
+    from pytorch_pose_proposal_network_amd import drn, model
+    g = np.load(os.path.join(golden_dir, "forward_d22_96.npz"))
+    stats = {k[3:]: g[k] for k in g.files if k.startswith("bn/")}
+    sd = synth.make_state_dict("drn_d_22", 0, bn_stats=stats)
+    m = model.PoseProposalNet(drn.drn_d_22(), compute_dtype=dtype, fuse_stem=True).cuda()
+    m.load_state_dict(sd)
+    u8 = _frames(g)
+    head = m.forward_u8(torch.from_numpy(u8).cuda()).cpu().numpy()
+    d = np.abs(head - g["head"])
+    if dtype == "float32":
+        assert d.max() <= F32_TOL
+        x = torch.from_numpy(synth.normalized_frames(u8)).cuda()
+        assert np.abs(m(x).cpu().numpy() - g["head"]).max() <= F32_TOL
+    else:
+        assert d.max() <= BF16_MAX_TOL and d.mean() <= BF16_MEAN_TOL
