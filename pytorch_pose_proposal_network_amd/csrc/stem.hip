@@ -50,12 +50,40 @@ template <typename T>
 __global__ void __launch_bounds__(256) stem7x7_kernel(StemArgs a) {
     __shared__ __attribute__((aligned(16))) T patch[PH * PW * 4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int bid = blockIdx.x;
+
+    // ---- weights as A fragments (rows = output channels) ---------------------------------------
+    const int ch = lane & 15, g = lane >> 4;
+    const float* wc = a.weight + (size_t)ch * 3 * 49;
+    constexpr bool BF = sizeof(T) == 2;
+    bf16x8 wa[7];        // bf16 mode: per dy, k = (dx = 2g + (i>>2), c = i&3)
+    float wf[49];        // f32 mode: per (dy,dx), k = c = g
+    if (BF) {
+#pragma unroll
+        for (int dy = 0; dy < 7; ++dy) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int dx = 2 * g + (i >> 2), c = i & 3;
+                const float w = (dx < 7 && c < 3) ? wc[(c * 7 + dy) * 7 + dx] : 0.f;
+                wa[dy][i] = (__bf16)w;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < 49; ++t) wf[t] = (g < 3) ? wc[g * 49 + t] : 0.f;
+    }
+    float sc[4], sh[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { sc[r] = a.scale[4 * g + r]; sh[r] = a.shift[4 * g + r]; }
+    // ---- persistent loop over tiles: the weight-fragment set-up above is paid once per workgroup ----------
+    const int col = lane & 15;
+    const int ntiles = a.tiles_x * a.tiles_y * a.B;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int bid = tile;
     const int tx = bid % a.tiles_x; bid /= a.tiles_x;
     const int ty = bid % a.tiles_y;
     const int b = bid / a.tiles_y;
     const int y0 = ty * TH, x0 = tx * TW;
-
+    __syncthreads();                                     // previous tile's readers are done with the patch
     // ---- stage the normalised patch ---------------------------------------------------------
     // (all global loads are issued before the first LDS store so that their latencies overlap)
     constexpr int NPIX = PH * PW, NIT = (NPIX + 255) / 256;
@@ -86,33 +114,9 @@ __global__ void __launch_bounds__(256) stem7x7_kernel(StemArgs a) {
         if (i < NPIX) patch_store<T>(patch + (size_t)i * 4, sv[it][0], sv[it][1], sv[it][2]);
     }
 
-    // ---- weights as A fragments (rows = output channels) ---------------------------------------
-    const int ch = lane & 15, g = lane >> 4;
-    const float* wc = a.weight + (size_t)ch * 3 * 49;
-    constexpr bool BF = sizeof(T) == 2;
-    bf16x8 wa[7];        // bf16 mode: per dy, k = (dx = 2g + (i>>2), c = i&3)
-    float wf[49];        // f32 mode: per (dy,dx), k = c = g
-    if (BF) {
-#pragma unroll
-        for (int dy = 0; dy < 7; ++dy) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int dx = 2 * g + (i >> 2), c = i & 3;
-                const float w = (dx < 7 && c < 3) ? wc[(c * 7 + dy) * 7 + dx] : 0.f;
-                wa[dy][i] = (__bf16)w;
-            }
-        }
-    } else {
-#pragma unroll
-        for (int t = 0; t < 49; ++t) wf[t] = (g < 3) ? wc[g * 49 + t] : 0.f;
-    }
-    float sc[4], sh[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { sc[r] = a.scale[4 * g + r]; sh[r] = a.shift[4 * g + r]; }
     __syncthreads();
 
     // ---- 16 row segments of 16 pixels per wave ----------------------------------------------
-    const int col = lane & 15;
     for (int sgi = 0; sgi < 16; ++sgi) {
         const int ry = wave * 4 + (sgi >> 2), sx = (sgi & 3) * 16;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -154,6 +158,7 @@ __global__ void __launch_bounds__(256) stem7x7_kernel(StemArgs a) {
             }
         }
     }
+    }   // persistent tile loop
 }
 
 }  // namespace
@@ -173,10 +178,11 @@ int stem_launch(int dtype, int src_is_u8, const void* src, int batch, int h, int
     a.tiles_x = (w + TW - 1) / TW; a.tiles_y = (h + TH - 1) / TH;
     const long long blocks = (long long)a.tiles_x * a.tiles_y * batch;
     if (blocks > 0x7fffffffLL) return fail(PPN_E_UNSUPPORTED, "too many tiles");
+    const unsigned grid = (unsigned)(blocks < 256 * 4 ? blocks : 256 * 4);      // persistent: <= 4 workgroups per CU
     if (dtype == PPN_F32)
-        hipLaunchKernelGGL(stem7x7_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(stem7x7_kernel<float>, dim3(grid), dim3(256), 0, st, a);
     else
-        hipLaunchKernelGGL(stem7x7_kernel<__bf16>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(stem7x7_kernel<__bf16>, dim3(grid), dim3(256), 0, st, a);
     PPN_LAUNCH_CHECK();
     return PPN_OK;
 }

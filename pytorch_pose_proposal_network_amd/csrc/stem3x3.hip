@@ -52,33 +52,6 @@ __global__ void __launch_bounds__(256) stem3x3_kernel(Stem3Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int bid = blockIdx.x;
-    const int tx = bid % a.tiles_x; bid /= a.tiles_x;
-    const int ty = bid % a.tiles_y;
-    const int b = bid / a.tiles_y;
-    const int oy0 = ty * TH, ox0 = tx * TW;
-    const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;     // pad 1
-
-    // ---- stage the input patch (zero padded) ------------------------------------------------------
-    const char* src = static_cast<const char*>(a.src);
-    // (all loads are issued before the first LDS store so that their latencies overlap)
-    constexpr int NCHUNK = PH * PW * CPP, NIT = (NCHUNK + 255) / 256;
-    uint4 stage[NIT];
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int i = it * 256 + tid;
-        const int py = i / (PW * CPP), r = i - py * (PW * CPP);
-        const int px = r / CPP, ch = r - px * CPP;
-        const int gy = iy0 + py, gx = ix0 + px;
-        stage[it] = make_uint4(0, 0, 0, 0);
-        if (i < NCHUNK && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
-            stage[it] = *reinterpret_cast<const uint4*>(src + ((((size_t)b * a.H + gy) * a.W + gx) * CPP + ch) * 16);
-    }
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int i = it * 256 + tid;
-        if (i < NCHUNK) *reinterpret_cast<uint4*>(smem + (size_t)i * 16) = stage[it];
-    }
 
     // ---- weights as A fragments (rows = output channels) ------------------------------------------
     const int ch = lane & 15, g = lane >> 4;
@@ -113,10 +86,41 @@ __global__ void __launch_bounds__(256) stem3x3_kernel(Stem3Args a) {
             s1[ct][r] = a.scale1[c]; b1[ct][r] = a.shift1[c];
             s2[ct][r] = a.scale2 ? a.scale2[c] : 1.f; b2[ct][r] = a.shift2 ? a.shift2[c] : 0.f;
         }
+    // ---- persistent loop over output tiles: the fragment set-up above is paid once per workgroup ----------
+    const int col = lane & 15;
+    const int ntiles = a.tiles_x * a.tiles_y * a.B;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int bid = tile;
+    const int tx = bid % a.tiles_x; bid /= a.tiles_x;
+    const int ty = bid % a.tiles_y;
+    const int b = bid / a.tiles_y;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;     // pad 1
+    __syncthreads();                                     // previous tile's readers are done with the patch
+    // ---- stage the input patch (zero padded) ------------------------------------------------------
+    const char* src = static_cast<const char*>(a.src);
+    // (all loads are issued before the first LDS store so that their latencies overlap)
+    constexpr int NCHUNK = PH * PW * CPP, NIT = (NCHUNK + 255) / 256;
+    uint4 stage[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int i = it * 256 + tid;
+        const int py = i / (PW * CPP), r = i - py * (PW * CPP);
+        const int px = r / CPP, ch = r - px * CPP;
+        const int gy = iy0 + py, gx = ix0 + px;
+        stage[it] = make_uint4(0, 0, 0, 0);
+        if (i < NCHUNK && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+            stage[it] = *reinterpret_cast<const uint4*>(src + ((((size_t)b * a.H + gy) * a.W + gx) * CPP + ch) * 16);
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int i = it * 256 + tid;
+        if (i < NCHUNK) *reinterpret_cast<uint4*>(smem + (size_t)i * 16) = stage[it];
+    }
+
     __syncthreads();
 
     // ---- TH*TW/16 row segments of 16 output pixels, TH*4/4 per wave ---------------------------------
-    const int col = lane & 15;
     constexpr int NSEG = TH * (TW / 16);
     for (int sgi = wave; sgi < NSEG; sgi += 4) {
         const int ry = sgi / (TW / 16), sx = (sgi % (TW / 16)) * 16;
@@ -177,6 +181,7 @@ __global__ void __launch_bounds__(256) stem3x3_kernel(Stem3Args a) {
             }
         }
     }
+    }   // persistent tile loop
 }
 
 template <typename T, int COUT, int S>
@@ -188,7 +193,10 @@ int launch(const Stem3Args& a, hipStream_t st) {
         PPN_LDS_ONCE(max_lds_set, reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       G::LDS_BYTES);
     }
-    hipLaunchKernelGGL(k, dim3((unsigned)(a.tiles_x * a.tiles_y * a.B)), dim3(256), G::LDS_BYTES, st, a);
+    const int ntiles = a.tiles_x * a.tiles_y * a.B;
+    const int per_cu = G::LDS_BYTES <= 40 * 1024 ? 4 : (G::LDS_BYTES <= 80 * 1024 ? 2 : 1);
+    const int grid = ntiles < 256 * per_cu ? ntiles : 256 * per_cu;
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(256), G::LDS_BYTES, st, a);
     PPN_LAUNCH_CHECK();
     return PPN_OK;
 }
