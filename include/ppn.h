@@ -155,6 +155,13 @@ typedef struct ppn_conv_desc {
      * zeroes the buffer before the launch, see ppn_plan_add_memset).  out_raw may then be NULL: the 17.5 MB/image
      * head tensor is never written (rt_test.py:109-120 copies it to the host instead).  ppn_decode_fused consumes
      * the two buffers. */
+    /* Fused 1x1 projection shortcut (BasicBlock.downsample, drn.py:53-54): when src2 != NULL the GEMM depth is
+     * extended by cin2 values gathered from src2 NHWC [B,in2_h,in2_w,cin2] at (oy*stride2, ox*stride2); the packed
+     * weight rows carry [main conv | shortcut 1x1 weights pre-multiplied by the shortcut BN scale] and shift1
+     * carries the shortcut BN shift, so  out = conv(src) + bn_ds(conv1x1(src2))  costs no extra launch and no
+     * residual tensor.  k_total = k_main + cin2, both multiples of the K step; scale1 must be NULL. */
+    const void* src2;
+    int32_t in2_h, in2_w, cin2, stride2;
     float* unary_out;
     uint64_t* argmax_keys;
     int32_t unary_channels;      /* 6K = 108                                                          */

@@ -57,6 +57,12 @@ def fused_forward_ref(sd, x: torch.Tensor, arch: str = "drn_d_22", emulate_bf16:
                 src_q, w_q = src, q(w)             # other inputs are already-stored (rounded) tensors
             acc = F.conv2d(src_q, w_q, None, op.stride, op.pad, op.dilation)
             s1 = b1 = None
+            if op.ds_src:
+                # fused projection shortcut: the BN scale is folded into the 1x1 weights BEFORE they are stored
+                sds, bds = _fold(sd, op.ds_bn)
+                wds = _t(sd[op.ds_weight]).float() * sds.float().view(-1, 1, 1, 1)
+                acc = acc + F.conv2d(tensors[op.ds_src], q(wds), None, op.ds_stride, 0, 1)
+                b1 = bds
             if op.bn1:
                 s1, b1 = _fold(sd, op.bn1)
             if op.bias:

@@ -63,6 +63,12 @@ class ConvOp:
     out_act: Optional[str] = None     # store act2(bn2(v))
     nchw_f32_out: bool = False        # head: sigmoid output in the reference's NCHW f32 layout
     next3x3: Optional["ConvOp"] = None  # layer0 only: layer1 (3x3 16->16 conv+BN+ReLU) fused into the same launch
+    # fused projection shortcut: out = conv(src) + bn_ds(conv1x1_stride(ds_src))  (BasicBlock.downsample, drn.py:53-54)
+    ds_src: Optional[str] = None
+    ds_weight: Optional[str] = None
+    ds_bn: Optional[str] = None
+    ds_cin: int = 0
+    ds_stride: int = 1
 
 
 @dataclass
@@ -172,12 +178,15 @@ def _needs(u: Optional[Unit]):
     return True, None                                    # cbr / bottleneck read raw x
 
 
-def build_program(arch: str = "drn_d_22", head_channels: Optional[int] = None, fuse_stem: bool = False) -> List[ConvOp]:
+def build_program(arch: str = "drn_d_22", head_channels: Optional[int] = None, fuse_stem: bool = False,
+                  fuse_shortcut: bool = True) -> List[ConvOp]:
     """Lower the module list into fused conv launches.
 
     fuse_stem: layer0 (7x7) and the first conv of layer1 (3x3 16->16) share one launch (csrc/stem01.hip): the
     16x384x384 tensor between them never goes to HBM.  Off by default: measured on MI355X the fused kernel is
     instruction-bound (235 us vs 83 + 133 us for the two separate launches at batch 32), see DESIGN.md."""
+    # fuse_shortcut: a BasicBlock's 1x1 projection shortcut (+BN) becomes extra GEMM depth of its second conv
+    # (no separate launch, no residual tensor) whenever its input width is a multiple of 64.
     hc = head_channels or cfg.lastsize()
     units = _units(arch)
     ops: List[ConvOp] = []
@@ -223,7 +232,8 @@ def build_program(arch: str = "drn_d_22", head_channels: Optional[int] = None, f
             p = u.prefix
             assert act is not None, "pre-activation tensor missing for BasicBlock"
             res = raw
-            if u.downsample:
+            fuse_ds = u.downsample and fuse_shortcut and u.cin % 64 == 0 and u.cout >= 64
+            if u.downsample and not fuse_ds:
                 res = t(p.replace(".", "_") + "_ds")
                 ops.append(ConvOp(f"{p}.downsample", raw, f"{p}.downsample.0.weight", u.cin, u.cout, 1,
                                   u.stride, 1, 0, bn1=f"{p}.downsample.1", out_raw=res))
@@ -231,7 +241,11 @@ def build_program(arch: str = "drn_d_22", head_channels: Optional[int] = None, f
             ops.append(ConvOp(f"{p}.conv1", act, f"{p}.conv1.weight", u.cin, u.cout, 3, u.stride,
                               u.dil[0], u.dil[0], bn1=f"{p}.bn2", act1=ACT_RELU, out_raw=mid))
             op = ConvOp(f"{p}.conv2", mid, f"{p}.conv2.weight", u.cout, u.cout, 3, 1, u.dil[1], u.dil[1],
-                        residual=res)
+                        residual=None if fuse_ds else res)
+            if fuse_ds:
+                op.name = f"{p}.conv2+downsample"
+                op.ds_src, op.ds_weight, op.ds_bn = raw, f"{p}.downsample.0.weight", f"{p}.downsample.1"
+                op.ds_cin, op.ds_stride = u.cin, u.stride
             finish(op, p.replace(".", "_"))
         elif u.kind == "bottleneck":
             p, pl = u.prefix, u.planes
@@ -305,6 +319,8 @@ def op_flops(op: ConvOp, shapes) -> int:
     """2*MACs of one launch for one image (a fused layer0+layer1 launch counts both convolutions)."""
     oh, ow, _ = shapes[op.out_raw or op.out_act]
     fl = 2 * op.cin * op.cout * op.k * op.k * oh * ow
+    if op.ds_src:
+        fl += 2 * op.ds_cin * op.cout * oh * ow
     if op.next3x3:
         n = op.next3x3
         fl += 2 * n.cin * n.cout * n.k * n.k * oh * ow

@@ -413,7 +413,15 @@ int ppn::conv_launch(const ppn_conv_desc* d, hipStream_t st, const char** kname)
     const int log2c = ilog2_exact(d->cin);
     if (smallc && log2c < 0) return ppn::fail(PPN_E_UNSUPPORTED, "cin %d < K step must be a power of two", d->cin);
     const int kreal = d->ksize * d->ksize * d->cin;
-    const int kpad = ((kreal + bk - 1) / bk) * bk;
+    int kpad = ((kreal + bk - 1) / bk) * bk;
+    const int kmain = kpad;
+    if (d->src2) {
+        if (d->cin2 < bk || d->cin2 % bk != 0 || d->stride2 < 1 || d->in2_h < 1 || d->in2_w < 1 || d->scale1 ||
+            d->out_nchw_f32 || smallc || (d->out_h - 1) * d->stride2 >= d->in2_h || (d->out_w - 1) * d->stride2 >= d->in2_w)
+            return ppn::fail(PPN_E_INVALID, "fused shortcut: cin2 must be a multiple of the K step, scale1 NULL, "
+                                            "and (out-1)*stride2 inside the second source");
+        kpad += d->cin2;
+    }
     if (d->k_total != kpad) return ppn::fail(PPN_E_INVALID, "k_total %d != %d", d->k_total, kpad);
     const long long m = (long long)d->batch * d->out_h * d->out_w;
     TileChoice tc = choose_tile(d->cout);
@@ -455,12 +463,20 @@ int ppn::conv_launch(const ppn_conv_desc* d, hipStream_t st, const char** kname)
     a.log2Cin = log2c < 0 ? 0 : log2c;
     a.n_ctiles = d->cout_pad / bc;
     a.n_ptiles = (int)((m + bp - 1) / bp);
+    a.src2 = static_cast<const char*>(d->src2);
+    a.H2 = d->src2 ? d->in2_h : 1; a.W2 = d->src2 ? d->in2_w : 1; a.Cin2 = d->src2 ? d->cin2 : 0;
+    a.stride2 = d->src2 ? d->stride2 : 1;
+    a.nsteps_main = kmain / bk;
+    a.src2_bytes = d->src2 ? (unsigned)((size_t)d->batch * d->in2_h * d->in2_w * d->cin2 * (d->dtype == PPN_F32 ? 4 : 2)) : 0u;
+    if (d->src2 && (size_t)d->batch * d->in2_h * d->in2_w * d->cin2 * 4 >= 0x7fffff00ull)
+        return ppn::fail(PPN_E_UNSUPPORTED, "second source too large for the buffer-addressed conv kernel");
     a.unary_out = d->unary_out;
     a.amax_keys = reinterpret_cast<unsigned long long*>(d->argmax_keys);
     a.unary_ch = d->unary_channels;
     a.window = d->limb_window;
     if (big) return launch_big(a, d->dtype, bt, st, kname);
     if (d->argmax_keys) return ppn::fail(PPN_E_UNSUPPORTED, "fused arg-max is implemented by the large-tile kernel only");
+    if (d->src2) return ppn::fail(PPN_E_UNSUPPORTED, "the fused shortcut is implemented by the large-tile kernel only");
     if (d->dtype == PPN_F32) return launch_dtype<float>(a, smallc, tc, st, kname);
     return launch_dtype<__bf16>(a, smallc, tc, st, kname);
 }

@@ -108,13 +108,17 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
 
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.src, 0, src_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.wgt, 0, wgt_bytes, 0x00020000);
+    // second activation source: the block input of a fused 1x1 projection shortcut (zero records when unused)
+    const __amdgpu_buffer_rsrc_t xrs2 =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(a.src2 ? a.src2 : a.src), 0, a.src2 ? a.src2_bytes : 0u, 0x00020000);
 
     // ---- per-lane loader state: 32-bit byte offsets ----------------------------------------------
     const int lrow = lane >> 3;
     const int chunk = (lane & 7) ^ (((lane >> 4) & 3) | ((wave & 1) << 2));
     const int ntaps = a.ks * a.ks;
     int xbase[NXI];          // byte offset of (pixel row, tap 0, ci 0, this lane's chunk); may be negative
-    unsigned xmask[NXI];
+    int xbase2[NXI];         // same for the shortcut source (1x1, stride2, no padding)
+    unsigned xmask[NXI];     // bit t: tap t in bounds;  bit 31: the output pixel itself exists (m < M)
 #pragma unroll
     for (int j = 0; j < NXI; ++j) {
         const int row = (j * NW + wave) * 8 + lrow;
@@ -131,7 +135,8 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
             const int iy = iy0 + dy * a.dil, ix = ix0 + dx * a.dil;
             if (vm && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) mk |= (1u << t);
         }
-        xmask[j] = mk;
+        xmask[j] = mk | (vm ? 0x80000000u : 0u);
+        xbase2[j] = (((b * a.H2 + oy * a.stride2) * a.W2 + ox * a.stride2) * a.Cin2 + chunk * EPC) * ES;
     }
     unsigned woff[NWI];
 #pragma unroll
@@ -150,21 +155,29 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
     unsigned tapbit = 1u;                                           // 0 once past the last K step
     unsigned ksoff = 0;
     bool live = true;
+    bool phase2 = a.nsteps_main == 0;                             // (never true at start: nsteps_main >= 1)
     int ld_step = 0;
     auto advance = [&]() {
         ++ld_step;
         live = ld_step < nsteps;
         ksoff = live ? ksoff + BK * ES : 0u;
-        ++u_tap; ++u_dx;
-        tapoff += dx_bytes;
-        const bool wrapx = u_dx == ksz;
-        u_dx = wrapx ? 0 : u_dx;
-        tapoff += wrapx ? dy_bytes : 0;
-        const bool wrapt = u_tap == ntaps;
-        u_tap = wrapt ? 0 : u_tap;
-        u_slab += wrapt ? BK * ES : 0;
-        tapoff = wrapt ? u_slab : tapoff;
-        tapbit = live ? (1u << u_tap) : 0u;
+        const bool now2 = ld_step >= a.nsteps_main;               // past the main convolution: shortcut slabs
+        if (!now2) {
+            ++u_tap; ++u_dx;
+            tapoff += dx_bytes;
+            const bool wrapx = u_dx == ksz;
+            u_dx = wrapx ? 0 : u_dx;
+            tapoff += wrapx ? dy_bytes : 0;
+            const bool wrapt = u_tap == ntaps;
+            u_tap = wrapt ? 0 : u_tap;
+            u_slab += wrapt ? BK * ES : 0;
+            tapoff = wrapt ? u_slab : tapoff;
+            tapbit = live ? (1u << u_tap) : 0u;
+        } else {
+            tapoff = phase2 ? tapoff + BK * ES : 0;               // plain channel slabs of the second source
+            tapbit = live ? 0x80000000u : 0u;                     // valid wherever the output pixel exists
+        }
+        phase2 = now2;
     };
     // one LDS-DMA instruction of the stage being loaded: g < NXI activation rows, else weight rows.
     // Past the last K step every offset is out of range (zero fill, no memory traffic); the SGPR offset is
@@ -173,8 +186,13 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
         constexpr int g = decltype(gc)::value;
         char* xs = smem + buf * STAGE;
         if constexpr (g < NXI) {
-            const unsigned voff = (xmask[g] & tapbit) ? (unsigned)(xbase[g] + tapoff) : kOOB;
-            bufload_lds16(xrs, xs + (g * NW + wave) * 1024, voff, 0);
+            if (!phase2) {
+                const unsigned voff = (xmask[g] & tapbit) ? (unsigned)(xbase[g] + tapoff) : kOOB;
+                bufload_lds16(xrs, xs + (g * NW + wave) * 1024, voff, 0);
+            } else {
+                const unsigned voff = (xmask[g] & tapbit) ? (unsigned)(xbase2[g] + tapoff) : kOOB;
+                bufload_lds16(xrs2, xs + (g * NW + wave) * 1024, voff, 0);
+            }
         } else {
             constexpr int j = g - NXI;
             bufload_lds16(wrs, xs + BP * 128 + (j * NW + wave) * 1024, live ? woff[j] : kOOB, ksoff);

@@ -32,6 +32,11 @@ struct ConvKArgs {
     float* unary_out;                 // f32 [B][unary_ch][HoWo]
     unsigned long long* amax_keys;    // u64 [B][n_edges][HoWo], zeroed by the caller
     int unary_ch, window;             // 6K (108), sH*sW (441)
+    // fused 1x1 projection shortcut (ppn_conv_desc.src2): extra K steps gathered from a second tensor
+    const char* src2;                 // NHWC [B][H2][W2][Cin2]
+    int H2, W2, Cin2, stride2;
+    int nsteps_main;                  // K steps of the main convolution; the rest belong to the shortcut
+    unsigned src2_bytes;
 };
 
 template <typename T>

@@ -33,6 +33,7 @@ class ConvDesc(C.Structure):
         ("src", C.c_void_p), ("weight", C.c_void_p), ("scale1", C.c_void_p), ("shift1", C.c_void_p),
         ("residual", C.c_void_p), ("out_raw", C.c_void_p), ("scale2", C.c_void_p), ("shift2", C.c_void_p),
         ("out_act", C.c_void_p), ("zero_page", C.c_void_p),
+        ("src2", C.c_void_p), ("in2_h", C.c_int32), ("in2_w", C.c_int32), ("cin2", C.c_int32), ("stride2", C.c_int32),
         ("unary_out", C.c_void_p), ("argmax_keys", C.c_void_p), ("unary_channels", C.c_int32),
         ("limb_window", C.c_int32),
     ]

@@ -172,6 +172,17 @@ class PoseProposalNet:
             packed = torch.empty(cpad, ktot, dtype=torch.float32 if korder == 2 else tdt, device=dev)
             L.check(lib.ppn_pack_weight(self.compute_dtype, wd.data_ptr(), op.cout, op.cin, op.k, cpad, ktot,
                                         korder, kstep, packed.data_ptr(), stream), "ppn_pack_weight")
+            if op.ds_src:
+                # fused projection shortcut: [main | 1x1 weights * BN scale] per packed row, BN shift -> shift1
+                assert korder == 1 and s1 is None and op.ds_cin % kstep == 0
+                sds, bds = self._fold_bn(op.ds_bn)
+                wds = (self._sd[op.ds_weight].double() * sds.view(-1, 1, 1, 1)).float().contiguous().to(dev)
+                pds = torch.empty(cpad, op.ds_cin, dtype=tdt, device=dev)
+                L.check(lib.ppn_pack_weight(self.compute_dtype, wds.data_ptr(), op.cout, op.ds_cin, 1, cpad,
+                                            op.ds_cin, 1, kstep, pds.data_ptr(), stream), "ppn_pack_weight")
+                packed = torch.cat([packed, pds], dim=1).contiguous()
+                ktot += op.ds_cin
+                self._dev[op.name + ".b1"] = (bds if b1 is None else b1 + bds).float().to(dev)
             self._dev[op.name + ".w"] = packed
             self._dev[op.name + ".geom"] = (ktot, cpad)
         torch.cuda.synchronize(dev)
@@ -236,6 +247,9 @@ class PoseProposalNet:
             d.weight = self._ptr(op.name + ".w")
             d.scale1, d.shift1 = self._ptr(op.name + ".s1"), self._ptr(op.name + ".b1")
             d.residual = bufs[op.residual].data_ptr() if op.residual else None
+            if op.ds_src:
+                sh2, sw2, sc2 = shapes[op.ds_src]
+                d.src2, d.in2_h, d.in2_w, d.cin2, d.stride2 = bufs[op.ds_src].data_ptr(), sh2, sw2, sc2, op.ds_stride
             d.out_raw = bufs[op.out_raw].data_ptr() if (op.out_raw and op.out_raw in bufs) else None
             if fused and op.nchw_f32_out:
                 keys = bufs["keys"]

@@ -19,7 +19,7 @@ def _act(v, a):
 
 
 def run_conv(x, w, dtype, stride=1, dil=1, pad=0, s1=None, b1=None, act1=0, residual=None, s2=None, b2=None, act2=0,
-             want_raw=True, want_act=False, nchw=False):
+             want_raw=True, want_act=False, nchw=False, shortcut=None):
     """x [B,Cin,H,W], w [Cout,Cin,k,k] CPU f32 -> (raw, act) as NCHW CPU f32 tensors via libppn."""
     from pytorch_pose_proposal_network_amd import lib as L
     lib = L.load()
@@ -52,6 +52,19 @@ def run_conv(x, w, dtype, stride=1, dil=1, pad=0, s1=None, b1=None, act1=0, resi
         return t.data_ptr()
 
     d.scale1, d.shift1, d.scale2, d.shift2 = dv(s1), dv(b1), dv(s2), dv(b2)
+    if shortcut is not None:
+        # fused projection shortcut: x2 [B,Cin2,H2,W2], w2 [Cout,Cin2,1,1], stride2 -- extra GEMM depth
+        x2, w2, stride2 = shortcut
+        cin2 = x2.shape[1]
+        assert korder == 1 and cin2 % kstep == 0
+        w2d = w2.contiguous().to(dev)
+        p2 = torch.empty(cpad, cin2, dtype=tdt, device=dev)
+        L.check(lib.ppn_pack_weight(dtype, w2d.data_ptr(), Cout, cin2, 1, cpad, cin2, 1, kstep, p2.data_ptr(), st))
+        packed = torch.cat([packed, p2], dim=1).contiguous()
+        xs2 = x2.permute(0, 2, 3, 1).contiguous().to(dev, tdt)
+        keep += [w2d, packed, xs2]
+        d.weight, d.k_total = packed.data_ptr(), ktot + cin2
+        d.src2, d.in2_h, d.in2_w, d.cin2, d.stride2 = xs2.data_ptr(), x2.shape[2], x2.shape[3], cin2, stride2
     if residual is not None:
         r = residual.permute(0, 2, 3, 1).contiguous().to(dev, tdt)
         keep.append(r)
@@ -231,3 +244,36 @@ def test_stem3x3_dual_output(dtype_name):
     tol = (F32_TOL if dtype == L.PPN_F32 else BF16_TOL) * max(1.0, float(rr.abs().max()))
     assert raw.shape == rr.shape == (2, 32, 19, 35)
     assert float((raw - rr).abs().max()) <= tol and float((act - ra).abs().max()) <= 2 * tol
+
+
+@pytest.mark.parametrize("dtype_name", ["f32", "bf16"])
+@pytest.mark.parametrize("case", [
+    # (B, Cmid, Cin2, Hout, stride2, dil)   main conv: 3x3 Cmid->Cout on [Hout,Hout]; shortcut 1x1 stride2 on x2
+    (2, 128, 64, 24, 2, 1),      # layer4.0: 64 -> 128, stride 2
+    (1, 256, 128, 12, 2, 1),     # layer5.0
+    (2, 512, 256, 9, 1, 2),      # layer6.0: stride 1, dilated main conv, ragged pixel count
+    (1, 128, 192, 7, 2, 1),      # odd source size (H2 = 13), 3 shortcut slabs
+])
+def test_fused_projection_shortcut(dtype_name, case):
+    """conv2 + BasicBlock.downsample (drn.py:53-54) as one GEMM: out = conv3x3(mid) + conv1x1_s(x2) + shift,
+    then the pre-activation second output."""
+    from pytorch_pose_proposal_network_amd import lib as L
+    dtype = L.PPN_F32 if dtype_name == "f32" else L.PPN_BF16
+    B, Cm, C2, Ho, s2, dil = case
+    H2 = Ho * s2 - (1 if s2 == 2 and Ho % 2 else 0)
+    assert (H2 - 1) // s2 + 1 == Ho
+    x = rnd(B, Cm, Ho, Ho, seed=1)
+    w = rnd(Cm, Cm, 3, 3, seed=2, scale=(Cm * 9) ** -0.5)
+    x2 = rnd(B, C2, H2, H2, seed=3)
+    w2 = rnd(Cm, C2, 1, 1, seed=4, scale=C2 ** -0.5)
+    b1, sc2, sh2 = rnd(Cm, seed=5), rnd(Cm, seed=6) + 1.5, rnd(Cm, seed=7)
+    if dtype == L.PPN_BF16:
+        x, w, x2, w2 = (t.to(torch.bfloat16).float() for t in (x, w, x2, w2))
+    raw, act = run_conv(x, w, dtype, 1, dil, dil, b1=b1, s2=sc2, b2=sh2, act2=1, want_act=True,
+                        shortcut=(x2, w2, s2))
+    y = F.conv2d(x.double(), w.double(), None, 1, dil, dil) + F.conv2d(x2.double(), w2.double(), None, s2)
+    y = y + b1.double().view(1, -1, 1, 1)
+    u = torch.relu(y * sc2.double().view(1, -1, 1, 1) + sh2.double().view(1, -1, 1, 1))
+    tol = 2e-5 if dtype == L.PPN_F32 else 2e-2
+    assert (raw.double() - y).abs().max() <= tol * max(1.0, y.abs().max().item())
+    assert (act.double() - u).abs().max() <= tol * max(1.0, u.abs().max().item())
