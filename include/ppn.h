@@ -233,6 +233,125 @@ int ppn_plan_destroy(ppn_plan* p);
 int ppn_pack_weight(int32_t dtype, const float* w, int32_t cout, int32_t cin, int32_t ksize, int32_t cout_pad,
                     int32_t k_total, int32_t k_order, int32_t k_step, void* out, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Training building blocks (main.py:623-777).  Activations are NHWC
+ * [pixels][channels] in `dtype`, channels a multiple of 8 and a power of two <= 2048 (every BN of the
+ * DRN-D / PPN stack); per-channel parameters, statistics and gradients are f32.
+ * ---------------------------------------------------------------------------------------- */
+
+/*
+ * A16: nn.BatchNorm2d in train mode (implicit in model.train(), main.py:643) fused with the activation that
+ * follows it (drn.py:44-51 ReLU, model.py:113-131 LeakyReLU(0.1)):
+ *     mean_c, var_c  = batch statistics over all pixels (biased variance)
+ *     y              = act((x - mean_c) / sqrt(var_c + eps) * gamma_c + beta_c)
+ *     running_mean   = (1-momentum) * running_mean + momentum * mean_c
+ *     running_var    = (1-momentum) * running_var  + momentum * var_c * n/(n-1)
+ * save_mean / save_rstd [C] are kept for the backward; scale / shift [C] are the folded affine
+ * (y = act(x*scale + shift)) a fused consumer can use instead of y.  y, running_*, scale, shift may be NULL.
+ */
+typedef struct ppn_bn_desc {
+    int32_t dtype;
+    int32_t channels;
+    int64_t pixels;
+    int32_t act;                  /* PPN_ACT_NONE / RELU / LRELU(0.1) */
+    float eps, momentum;
+    const void* x;
+    const float* gamma;
+    const float* beta;
+    float* running_mean;
+    float* running_var;
+    float* save_mean;
+    float* save_rstd;
+    float* scale;
+    float* shift;
+    void* y;
+    void* workspace;              /* >= ppn_bn_workspace_bytes(channels) */
+} ppn_bn_desc;
+
+size_t ppn_bn_workspace_bytes(int32_t channels);
+int ppn_bn_train_fwd(const ppn_bn_desc* d, void* stream);
+
+/*
+ * Backward of the same fused BN + activation.  dy is the gradient w.r.t. y; with z = x_hat*gamma + beta,
+ * g = dy * act'(z):   dgamma = sum g*x_hat,  dbeta = sum g,
+ *                     dx = gamma*rstd * (g - dbeta/n - x_hat*dgamma/n)  (+ dx_add, e.g. the skip-path gradient)
+ * dgamma / dbeta are OVERWRITTEN.  dx may alias dy or dx_add.
+ */
+typedef struct ppn_bn_bwd_desc {
+    int32_t dtype;
+    int32_t channels;
+    int64_t pixels;
+    int32_t act;
+    const void* x;
+    const void* dy;
+    const void* dx_add;           /* NULL or [pixels][channels] */
+    const float* gamma;
+    const float* beta;
+    const float* save_mean;
+    const float* save_rstd;
+    float* dgamma;
+    float* dbeta;
+    void* dx;
+    void* workspace;              /* >= ppn_bn_workspace_bytes(channels) */
+} ppn_bn_bwd_desc;
+
+int ppn_bn_train_bwd(const ppn_bn_bwd_desc* d, void* stream);
+
+/*
+ * A15: one torch.optim.Adam step (main.py:278-279: betas (0.9, 0.999), eps 1e-8, weight_decay 0, no amsgrad)
+ * over a flat f32 buffer -- the whole model is one launch.  `step` is the 1-based step count.
+ *     m = b1*m + (1-b1)*g;  v = b2*v + (1-b2)*g*g
+ *     p -= lr/(1-b1^step) * m / (sqrt(v)/sqrt(1-b2^step) + eps)
+ * grad_scale multiplies g first (1/world_size after the SUM all-reduce, main.py:1233-1238).
+ * param_lp (optional) receives the updated parameters rounded to bf16 (the copy the bf16 kernels read).
+ * Hyper-parameters are doubles (Python floats): torch forms 1-beta and the bias corrections in double.
+ */
+int ppn_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, double lr,
+                  double beta1, double beta2, double eps, double weight_decay, int32_t step, float grad_scale,
+                  void* param_lp, void* stream);
+
+/* sum of squares of a f32 buffer, written (not accumulated) to out[0]; deterministic.  n <= 2^31.
+ * workspace >= 1024 doubles.  Building block of G_i = ||d(w_i L_i)/dW||_2 (main.py:704-717). */
+int ppn_sumsq(const float* x, int64_t n, float* out, void* workspace, void* stream);
+
+/*
+ * A13: the task-weight half of the GradNorm step (main.py:717-765), all on device, one launch:
+ *     l_i = w_i*L_i;  G_i = w_i*gnorm_i;  G_avg = mean G;  lhat_i = l_i/base_i;  r_i = lhat_i/mean(lhat)
+ *     C_i = G_avg * r_i^alpha (constant);  Lgrad = sum |G_i - C_i|;  dLgrad/dw_i = sign(G_i - C_i)*gnorm_i
+ *     Adam step on w (optimizerR)
+ * gnorm_i = ||dL_i/dW||_2 for the probe weight W (head conv1.weight).  out5x4 (optional, f32[20]) receives
+ * G, C, dw and [Lgrad, G_avg, 0, 0, 0] for logging / tests.
+ */
+int ppn_gradnorm_weight_step(float* w, const float* losses, const float* gnorm, const float* base, float alpha,
+                             float* exp_avg, float* exp_avg_sq, double lr, double beta1, double beta2, double eps,
+                             int32_t step, float* out5x4, void* stream);
+/* main.py:767-777 after the all-reduce(SUM): w = clamp(w/world, min 0);  w /= mean(w). */
+int ppn_gradnorm_renorm(float* w, int32_t world_size, void* stream);
+
+/*
+ * Convolution weight gradient (autograd of nn.Conv2d inside loss.backward(), main.py:677-683):
+ *     dw[co][ci][ky][kx] = beta*dw + sum_{b,oy,ox} dy[b,oy,ox,co] * x[b, oy*stride+ky*dil-pad, ox*stride+kx*dil-pad, ci]
+ * x, dy NHWC in `dtype` (cin, cout multiples of 8 for bf16 / 4 for f32), dw f32 in the REFERENCE layout
+ * [cout,cin,k,k] (the layout of the flat gradient buffer the all-reduce and Adam work on).  Deterministic.
+ * The input gradient needs no entry point of its own: it is ppn_conv2d_fused on dy with the weights transposed
+ * and flipped (see pytorch_pose_proposal_network_amd/train.py: conv_dgrad).
+ */
+typedef struct ppn_wgrad_desc {
+    int32_t dtype;
+    int32_t batch, in_h, in_w, cin;
+    int32_t out_h, out_w, cout;
+    int32_t ksize, stride, dilation, pad;
+    float beta;                   /* 0: overwrite dw, 1: accumulate into it */
+    const void* x;
+    const void* dy;
+    float* dw;
+    void* workspace;
+    uint64_t workspace_bytes;     /* >= ppn_conv_wgrad_workspace_bytes(desc) */
+} ppn_wgrad_desc;
+
+size_t ppn_conv_wgrad_workspace_bytes(const ppn_wgrad_desc* d);
+int ppn_conv_wgrad(const ppn_wgrad_desc* d, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

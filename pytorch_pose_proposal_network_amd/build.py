@@ -26,6 +26,8 @@ SOURCES = [
     ("stem01.hip", []),
     ("plan.hip", []),
     ("loss.hip", []),
+    ("train.hip", []),
+    ("wgrad.hip", []),
 ]
 
 

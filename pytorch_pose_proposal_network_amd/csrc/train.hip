@@ -1,0 +1,504 @@
+// Training building blocks for gfx950: train-mode BatchNorm (+ fused activation) forward / backward, the fused
+// Adam step, and the task-weight half of GradNorm.  SURVEY section 8 rows A13, A15, A16 (main.py:623-777).
+//
+// All of these are HBM-bound streaming kernels over NHWC [pixels][channels] tensors:
+//   * a thread owns ONE 8-channel chunk column for its whole life (per-channel constants live in registers)
+//     and walks pixel rows; a wave therefore reads whole contiguous rows -> fully coalesced 16/32-byte loads;
+//   * statistics are accumulated in f64 per thread, combined through LDS, written as per-workgroup partials and
+//     folded by a tiny finalize launch in a fixed order -> bitwise reproducible, no atomics;
+//   * algorithmic bytes: BN forward = 2 reads + 1 write of the tensor (statistics pass + apply pass),
+//     BN backward = 2 reads (x, dy) for the reduction + 2..3 reads + 1 write for the apply pass.
+#include "common.h"
+#include "conv_common.h"
+
+namespace {
+
+using ppnconv::load8;
+using ppnconv::store8;
+
+constexpr int kThreads = 256;
+constexpr int kMaxBlocks = 1024;
+
+__device__ __forceinline__ float act_fwd(float z, int act) {
+    if (act == PPN_ACT_RELU) return z > 0.f ? z : 0.f;
+    if (act == PPN_ACT_LRELU) return z > 0.f ? z : 0.1f * z;
+    return z;
+}
+__device__ __forceinline__ float act_slope(float z, int act) {
+    if (act == PPN_ACT_RELU) return z > 0.f ? 1.f : 0.f;
+    if (act == PPN_ACT_LRELU) return z > 0.f ? 1.f : 0.1f;
+    return 1.f;
+}
+
+struct Slab {
+    int cc;          // chunk columns = C/8
+    int rpi;         // pixel rows handled per iteration by one workgroup = 256/cc
+    long long slab;  // pixel rows per workgroup (multiple of rpi)
+    int nblocks;
+};
+
+// ---- per-channel reductions: out[b][c] = {sum f(x), sum h(x)} over the workgroup's pixel slab ------------
+// MODE 0: {x, x*x}            (forward statistics)
+// MODE 1: {g, g*x_hat}        (backward: dbeta, dgamma), g = dy*act'(x*scale+shift)
+template <typename T, int MODE>
+__global__ void __launch_bounds__(kThreads) bn_reduce_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta,
+                                                             const float* __restrict__ mean,
+                                                             const float* __restrict__ rstd, int act, long long P,
+                                                             int C, Slab s, double* __restrict__ partial) {
+    __shared__ double red[kThreads][17];
+    const int t = threadIdx.x;
+    const int col = t % s.cc, roff = t / s.cc;
+    const long long p0 = (long long)blockIdx.x * s.slab;
+    const long long p1 = p0 + s.slab < P ? p0 + s.slab : P;
+    double a[8], b[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = b[j] = 0.0;
+    float sc[8], sh[8], mu[8], rs[8];
+    if (MODE == 1) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = col * 8 + j;
+            mu[j] = mean[c];
+            rs[j] = rstd[c];
+            sc[j] = gamma[c] * rs[j];
+            sh[j] = beta[c] - mu[j] * sc[j];
+        }
+    }
+    const size_t row_bytes = (size_t)C * sizeof(T);
+    const char* xb = reinterpret_cast<const char*>(x) + (size_t)col * 8 * sizeof(T);
+    const char* db = reinterpret_cast<const char*>(dy) + (size_t)col * 8 * sizeof(T);
+    for (long long p = p0 + roff; p < p1; p += s.rpi) {
+        float v[8];
+        load8<T>(xb + p * row_bytes, v);
+        if (MODE == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const double d = (double)v[j];
+                a[j] += d;
+                b[j] += d * d;
+            }
+        } else {
+            float g[8];
+            load8<T>(db + p * row_bytes, g);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float z = v[j] * sc[j] + sh[j];
+                const float gg = g[j] * act_slope(z, act);
+                const float xh = (v[j] - mu[j]) * rs[j];
+                a[j] += (double)gg;
+                b[j] += (double)gg * (double)xh;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        red[t][j] = a[j];
+        red[t][8 + j] = b[j];
+    }
+    __syncthreads();
+    // thread (col, j) folds the rpi row-threads of its column in a fixed order
+    for (int o = t; o < s.cc * 16; o += kThreads) {
+        const int c_ = o / 16, j = o % 16;
+        double acc = 0.0;
+        for (int r = 0; r < s.rpi; ++r) acc += red[r * s.cc + c_][j];
+        const int c = c_ * 8 + (j & 7);
+        partial[((size_t)blockIdx.x * C + c) * 2 + (j >> 3)] = acc;
+    }
+}
+
+// forward finalize: mean / rstd / folded affine / running statistics
+__global__ void bn_fwd_finalize_kernel(const double* __restrict__ partial, int nblocks, int C, long long P,
+                                       const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                       float momentum, float* __restrict__ running_mean,
+                                       float* __restrict__ running_var, float* __restrict__ save_mean,
+                                       float* __restrict__ save_rstd, float* __restrict__ scale,
+                                       float* __restrict__ shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double S = 0.0, Q = 0.0;
+    for (int b = 0; b < nblocks; ++b) {
+        S += partial[((size_t)b * C + c) * 2];
+        Q += partial[((size_t)b * C + c) * 2 + 1];
+    }
+    const double n = (double)P;
+    const double m = S / n;
+    double var = Q / n - m * m;
+    var = var > 0.0 ? var : 0.0;
+    const float mf = (float)m, vf = (float)var;
+    const float r = 1.0f / sqrtf(vf + eps);
+    save_mean[c] = mf;
+    save_rstd[c] = r;
+    if (scale) {
+        const float sc = gamma[c] * r;
+        scale[c] = sc;
+        shift[c] = beta[c] - mf * sc;
+    }
+    if (running_mean) {
+        const float unbiased = (float)(var * (n / (n > 1.0 ? n - 1.0 : 1.0)));
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mf;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kThreads) bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta,
+                                                            const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, int act, long long P,
+                                                            int C, Slab s, T* __restrict__ y) {
+    const int t = threadIdx.x;
+    const int col = t % s.cc, roff = t / s.cc;
+    const long long p0 = (long long)blockIdx.x * s.slab;
+    const long long p1 = p0 + s.slab < P ? p0 + s.slab : P;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = col * 8 + j;
+        sc[j] = gamma[c] * rstd[c];
+        sh[j] = beta[c] - mean[c] * sc[j];
+    }
+    const size_t row_bytes = (size_t)C * sizeof(T);
+    const char* xb = reinterpret_cast<const char*>(x) + (size_t)col * 8 * sizeof(T);
+    char* yb = reinterpret_cast<char*>(y) + (size_t)col * 8 * sizeof(T);
+    for (long long p = p0 + roff; p < p1; p += s.rpi) {
+        float v[8];
+        load8<T>(xb + p * row_bytes, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = act_fwd(v[j] * sc[j] + sh[j], act);
+        store8<T>(yb + p * row_bytes, v);
+    }
+}
+
+// backward finalize: dgamma, dbeta and the three per-channel coefficients of  dx = ca*g + cb*x + cc
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ partial, int nblocks, int C, long long P,
+                                       const float* __restrict__ gamma, const float* __restrict__ mean,
+                                       const float* __restrict__ rstd, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta, float* __restrict__ coef) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double db = 0.0, dg = 0.0;
+    for (int b = 0; b < nblocks; ++b) {
+        db += partial[((size_t)b * C + c) * 2];
+        dg += partial[((size_t)b * C + c) * 2 + 1];
+    }
+    dgamma[c] = (float)dg;
+    dbeta[c] = (float)db;
+    const double n = (double)P, g = gamma[c], r = rstd[c], m = mean[c];
+    coef[c] = (float)(g * r);
+    coef[C + c] = (float)(-g * r * r * dg / n);
+    coef[2 * C + c] = (float)(g * r * (m * r * dg - db) / n);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kThreads) bn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                                const T* __restrict__ add,
+                                                                const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta,
+                                                                const float* __restrict__ mean,
+                                                                const float* __restrict__ rstd,
+                                                                const float* __restrict__ coef, int act,
+                                                                long long P, int C, Slab s, T* __restrict__ dx) {
+    const int t = threadIdx.x;
+    const int col = t % s.cc, roff = t / s.cc;
+    const long long p0 = (long long)blockIdx.x * s.slab;
+    const long long p1 = p0 + s.slab < P ? p0 + s.slab : P;
+    float sc[8], sh[8], ca[8], cb[8], cc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = col * 8 + j;
+        sc[j] = gamma[c] * rstd[c];
+        sh[j] = beta[c] - mean[c] * sc[j];
+        ca[j] = coef[c];
+        cb[j] = coef[C + c];
+        cc[j] = coef[2 * C + c];
+    }
+    const size_t row_bytes = (size_t)C * sizeof(T);
+    const size_t cofs = (size_t)col * 8 * sizeof(T);
+    const char* xb = reinterpret_cast<const char*>(x) + cofs;
+    const char* db = reinterpret_cast<const char*>(dy) + cofs;
+    const char* ab = add ? reinterpret_cast<const char*>(add) + cofs : nullptr;
+    char* ob = reinterpret_cast<char*>(dx) + cofs;
+    for (long long p = p0 + roff; p < p1; p += s.rpi) {
+        float v[8], g[8], o[8];
+        load8<T>(xb + p * row_bytes, v);
+        load8<T>(db + p * row_bytes, g);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float z = v[j] * sc[j] + sh[j];
+            o[j] = ca[j] * (g[j] * act_slope(z, act)) + cb[j] * v[j] + cc[j];
+        }
+        if (ab) {
+            float r[8];
+            load8<T>(ab + p * row_bytes, r);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] += r[j];
+        }
+        store8<T>(ob + p * row_bytes, o);
+    }
+}
+
+// ---- Adam ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kThreads) adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                        float* __restrict__ m, float* __restrict__ v, long long n,
+                                                        float omb1, float b2, float omb2, float eps, float wd,
+                                                        float step_size, float inv_bc2_sqrt, float gscale,
+                                                        __bf16* __restrict__ lp) {
+    const long long stride = (long long)gridDim.x * kThreads;
+    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
+        float gi = g[i] * gscale;
+        const float pi = p[i];
+        if (wd != 0.f) gi += wd * pi;
+        const float mi = m[i] + (gi - m[i]) * omb1;                  // exp_avg.lerp_(grad, 1 - beta1)
+        const float vi = v[i] * b2 + omb2 * gi * gi;                 // mul_(beta2).addcmul_(g, g, 1 - beta2)
+        const float denom = sqrtf(vi) * inv_bc2_sqrt + eps;
+        const float po = pi - step_size * (mi / denom);
+        m[i] = mi;
+        v[i] = vi;
+        p[i] = po;
+        if (lp) lp[i] = (__bf16)po;
+    }
+}
+
+// ---- sum of squares -----------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kThreads) sumsq_partial_kernel(const float* __restrict__ x, long long n,
+                                                                 double* __restrict__ partial) {
+    __shared__ double red[kThreads];
+    double acc = 0.0;
+    const long long stride = (long long)gridDim.x * kThreads;
+    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
+        const double d = (double)x[i];
+        acc += d * d;
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = kThreads / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+__global__ void sumsq_final_kernel(const double* __restrict__ partial, int nb, float* __restrict__ out) {
+    double acc = 0.0;
+    for (int b = 0; b < nb; ++b) acc += partial[b];
+    out[0] = (float)acc;
+}
+
+// ---- GradNorm task weights (5 scalars, one lane) ------------------------------------------------------------
+__global__ void gradnorm_kernel(float* __restrict__ w, const float* __restrict__ L, const float* __restrict__ gn,
+                                const float* __restrict__ base, float alpha, float* __restrict__ m,
+                                float* __restrict__ v, float omb1, float b2, float omb2, float eps,
+                                float step_size, float inv_bc2_sqrt, float* __restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float l[5], G[5], lhat[5], Cc[5], dw[5];
+    float gsum = 0.f, lsum = 0.f;
+    for (int i = 0; i < 5; ++i) {
+        l[i] = w[i] * L[i];                          // main.py:668-672
+        G[i] = fabsf(w[i]) * gn[i];                  // ||d(w_i L_i)/dW||_2, main.py:704-721
+    }
+    gsum = (((G[0] + G[1]) + G[2]) + G[3]) + G[4];
+    const float gavg = gsum / 5.f;                   // main.py:723
+    for (int i = 0; i < 5; ++i) lhat[i] = l[i] / base[i];
+    lsum = (((lhat[0] + lhat[1]) + lhat[2]) + lhat[3]) + lhat[4];
+    const float lavg = lsum / 5.f;                   // main.py:732
+    float lgrad = 0.f;
+    for (int i = 0; i < 5; ++i) {
+        Cc[i] = gavg * powf(lhat[i] / lavg, alpha);  // main.py:735-746, detached
+        const float d = G[i] - Cc[i];
+        lgrad += fabsf(d);                           // nn.L1Loss on scalars
+        const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+        const float sw = w[i] > 0.f ? 1.f : (w[i] < 0.f ? -1.f : 0.f);
+        dw[i] = sgn * sw * gn[i];
+    }
+    for (int i = 0; i < 5; ++i) {                    // optimizerR.step(): Adam on the 5 weights
+        const float mi = m[i] + (dw[i] - m[i]) * omb1;
+        const float vi = v[i] * b2 + omb2 * dw[i] * dw[i];
+        m[i] = mi;
+        v[i] = vi;
+        w[i] = w[i] - step_size * (mi / (sqrtf(vi) * inv_bc2_sqrt + eps));
+    }
+    if (out) {
+        for (int i = 0; i < 5; ++i) {
+            out[i] = G[i];
+            out[5 + i] = Cc[i];
+            out[10 + i] = dw[i];
+            out[15 + i] = 0.f;
+        }
+        out[15] = lgrad;
+        out[16] = gavg;
+    }
+}
+
+__global__ void gradnorm_renorm_kernel(float* __restrict__ w, float world) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float t[5], s = 0.f;
+    for (int i = 0; i < 5; ++i) {
+        t[i] = w[i] / world;
+        t[i] = t[i] < 0.f ? 0.f : t[i];              // clamp_(min=0.0)
+    }
+    s = (((t[0] + t[1]) + t[2]) + t[3]) + t[4];
+    const float mean = s / 5.f;
+    for (int i = 0; i < 5; ++i) w[i] = t[i] / mean;
+}
+
+int make_slab(int C, long long P, Slab* s) {
+    if (C < 8 || C > 2048 || (C & (C - 1)) != 0)
+        return ppn::fail(PPN_E_UNSUPPORTED, "BatchNorm channels must be a power of two in [8, 2048], got %d", C);
+    if (P <= 0) return ppn::fail(PPN_E_INVALID, "BatchNorm needs pixels > 0");
+    s->cc = C / 8;
+    s->rpi = kThreads / s->cc;
+    const long long rows_iter = s->rpi;
+    long long nb = (P + rows_iter * 8 - 1) / (rows_iter * 8);        // >= 8 rows per thread when possible
+    if (nb > kMaxBlocks) nb = kMaxBlocks;
+    if (nb < 1) nb = 1;
+    long long slab = (P + nb - 1) / nb;
+    slab = (slab + rows_iter - 1) / rows_iter * rows_iter;
+    s->slab = slab;
+    s->nblocks = (int)((P + slab - 1) / slab);
+    return PPN_OK;
+}
+
+void adam_consts(double lr, double b1, double b2, int step, float* step_size, float* inv_bc2_sqrt) {
+    const double bc1 = 1.0 - pow(b1, (double)step);
+    const double bc2 = 1.0 - pow(b2, (double)step);
+    *step_size = (float)(lr / bc1);
+    *inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t ppn_bn_workspace_bytes(int32_t channels) {
+    if (channels <= 0) return 0;
+    return (size_t)kMaxBlocks * channels * 2 * sizeof(double) + (size_t)3 * channels * sizeof(float);
+}
+
+int ppn_bn_train_fwd(const ppn_bn_desc* d, void* stream) {
+    if (!d || !d->x || !d->gamma || !d->beta || !d->save_mean || !d->save_rstd || !d->workspace)
+        return ppn::fail(PPN_E_INVALID, "ppn_bn_train_fwd: x, gamma, beta, save_mean, save_rstd, workspace required");
+    if ((d->scale == nullptr) != (d->shift == nullptr) || (d->running_mean == nullptr) != (d->running_var == nullptr))
+        return ppn::fail(PPN_E_INVALID, "ppn_bn_train_fwd: scale/shift and running_mean/var come in pairs");
+    if (d->dtype != PPN_F32 && d->dtype != PPN_BF16) return ppn::fail(PPN_E_INVALID, "bad dtype %d", d->dtype);
+    if (d->act < PPN_ACT_NONE || d->act > PPN_ACT_LRELU) return ppn::fail(PPN_E_UNSUPPORTED, "bad act %d", d->act);
+    Slab s;
+    if (int rc = make_slab(d->channels, d->pixels, &s)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    double* partial = reinterpret_cast<double*>(d->workspace);
+    const int C = d->channels;
+    if (d->dtype == PPN_F32)
+        bn_reduce_kernel<float, 0><<<s.nblocks, kThreads, 0, st>>>((const float*)d->x, nullptr, nullptr, nullptr,
+                                                                   nullptr, nullptr, 0, d->pixels, C, s, partial);
+    else
+        bn_reduce_kernel<__bf16, 0><<<s.nblocks, kThreads, 0, st>>>((const __bf16*)d->x, nullptr, nullptr, nullptr,
+                                                                    nullptr, nullptr, 0, d->pixels, C, s, partial);
+    PPN_LAUNCH_CHECK();
+    bn_fwd_finalize_kernel<<<(C + 63) / 64, 64, 0, st>>>(partial, s.nblocks, C, d->pixels, d->gamma, d->beta, d->eps,
+                                                         d->momentum, d->running_mean, d->running_var, d->save_mean,
+                                                         d->save_rstd, d->scale, d->shift);
+    PPN_LAUNCH_CHECK();
+    if (d->y) {
+        if (d->dtype == PPN_F32)
+            bn_apply_kernel<float><<<s.nblocks, kThreads, 0, st>>>((const float*)d->x, d->gamma, d->beta, d->save_mean,
+                                                                   d->save_rstd, d->act, d->pixels, C, s,
+                                                                   (float*)d->y);
+        else
+            bn_apply_kernel<__bf16><<<s.nblocks, kThreads, 0, st>>>((const __bf16*)d->x, d->gamma, d->beta,
+                                                                    d->save_mean, d->save_rstd, d->act, d->pixels, C,
+                                                                    s, (__bf16*)d->y);
+        PPN_LAUNCH_CHECK();
+    }
+    return PPN_OK;
+}
+
+int ppn_bn_train_bwd(const ppn_bn_bwd_desc* d, void* stream) {
+    if (!d || !d->x || !d->dy || !d->gamma || !d->beta || !d->save_mean || !d->save_rstd || !d->dgamma ||
+        !d->dbeta || !d->dx || !d->workspace)
+        return ppn::fail(PPN_E_INVALID, "ppn_bn_train_bwd: NULL argument");
+    if (d->dtype != PPN_F32 && d->dtype != PPN_BF16) return ppn::fail(PPN_E_INVALID, "bad dtype %d", d->dtype);
+    if (d->act < PPN_ACT_NONE || d->act > PPN_ACT_LRELU) return ppn::fail(PPN_E_UNSUPPORTED, "bad act %d", d->act);
+    Slab s;
+    if (int rc = make_slab(d->channels, d->pixels, &s)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const int C = d->channels;
+    double* partial = reinterpret_cast<double*>(d->workspace);
+    float* coef = reinterpret_cast<float*>(reinterpret_cast<char*>(d->workspace) +
+                                           (size_t)kMaxBlocks * C * 2 * sizeof(double));
+    if (d->dtype == PPN_F32)
+        bn_reduce_kernel<float, 1><<<s.nblocks, kThreads, 0, st>>>((const float*)d->x, (const float*)d->dy, d->gamma,
+                                                                   d->beta, d->save_mean, d->save_rstd, d->act,
+                                                                   d->pixels, C, s, partial);
+    else
+        bn_reduce_kernel<__bf16, 1><<<s.nblocks, kThreads, 0, st>>>((const __bf16*)d->x, (const __bf16*)d->dy,
+                                                                    d->gamma, d->beta, d->save_mean, d->save_rstd,
+                                                                    d->act, d->pixels, C, s, partial);
+    PPN_LAUNCH_CHECK();
+    bn_bwd_finalize_kernel<<<(C + 63) / 64, 64, 0, st>>>(partial, s.nblocks, C, d->pixels, d->gamma, d->save_mean,
+                                                         d->save_rstd, d->dgamma, d->dbeta, coef);
+    PPN_LAUNCH_CHECK();
+    if (d->dtype == PPN_F32)
+        bn_bwd_apply_kernel<float><<<s.nblocks, kThreads, 0, st>>>(
+            (const float*)d->x, (const float*)d->dy, (const float*)d->dx_add, d->gamma, d->beta, d->save_mean,
+            d->save_rstd, coef, d->act, d->pixels, C, s, (float*)d->dx);
+    else
+        bn_bwd_apply_kernel<__bf16><<<s.nblocks, kThreads, 0, st>>>(
+            (const __bf16*)d->x, (const __bf16*)d->dy, (const __bf16*)d->dx_add, d->gamma, d->beta, d->save_mean,
+            d->save_rstd, coef, d->act, d->pixels, C, s, (__bf16*)d->dx);
+    PPN_LAUNCH_CHECK();
+    return PPN_OK;
+}
+
+int ppn_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, double lr,
+                  double beta1, double beta2, double eps, double weight_decay, int32_t step, float grad_scale,
+                  void* param_lp, void* stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || n < 0 || step < 1)
+        return ppn::fail(PPN_E_INVALID, "ppn_adam_step: NULL buffer, n < 0 or step < 1");
+    if (n == 0) return PPN_OK;
+    float step_size, inv_bc2_sqrt;
+    adam_consts(lr, beta1, beta2, step, &step_size, &inv_bc2_sqrt);
+    long long blocks = (n + kThreads - 1) / kThreads;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    // 1 - beta is formed in double from the caller's value, as torch does, then rounded once
+    adam_kernel<<<(int)blocks, kThreads, 0, (hipStream_t)stream>>>(
+        param, grad, exp_avg, exp_avg_sq, n, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps,
+        (float)weight_decay, step_size, inv_bc2_sqrt, grad_scale, (__bf16*)param_lp);
+    PPN_LAUNCH_CHECK();
+    return PPN_OK;
+}
+
+int ppn_sumsq(const float* x, int64_t n, float* out, void* workspace, void* stream) {
+    if (!x || !out || !workspace || n < 0) return ppn::fail(PPN_E_INVALID, "ppn_sumsq: NULL argument");
+    long long blocks = (n + kThreads * 8 - 1) / (kThreads * 8);
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    hipStream_t st = (hipStream_t)stream;
+    sumsq_partial_kernel<<<(int)blocks, kThreads, 0, st>>>(x, n, (double*)workspace);
+    PPN_LAUNCH_CHECK();
+    sumsq_final_kernel<<<1, 1, 0, st>>>((const double*)workspace, (int)blocks, out);
+    PPN_LAUNCH_CHECK();
+    return PPN_OK;
+}
+
+int ppn_gradnorm_weight_step(float* w, const float* losses, const float* gnorm, const float* base, float alpha,
+                             float* exp_avg, float* exp_avg_sq, double lr, double beta1, double beta2, double eps,
+                             int32_t step, float* out5x4, void* stream) {
+    if (!w || !losses || !gnorm || !base || !exp_avg || !exp_avg_sq || step < 1)
+        return ppn::fail(PPN_E_INVALID, "ppn_gradnorm_weight_step: NULL argument or step < 1");
+    float step_size, inv_bc2_sqrt;
+    adam_consts(lr, beta1, beta2, step, &step_size, &inv_bc2_sqrt);
+    gradnorm_kernel<<<1, 64, 0, (hipStream_t)stream>>>(w, losses, gnorm, base, alpha, exp_avg, exp_avg_sq,
+                                                       (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2),
+                                                       (float)eps, step_size, inv_bc2_sqrt, out5x4);
+    PPN_LAUNCH_CHECK();
+    return PPN_OK;
+}
+
+int ppn_gradnorm_renorm(float* w, int32_t world_size, void* stream) {
+    if (!w || world_size < 1) return ppn::fail(PPN_E_INVALID, "ppn_gradnorm_renorm: NULL w or world_size < 1");
+    gradnorm_renorm_kernel<<<1, 64, 0, (hipStream_t)stream>>>(w, (float)world_size);
+    PPN_LAUNCH_CHECK();
+    return PPN_OK;
+}
+
+}  // extern "C"

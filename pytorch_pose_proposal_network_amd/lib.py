@@ -43,6 +43,26 @@ class LossCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("K", "E", "sH", "sW", "H", "W", "inH", "inW")]
 
 
+class BnDesc(C.Structure):
+    _fields_ = [("dtype", C.c_int32), ("channels", C.c_int32), ("pixels", C.c_int64), ("act", C.c_int32),
+                ("eps", C.c_float), ("momentum", C.c_float)] + [
+        (n, C.c_void_p) for n in ("x", "gamma", "beta", "running_mean", "running_var", "save_mean", "save_rstd",
+                                  "scale", "shift", "y", "workspace")]
+
+
+class BnBwdDesc(C.Structure):
+    _fields_ = [("dtype", C.c_int32), ("channels", C.c_int32), ("pixels", C.c_int64), ("act", C.c_int32)] + [
+        (n, C.c_void_p) for n in ("x", "dy", "dx_add", "gamma", "beta", "save_mean", "save_rstd", "dgamma", "dbeta",
+                                  "dx", "workspace")]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("dtype", "batch", "in_h", "in_w", "cin", "out_h", "out_w", "cout", "ksize",
+                                         "stride", "dilation", "pad")] + [
+        ("beta", C.c_float), ("x", C.c_void_p), ("dy", C.c_void_p), ("dw", C.c_void_p), ("workspace", C.c_void_p),
+        ("workspace_bytes", C.c_uint64)]
+
+
 class PPNError(RuntimeError):
     pass
 
@@ -86,6 +106,21 @@ _SIGNATURES = {
     "ppn_pack_weight": (C.c_int, [C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                   C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
 }
+
+_SIGNATURES.update({
+    "ppn_bn_workspace_bytes": (C.c_size_t, [C.c_int32]),
+    "ppn_bn_train_fwd": (C.c_int, [C.POINTER(BnDesc), C.c_void_p]),
+    "ppn_bn_train_bwd": (C.c_int, [C.POINTER(BnBwdDesc), C.c_void_p]),
+    "ppn_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double,
+                                C.c_double, C.c_double, C.c_double, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
+    "ppn_sumsq": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ppn_gradnorm_weight_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,
+                                           C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32,
+                                           C.c_void_p, C.c_void_p]),
+    "ppn_gradnorm_renorm": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "ppn_conv_wgrad_workspace_bytes": (C.c_size_t, [C.POINTER(WgradDesc)]),
+    "ppn_conv_wgrad": (C.c_int, [C.POINTER(WgradDesc), C.c_void_p]),
+})
 
 EXPORTS = tuple(_SIGNATURES)
 

@@ -1,0 +1,198 @@
+"""GPU parity of the training building blocks against plain PyTorch-CPU ops (what the reference's autograd /
+torch.optim.Adam / nn.BatchNorm2d execute: main.py:278-279, 643, 664-777)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _act(t, a):
+    return {"none": lambda v: v, "relu": F.relu, "lrelu": lambda v: F.leaky_relu(v, 0.1)}[a](t)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape,act", [((2, 24, 24, 16), "relu"), ((3, 12, 12, 512), "lrelu"),
+                                        ((2, 7, 5, 64), "none"), ((1, 3, 3, 2048), "relu"),
+                                        ((4, 96, 96, 32), "relu")])
+def test_bn_train_forward_backward(dtype, shape, act):
+    from pytorch_pose_proposal_network_amd import train as T
+    g = torch.Generator().manual_seed(11)
+    c = shape[-1]
+    x = (torch.randn(*shape, generator=g) * 1.7 + 0.6).to(dtype)
+    gamma = torch.rand(c, generator=g) + 0.5
+    beta = torch.randn(c, generator=g) * 0.3
+    rm, rv = torch.randn(c, generator=g) * 0.1, torch.rand(c, generator=g) + 0.5
+    dy = torch.randn(*shape, generator=g).to(dtype)
+    skip = torch.randn(*shape, generator=g).to(dtype)
+
+    # reference: nn.BatchNorm2d semantics in f64 on the (already rounded) inputs
+    xr = x.double().permute(0, 3, 1, 2).requires_grad_(True)
+    gr, br = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    rm_r, rv_r = rm.double().clone(), rv.double().clone()
+    z = F.batch_norm(xr, rm_r, rv_r, gr, br, True, 0.1, 1e-5)
+    yr = _act(z, act)
+    yr.backward(dy.double().permute(0, 3, 1, 2))
+    dx_ref = xr.grad.permute(0, 2, 3, 1) + skip.double()
+
+    dev = torch.device("cuda")
+    rm_d, rv_d = rm.to(dev), rv.to(dev)
+    xd, gd, bd = x.to(dev), gamma.to(dev), beta.to(dev)
+    y, saved = T.bn_train_forward(xd, gd, bd, rm_d, rv_d, act=act)
+    dx, dgamma, dbeta = T.bn_train_backward(xd, dy.to(dev), gd, bd, saved, act=act, dx_add=skip.to(dev))
+    torch.cuda.synchronize()
+
+    lo = dtype == torch.bfloat16
+    n = x.numel() // c
+    assert torch.allclose(saved.mean.cpu().double(), x.double().reshape(-1, c).mean(0), atol=2e-6, rtol=1e-6)
+    assert torch.allclose(rm_d.cpu().double(), rm_r, atol=2e-6, rtol=1e-6)
+    assert torch.allclose(rv_d.cpu().double(), rv_r, atol=1e-6, rtol=3e-6)
+    tol = 2e-2 if lo else 2e-5
+    yref = yr.detach().permute(0, 2, 3, 1)
+    assert (y.cpu().double() - yref).abs().max() <= tol * max(1.0, yref.abs().max().item())
+    # parameter gradients are f32 sums of n terms
+    scale = max(1.0, n ** 0.5)
+    assert (dgamma.cpu().double() - gr.grad).abs().max() <= (3e-2 if lo else 2e-5) * scale
+    assert (dbeta.cpu().double() - br.grad).abs().max() <= (3e-2 if lo else 2e-5) * scale
+    assert (dx.cpu().double() - dx_ref).abs().max() <= (6e-2 if lo else 5e-5) * max(1.0, dx_ref.abs().max().item())
+
+
+def test_bn_rejects_bad_shapes():
+    from pytorch_pose_proposal_network_amd import train as T, lib as L
+    dev = torch.device("cuda")
+    x = torch.zeros(2, 4, 4, 24, device=dev)           # 24 channels: not a power of two
+    with pytest.raises(L.PPNError):
+        T.bn_train_forward(x, torch.ones(24, device=dev), torch.zeros(24, device=dev))
+
+
+@pytest.mark.parametrize("n", [5, 1000, 128 * 128 * 9 + 3, 4_000_037])
+def test_flat_adam_matches_torch(n):
+    from pytorch_pose_proposal_network_amd import train as T
+    g = torch.Generator().manual_seed(n)
+    p0 = torch.randn(n, generator=g)
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([ref], lr=7e-4)              # train.sh:5
+    dev = torch.device("cuda")
+    pd = p0.to(dev)
+    lp = torch.empty(n, dtype=torch.bfloat16, device=dev)
+    mine = T.FlatAdam(pd, lr=7e-4, param_lp=lp)
+    for it in range(4):
+        grad = torch.randn(n, generator=g) * (10.0 ** (it - 2))
+        ref.grad = grad.clone() / 2                      # world_size 2: SUM all-reduce then /world
+        opt.step()
+        mine.step(grad.to(dev), grad_scale=0.5)
+    torch.cuda.synchronize()
+    assert torch.allclose(pd.cpu(), ref.detach(), rtol=2e-6, atol=2e-7)
+    st = opt.state[ref]
+    assert torch.allclose(mine.exp_avg.cpu(), st["exp_avg"], rtol=2e-6, atol=1e-9)
+    assert torch.allclose(mine.exp_avg_sq.cpu(), st["exp_avg_sq"], rtol=2e-6, atol=1e-12)
+    assert torch.equal(lp.cpu(), pd.cpu().to(torch.bfloat16))
+
+
+def test_sumsq():
+    from pytorch_pose_proposal_network_amd import train as T
+    x = torch.randn(128 * 128 * 9, generator=torch.Generator().manual_seed(3))
+    out = T.sumsq(x.cuda()).cpu().item()
+    assert abs(out - (x.double() ** 2).sum().item()) <= 1e-6 * out
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_gradnorm_weight_step_matches_autograd(seed):
+    """main.py:668-777 restated with torch autograd on 5 scalars: l_i = w_i L_i, G_i = ||w_i g_i||, C_i detached,
+    Lgrad = sum L1(G_i, C_i), Adam on w, clamp, renormalise."""
+    from pytorch_pose_proposal_network_amd import train as T
+    g = torch.Generator().manual_seed(seed)
+    losses = torch.rand(5, generator=g) * 3 + 0.1
+    base = torch.rand(5, generator=g) * 3 + 0.1
+    gvec = [torch.randn(64, generator=g) * (0.2 + i) for i in range(5)]     # dL_i/dW stand-ins
+    alpha, lr = 0.12, 0.025
+    wm = torch.nn.Linear(5, 1, bias=False)
+    wm.weight.data.fill_(1.0)
+    if seed == 2:
+        wm.weight.data = torch.tensor([[1.3, 0.4, 1.1, 0.9, 1.3]])
+    opt = torch.optim.Adam(wm.parameters(), lr=lr)
+    dev = torch.device("cuda")
+    mine = T.GradNormWeights(dev, lr=lr, alpha=alpha)
+    mine.w.copy_(wm.weight.data[0])
+    for it in range(3):
+        l = [wm.weight[0][i] * losses[i] for i in range(5)]
+        G = [torch.norm(wm.weight[0][i] * gvec[i], 2) for i in range(5)]
+        G_avg = sum(G) / 5
+        lhat = [l[i] / base[i] for i in range(5)]
+        lhat_avg = sum(lhat) / 5
+        Cc = [(G_avg * (lhat[i] / lhat_avg) ** alpha).detach() for i in range(5)]
+        opt.zero_grad()
+        Lgrad = sum(F.l1_loss(G[i], Cc[i]) for i in range(5))
+        Lgrad.backward()
+        opt.step()
+        with torch.no_grad():
+            wm.weight.clamp_(min=0.0)
+            wm.weight.div_(torch.mean(wm.weight))
+        gn = torch.stack([torch.norm(v, 2) for v in gvec])
+        log = mine.step(losses.to(dev), gn.to(dev), base.to(dev)).cpu()
+        assert torch.allclose(log[0:5], torch.stack(G).detach(), rtol=1e-5)
+        assert torch.allclose(log[5:10], torch.stack(Cc), rtol=1e-5)
+        assert abs(log[15].item() - Lgrad.item()) <= 1e-5 * max(1.0, abs(Lgrad.item()))
+        assert torch.allclose(mine.w.cpu(), wm.weight.data[0], rtol=2e-5, atol=1e-6)
+        losses = losses * 0.9 + torch.rand(5, generator=g) * 0.1
+
+
+CONV_CASES = [
+    # (B, Cin, Cout, H, k, stride, dil, pad)
+    (2, 64, 64, 12, 3, 1, 1, 1),
+    (2, 128, 256, 9, 3, 1, 2, 2),         # dilated, ragged pixel count, two cout tiles
+    (1, 512, 128, 6, 1, 1, 1, 0),         # 1x1 neck conv
+    (2, 64, 128, 16, 3, 2, 1, 1),         # strided 3x3 (layer4.0.conv1)
+    (2, 64, 128, 16, 1, 2, 1, 0),         # strided 1x1 projection shortcut
+    (1, 160, 72, 7, 3, 1, 4, 4),          # channel counts that are not tile multiples; dilation > image/2
+    (3, 32, 64, 20, 3, 2, 1, 1),          # layer3.0.conv1: 32 input channels
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_wgrad(dtype, case):
+    from pytorch_pose_proposal_network_amd import train as T
+    B, ci, co, H, k, s, dil, pad = case
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, H, H, ci, generator=g).to(dtype)
+    eff = dil * (k - 1) + 1
+    Ho = (H + 2 * pad - eff) // s + 1
+    dy = torch.randn(B, Ho, Ho, co, generator=g).to(dtype)
+    w = torch.zeros(co, ci, k, k, dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(x.double().permute(0, 3, 1, 2), w, None, s, pad, dil)
+    y.backward(dy.double().permute(0, 3, 1, 2))
+    dev = torch.device("cuda")
+    pre = torch.full((co, ci, k, k), 0.5, device=dev)
+    dw = T.conv_wgrad(x.to(dev), dy.to(dev), k, s, dil, pad)
+    dw2 = T.conv_wgrad(x.to(dev), dy.to(dev), k, s, dil, pad, out=pre, accumulate=True)
+    torch.cuda.synchronize()
+    # inputs are already rounded, products are exact in f32, only the f32 accumulation order differs
+    tol = 3e-5 * (B * Ho * Ho) ** 0.5
+    assert (dw.cpu().double() - w.grad).abs().max() <= tol
+    assert (dw2.cpu().double() - 0.5 - w.grad).abs().max() <= tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", CONV_CASES[:5] + [(1, 64, 64, 11, 3, 2, 1, 1)])
+def test_conv_dgrad(dtype, case):
+    from pytorch_pose_proposal_network_amd import train as T
+    B, ci, co, H, k, s, dil, pad = case
+    g = torch.Generator().manual_seed(6)
+    eff = dil * (k - 1) + 1
+    Ho = (H + 2 * pad - eff) // s + 1
+    w = (torch.randn(co, ci, k, k, generator=g) * (ci * k * k) ** -0.5)
+    if dtype == torch.bfloat16:
+        w = w.to(dtype).float()
+    dy = torch.randn(B, Ho, Ho, co, generator=g).to(dtype)
+    skip = torch.randn(B, H, H, ci, generator=g).to(dtype)
+    x = torch.zeros(B, ci, H, H, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x, w.double(), None, s, pad, dil).backward(dy.double().permute(0, 3, 1, 2))
+    ref = x.grad.permute(0, 2, 3, 1) + skip.double()
+    dev = torch.device("cuda")
+    dx = T.conv_dgrad(dy.to(dev), w.to(dev), (H, H), s, dil, pad, add=skip.to(dev))
+    torch.cuda.synchronize()
+    tol = 2e-2 if dtype == torch.bfloat16 else 3e-5
+    assert dx.shape == ref.shape
+    assert (dx.cpu().double() - ref).abs().max() <= tol * max(1.0, ref.abs().max().item())
