@@ -186,7 +186,8 @@ int ppn_conv2d_fused(const ppn_conv_desc* d, void* stream);
  * rt_test.py:97-101 / aug.py:149-153 fused into the load.
  *   src      u8  [B,H,W,3]  RGB frame (src_is_u8=1): (x-mean_c)/std_c applied on the fly, or
  *            f32 [B,3,H,W]  already normalised NCHW input, the model.forward() argument (src_is_u8=0)
- *   weight   f32 [16,3,7,7] (reference layout, device), scale/shift f32[16] folded BN (device)
+ *   weight   f32 [16,3,7,7] (reference layout, device), scale/shift f32[16] folded BN (device); both NULL =
+ *            train mode: the plain convolution output is written (no affine, no ReLU)
  *   mean,std_ HOST pointers to 3 floats (read at call time; may be NULL when src_is_u8=0)
  *   out      NHWC [B,H,W,16] dtype
  */
@@ -296,6 +297,20 @@ typedef struct ppn_bn_bwd_desc {
 } ppn_bn_bwd_desc;
 
 int ppn_bn_train_bwd(const ppn_bn_bwd_desc* d, void* stream);
+
+/* out[c] = sum over pixels of x[p][c] (NHWC, channels a power of two in [8,2048]); the bias gradient of a
+ * convolution whose output gradient is x (model.py:91 conv2.bias).  workspace >= ppn_bn_workspace_bytes(channels). */
+int ppn_colsum(int32_t dtype, const void* x, int64_t pixels, int32_t channels, float* out, void* workspace,
+               void* stream);
+
+/*
+ * Backward through the head's sigmoid (model.py:134) + relayout for the conv3 backward kernels:
+ *     dz[b][hw][c] = grad_head[b][c][hw] * s*(1-s),  s = head[b][c][hw]          (NCHW f32 -> NHWC `dtype`)
+ * dz has channels_pad (multiple of 64 >= channels) channels, the padding is written as zeros;
+ * dbias (optional, f32[channels]) = sum over b,hw of the same quantity = d/d(conv3.bias).
+ */
+int ppn_head_grad(int32_t dtype, const float* head, const float* grad_head, int32_t batch, int32_t channels,
+                  int32_t hw, int32_t channels_pad, void* dz, float* dbias, void* stream);
 
 /*
  * A15: one torch.optim.Adam step (main.py:278-279: betas (0.9, 0.999), eps 1e-8, weight_decay 0, no amsgrad)

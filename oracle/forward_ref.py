@@ -82,7 +82,7 @@ class _Net:
 
 
 def forward_ref(sd, x: torch.Tensor, arch: str = "drn_d_22", train_bn: bool = False, momentum: float = 0.1,
-                taps=None) -> torch.Tensor:
+                taps=None, grad: bool = False) -> torch.Tensor:
     """x: f32[B,3,H,W] normalised input -> sigmoid head f32[B,C,H/16,W/16].
 
     `taps`, if a dict, receives named intermediate tensors (for bisecting, fixture G2).
@@ -93,7 +93,8 @@ def forward_ref(sd, x: torch.Tensor, arch: str = "drn_d_22", train_bn: bool = Fa
     exp = 1 if block == "basic" else 4
     channels = (16, 32, 64, 128, 256, 512, 512, 512)
     net = _Net(sd, train_bn, momentum)
-    with torch.no_grad():
+    # grad=True keeps the autograd graph (oracle/train_ref.py differentiates this very function)
+    with (torch.enable_grad() if grad else torch.no_grad()):
         def tap(name, v):
             if taps is not None:
                 taps[name] = v

@@ -401,9 +401,11 @@ int ppn::conv_launch(const ppn_conv_desc* d, hipStream_t st, const char** kname)
     if (oh != d->out_h || ow != d->out_w)
         return ppn::fail(PPN_E_INVALID, "out size %dx%d inconsistent with %dx%d", d->out_h, d->out_w, oh, ow);
     if (ppn::stem3x3_supported(d->cin, d->cout, d->ksize, d->stride, d->dilation, d->pad) && d->k_total == 144 &&
-        d->cout_pad == d->cout && !d->residual && !d->out_nchw_f32 && d->act1 == PPN_ACT_RELU &&
+        d->cout_pad == d->cout && !d->residual && !d->out_nchw_f32 &&
+        ((d->act1 == PPN_ACT_RELU && d->scale1 && d->shift1) ||
+         (d->act1 == PPN_ACT_NONE && !d->scale1 && !d->shift1 && !d->out_act)) &&
         (!d->out_act || d->act2 == PPN_ACT_RELU)) {
-        if (!d->src || !d->weight || !d->scale1 || !d->shift1) return ppn::fail(PPN_E_INVALID, "NULL src/weight/scale");
+        if (!d->src || !d->weight) return ppn::fail(PPN_E_INVALID, "NULL src/weight");
         if (oh != d->out_h || ow != d->out_w) return ppn::fail(PPN_E_INVALID, "inconsistent output size");
         return ppn::stem3x3_launch(d->dtype, d->src, d->batch, d->in_h, d->in_w, d->cout, d->stride,
                                    static_cast<const float*>(d->weight), d->scale1, d->shift1, d->scale2, d->shift2,

@@ -72,8 +72,9 @@ __global__ void __launch_bounds__(256) stem7x7_kernel(StemArgs a) {
         for (int t = 0; t < 49; ++t) wf[t] = (g < 3) ? wc[g * 49 + t] : 0.f;
     }
     float sc[4], sh[4];
+    const bool raw = a.scale == nullptr;          // train mode: plain convolution output, BN runs on batch statistics
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { sc[r] = a.scale[4 * g + r]; sh[r] = a.shift[4 * g + r]; }
+    for (int r = 0; r < 4; ++r) { sc[r] = raw ? 1.f : a.scale[4 * g + r]; sh[r] = raw ? 0.f : a.shift[4 * g + r]; }
     // ---- persistent loop over tiles: the weight-fragment set-up above is paid once per workgroup ----------
     const int col = lane & 15;
     const int ntiles = a.tiles_x * a.tiles_y * a.B;
@@ -145,7 +146,7 @@ __global__ void __launch_bounds__(256) stem7x7_kernel(StemArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float t = acc[r] * sc[r] + sh[r];
-                v[r] = t > 0.f ? t : 0.f;                                  // BN + ReLU (drn.py:126-127)
+                v[r] = (t > 0.f || raw) ? t : 0.f;                         // BN + ReLU (drn.py:126-127)
             }
             const size_t o = (((size_t)b * a.H + gy) * a.W + gx) * CO + 4 * g;
             if (BF) {
@@ -168,7 +169,7 @@ int stem_launch(int dtype, int src_is_u8, const void* src, int batch, int h, int
                 const float* scale, const float* shift, const float* mean, const float* stdv, void* out,
                 hipStream_t st) {
     if (dtype != PPN_F32 && dtype != PPN_BF16) return fail(PPN_E_INVALID, "bad dtype %d", dtype);
-    if (!src || !weight || !scale || !shift || !out || batch < 1 || h < 1 || w < 1)
+    if (!src || !weight || (scale == nullptr) != (shift == nullptr) || !out || batch < 1 || h < 1 || w < 1)
         return fail(PPN_E_INVALID, "ppn_stem7x7: bad arguments");
     if (src_is_u8 && (!mean || !stdv)) return fail(PPN_E_INVALID, "ppn_stem7x7: mean/std required for u8 input");
     StemArgs a;

@@ -78,12 +78,13 @@ __global__ void __launch_bounds__(256) stem3x3_kernel(Stem3Args a) {
         }
     }
     float s1[NCT][4], b1[NCT][4], s2[NCT][4], b2[NCT][4];
+    const bool raw = a.scale1 == nullptr;         // train mode / input gradient: plain convolution output
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int c = ct * 16 + 4 * g + r;
-            s1[ct][r] = a.scale1[c]; b1[ct][r] = a.shift1[c];
+            s1[ct][r] = a.scale1 ? a.scale1[c] : 1.f; b1[ct][r] = a.scale1 ? a.shift1[c] : 0.f;
             s2[ct][r] = a.scale2 ? a.scale2[c] : 1.f; b2[ct][r] = a.shift2 ? a.shift2[c] : 0.f;
         }
     // ---- persistent loop over output tiles: the fragment set-up above is paid once per workgroup ----------
@@ -163,7 +164,7 @@ __global__ void __launch_bounds__(256) stem3x3_kernel(Stem3Args a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float t = acc[ct][r] * s1[ct][r] + b1[ct][r];
-                    v[r] = t > 0.f ? t : 0.f;                        // BN + ReLU (drn.py:198-200)
+                    v[r] = (t > 0.f || raw) ? t : 0.f;               // BN + ReLU (drn.py:198-200)
                     const float w2 = v[r] * s2[ct][r] + b2[ct][r];
                     u[r] = w2 > 0.f ? w2 : 0.f;                      // next block's relu(bn1(x)) (drn.py:45-46)
                 }
@@ -213,7 +214,8 @@ bool stem3x3_supported(int cin, int cout, int ksize, int stride, int dilation, i
 int stem3x3_launch(int dtype, const void* src, int batch, int h, int w, int cout, int stride, const float* weight,
                    const float* scale1, const float* shift1, const float* scale2, const float* shift2, void* out_raw,
                    void* out_act, hipStream_t st, const char** kname) {
-    if (!src || !weight || !scale1 || !shift1 || (!out_raw && !out_act) || batch < 1 || h < 1 || w < 1)
+    if (!src || !weight || (scale1 == nullptr) != (shift1 == nullptr) || (!out_raw && !out_act) || batch < 1 ||
+        h < 1 || w < 1)
         return fail(PPN_E_INVALID, "stem3x3: bad arguments");
     Stem3Args a;
     a.src = src; a.weight = weight; a.scale1 = scale1; a.shift1 = shift1; a.scale2 = scale2; a.shift2 = shift2;

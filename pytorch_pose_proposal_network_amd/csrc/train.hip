@@ -342,6 +342,72 @@ __global__ void gradnorm_renorm_kernel(float* __restrict__ w, float world) {
     for (int i = 0; i < 5; ++i) w[i] = t[i] / mean;
 }
 
+
+// ---- column sums (bias gradient of a convolution that feeds NHWC) ----------------------------------------------
+__global__ void colsum_finalize_kernel(const double* __restrict__ partial, int nblocks, int C, float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double S = 0.0;
+    for (int b = 0; b < nblocks; ++b) S += partial[((size_t)b * C + c) * 2];
+    out[c] = (float)S;
+}
+
+// ---- head: gradient through the sigmoid + NCHW f32 -> NHWC relayout ---------------------------------------------
+// dz[b][hw][c] = g[b][c][hw] * s*(1-s),  s = head[b][c][hw]   (channels c >= C of the padded output are zero)
+template <typename T>
+__global__ void __launch_bounds__(256) head_grad_kernel(const float* __restrict__ head, const float* __restrict__ grad,
+                                                        int C, int HW, int Cpad, T* __restrict__ dz) {
+    __shared__ float tile[64][65];
+    const int c0 = blockIdx.x * 64, p0 = blockIdx.y * 64, b = blockIdx.z;
+    const int t = threadIdx.x;
+    const int px = t & 63;
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {
+        const int cl = (t >> 6) + 4 * i;
+        const int c = c0 + cl, p = p0 + px;
+        float v = 0.f;
+        if (c < C && p < HW) {
+            const size_t o = ((size_t)b * C + c) * HW + p;
+            const float sg = head[o];
+            v = grad[o] * (sg * (1.f - sg));
+        }
+        tile[px][cl] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int item = t + 256 * i;
+        const int pr = item >> 3, ch = item & 7;
+        const int p = p0 + pr;
+        if (p < HW && c0 + ch * 8 < Cpad) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = tile[pr][ch * 8 + j];
+            store8<T>(reinterpret_cast<char*>(dz) + (((size_t)b * HW + p) * Cpad + c0 + ch * 8) * sizeof(T), v);
+        }
+    }
+}
+
+// dbias[c] = sum_{b,hw} g*s*(1-s): one wave per channel, fixed order
+__global__ void __launch_bounds__(256) head_bias_grad_kernel(const float* __restrict__ head,
+                                                             const float* __restrict__ grad, int B, int C, int HW,
+                                                             float* __restrict__ dbias) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (c >= C) return;
+    double acc = 0.0;
+    for (int b = 0; b < B; ++b) {
+        const size_t o = ((size_t)b * C + c) * HW;
+        for (int p = lane; p < HW; p += 64) {
+            const float sg = head[o + p];
+            acc += (double)(grad[o + p] * (sg * (1.f - sg)));
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (lane == 0) dbias[c] = (float)acc;
+}
+
 int make_slab(int C, long long P, Slab* s) {
     if (C < 8 || C > 2048 || (C & (C - 1)) != 0)
         return ppn::fail(PPN_E_UNSUPPORTED, "BatchNorm channels must be a power of two in [8, 2048], got %d", C);
@@ -446,6 +512,46 @@ int ppn_bn_train_bwd(const ppn_bn_bwd_desc* d, void* stream) {
             (const __bf16*)d->x, (const __bf16*)d->dy, (const __bf16*)d->dx_add, d->gamma, d->beta, d->save_mean,
             d->save_rstd, coef, d->act, d->pixels, C, s, (__bf16*)d->dx);
     PPN_LAUNCH_CHECK();
+    return PPN_OK;
+}
+
+int ppn_colsum(int32_t dtype, const void* x, int64_t pixels, int32_t channels, float* out, void* workspace,
+               void* stream) {
+    if (!x || !out || !workspace) return ppn::fail(PPN_E_INVALID, "ppn_colsum: NULL argument");
+    if (dtype != PPN_F32 && dtype != PPN_BF16) return ppn::fail(PPN_E_INVALID, "bad dtype %d", dtype);
+    Slab s;
+    if (int rc = make_slab(channels, pixels, &s)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    double* partial = reinterpret_cast<double*>(workspace);
+    if (dtype == PPN_F32)
+        bn_reduce_kernel<float, 0><<<s.nblocks, kThreads, 0, st>>>((const float*)x, nullptr, nullptr, nullptr, nullptr,
+                                                                   nullptr, 0, pixels, channels, s, partial);
+    else
+        bn_reduce_kernel<__bf16, 0><<<s.nblocks, kThreads, 0, st>>>((const __bf16*)x, nullptr, nullptr, nullptr,
+                                                                    nullptr, nullptr, 0, pixels, channels, s, partial);
+    PPN_LAUNCH_CHECK();
+    colsum_finalize_kernel<<<(channels + 63) / 64, 64, 0, st>>>(partial, s.nblocks, channels, out);
+    PPN_LAUNCH_CHECK();
+    return PPN_OK;
+}
+
+int ppn_head_grad(int32_t dtype, const float* head, const float* grad_head, int32_t batch, int32_t channels,
+                  int32_t hw, int32_t channels_pad, void* dz, float* dbias, void* stream) {
+    if (!head || !grad_head || !dz) return ppn::fail(PPN_E_INVALID, "ppn_head_grad: NULL argument");
+    if (dtype != PPN_F32 && dtype != PPN_BF16) return ppn::fail(PPN_E_INVALID, "bad dtype %d", dtype);
+    if (batch < 1 || channels < 1 || hw < 1 || channels_pad < channels || channels_pad % 64)
+        return ppn::fail(PPN_E_INVALID, "ppn_head_grad: channels_pad must be a multiple of 64 >= channels");
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(channels_pad / 64, (hw + 63) / 64, batch);
+    if (dtype == PPN_F32)
+        head_grad_kernel<float><<<grid, 256, 0, st>>>(head, grad_head, channels, hw, channels_pad, (float*)dz);
+    else
+        head_grad_kernel<__bf16><<<grid, 256, 0, st>>>(head, grad_head, channels, hw, channels_pad, (__bf16*)dz);
+    PPN_LAUNCH_CHECK();
+    if (dbias) {
+        head_bias_grad_kernel<<<(channels + 3) / 4, 256, 0, st>>>(head, grad_head, batch, channels, hw, dbias);
+        PPN_LAUNCH_CHECK();
+    }
     return PPN_OK;
 }
 

@@ -11,6 +11,7 @@ LIB_PATH = os.environ.get("PPN_LIB", os.path.join(_HERE, "csrc", "libppn.so"))  
 PPN_MAX_EDGES = 32
 PPN_MAX_KP = 32
 PPN_F32, PPN_BF16 = 0, 1
+PPN_ACT_NONE, PPN_ACT_RELU, PPN_ACT_LRELU, PPN_ACT_SIGMOID = 0, 1, 2, 3
 
 
 class DecodeCfg(C.Structure):
@@ -118,6 +119,9 @@ _SIGNATURES.update({
                                            C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32,
                                            C.c_void_p, C.c_void_p]),
     "ppn_gradnorm_renorm": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "ppn_colsum": (C.c_int, [C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ppn_head_grad": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                C.c_void_p, C.c_void_p, C.c_void_p]),
     "ppn_conv_wgrad_workspace_bytes": (C.c_size_t, [C.POINTER(WgradDesc)]),
     "ppn_conv_wgrad": (C.c_int, [C.POINTER(WgradDesc), C.c_void_p]),
 })

@@ -201,7 +201,8 @@ class GradNormWeights:
 # ---- convolution forward / input gradient / weight gradient on NHWC tensors -------------------------------------
 
 def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, stride: int = 1, dilation: int = 1, pad: int = 0,
-                add: Optional[torch.Tensor] = None) -> torch.Tensor:
+                add: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None, act: int = 0,
+                nchw_f32: bool = False) -> torch.Tensor:
     """Raw convolution (no folded BN: train mode keeps BN separate) of an NHWC tensor with a reference-layout
     f32 weight [cout,cin,k,k] on the device, + `add` (NHWC, the residual).  Packs the weight for the MFMA
     kernels on the fly: in training the weights change every step anyway."""
@@ -218,14 +219,19 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, stride: int = 1, dilation: int
     packed = torch.empty(cpad, ktot, dtype=torch.float32 if korder == 2 else x.dtype, device=x.device)
     L.check(lib.ppn_pack_weight(dt, w.data_ptr(), cout, cin, k, cpad, ktot, korder, kstep, packed.data_ptr(), st),
             "ppn_pack_weight")
-    out = torch.empty(B, Ho, Wo, cout, dtype=x.dtype, device=x.device)
+    if nchw_f32:                                  # the head tensor the loss / decode kernels read (model.py:134-136)
+        out = torch.empty(B, cout, Ho, Wo, dtype=torch.float32, device=x.device)
+    else:
+        out = torch.empty(B, Ho, Wo, cout, dtype=x.dtype, device=x.device)
     zero = _zero_page(x.device)
     d = L.ConvDesc()
     d.dtype, d.batch, d.in_h, d.in_w, d.cin = dt, B, H, W, cin
     d.out_h, d.out_w, d.cout = Ho, Wo, cout
     d.ksize, d.stride, d.dilation, d.pad = k, stride, dilation, pad
-    d.k_total, d.cout_pad = ktot, cpad
+    d.k_total, d.cout_pad, d.act1, d.out_nchw_f32 = ktot, cpad, act, 1 if nchw_f32 else 0
     d.src, d.weight, d.zero_page, d.out_raw = x.data_ptr(), packed.data_ptr(), zero.data_ptr(), out.data_ptr()
+    if bias is not None:
+        d.shift1 = _f32(bias, cout, "bias")       # v = act(conv + bias)
     if add is not None:
         if add.shape != out.shape or add.dtype != x.dtype or not add.is_contiguous():
             raise ValueError("conv2d_nhwc: `add` must match the output")

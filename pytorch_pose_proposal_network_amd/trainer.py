@@ -1,0 +1,283 @@
+"""Training step of the Pose Proposal Network on one MI355X (main.py:623-777).
+
+`PPNTrainer` keeps every parameter of the reference's PoseProposalNet(arch) in ONE flat f32 buffer (in
+`model.named_parameters()` order, so `params[-13]` is the head's conv1.weight as in main.py:704) with a matching
+flat gradient buffer: the data-parallel exchange is a single RCCL all-reduce and the optimiser a single launch.
+Forward and backward are explicit: a tape of saved activations per unit (arch._units), train-mode BatchNorm with
+batch statistics (train.py / csrc/train.hip), convolutions, input gradients and weight gradients on the MFMA
+kernels (csrc/conv*.hip, csrc/wgrad.hip), the loss and its gradient from csrc/loss.hip.  There is no autograd and
+no CPU path.
+
+One iteration (main.py:664-777):
+    head              = forward(x)                                  train-mode BN, running stats updated
+    L_i, dhead        = PPNLoss fwd+bwd with coeff w_i/5            loss = sum w_i L_i / 5
+    grad              = backward(dhead)                             d loss / d theta
+    gnorm_i           = ||d L_i / d W||, W = head conv1.weight      5 partial backward passes (head only)
+    w                <- GradNorm weight step (Adam), all-reduce, clamp, renormalise
+    grad             <- all-reduce(grad) / world;  theta <- Adam(theta, grad)
+
+Deviation from the reference, stated plainly: main.py:759 back-propagates Lgrad through the graph of the G_i
+(create_graph=True), which adds d Lgrad / d theta -- a second-order term -- to the model gradients.  This
+trainer applies the first-order gradient d loss / d theta only; the task-weight update (which needs no second
+order) is exact.  DESIGN.md lists the term as the next training item.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import arch as A
+from . import config as cfg
+from . import lib as L
+from . import train as T
+from .loss import PPNLoss
+
+_BUFFER_SUFFIXES = (".running_mean", ".running_var", ".num_batches_tracked")
+
+
+class PPNTrainer:
+    def __init__(self, arch: str = "drn_d_22", state_dict: Optional[Dict] = None, compute_dtype: int = L.PPN_BF16,
+                 lr: float = 7e-4, lr_weights: float = 0.025, alpha: float = 0.12, insize=(384, 384),
+                 device="cuda"):
+        L.load()                                               # fail loudly without libppn.so
+        if A.DRN_D[arch][0] != "basic":
+            raise NotImplementedError("training is implemented for the BasicBlock DRN-D variants (22/24/38/40)")
+        self.arch, self.compute_dtype, self.device = arch, compute_dtype, torch.device(device)
+        self.tdt = torch.float32 if compute_dtype == L.PPN_F32 else torch.bfloat16
+        self.units = A._units(arch)
+        self.insize = insize
+        spec = A.param_spec(arch)
+        self.param_names = [n for n, _ in spec if not n.endswith(_BUFFER_SUFFIXES)]
+        shapes = dict(spec)
+        n_total = sum(int(np.prod(shapes[n])) for n in self.param_names)
+        self.flat = torch.zeros(n_total, dtype=torch.float32, device=self.device)
+        self.grad = torch.zeros(n_total, dtype=torch.float32, device=self.device)
+        self.P: Dict[str, torch.Tensor] = {}
+        self.G: Dict[str, torch.Tensor] = {}
+        o = 0
+        for n in self.param_names:
+            k = int(np.prod(shapes[n]))
+            self.P[n] = self.flat[o:o + k].view(shapes[n])
+            self.G[n] = self.grad[o:o + k].view(shapes[n])
+            o += k
+        self.buffers: Dict[str, torch.Tensor] = {}
+        for n, shp in spec:
+            if n.endswith((".running_mean", ".running_var")):
+                self.buffers[n] = torch.zeros(shp, dtype=torch.float32, device=self.device)
+                if n.endswith("var"):
+                    self.buffers[n].fill_(1.0)
+        self.num_batches_tracked = 0
+        if state_dict is not None:
+            self.load_state_dict(state_dict)
+        self.opt = T.FlatAdam(self.flat, lr=lr)                               # optimizerM, main.py:278
+        self.task = T.GradNormWeights(self.device, lr=lr_weights, alpha=alpha)  # weight_model + optimizerR
+        self.criterion = PPNLoss(insize=insize, outsize=(insize[0] // 16, insize[1] // 16))
+        self.base: Optional[torch.Tensor] = None
+        self._tape = None
+
+    # ---- state ------------------------------------------------------------------------------------------------
+    def load_state_dict(self, sd):
+        for n in self.param_names:
+            v = sd[n] if n in sd else sd["module." + n]
+            self.P[n].copy_(torch.as_tensor(np.asarray(v) if not isinstance(v, torch.Tensor) else v).float())
+        for n, b in self.buffers.items():
+            v = sd.get(n, sd.get("module." + n))
+            if v is not None:
+                b.copy_(torch.as_tensor(np.asarray(v) if not isinstance(v, torch.Tensor) else v).float())
+
+    def state_dict(self):
+        """Checkpoint-compatible dict (main.py:1175-1181 'state_dict' entry)."""
+        sd = {n: self.P[n].detach().clone() for n in self.param_names}
+        for n, b in self.buffers.items():
+            sd[n] = b.clone()
+            if n.endswith(".running_var"):
+                sd[n[:-len("running_var")] + "num_batches_tracked"] = torch.tensor(self.num_batches_tracked)
+        return sd
+
+    # ---- small helpers ------------------------------------------------------------------------------------------
+    def _bn(self, x, prefix, act):
+        y, saved = T.bn_train_forward(x, self.P[prefix + ".weight"], self.P[prefix + ".bias"],
+                                      self.buffers[prefix + ".running_mean"], self.buffers[prefix + ".running_var"],
+                                      act=act)
+        return y, saved
+
+    def _bn_bwd(self, x, dy, prefix, act, saved, dx_add=None, keep=True):
+        dx, dg, db = T.bn_train_backward(x, dy, self.P[prefix + ".weight"], self.P[prefix + ".bias"], saved, act=act,
+                                         dx_add=dx_add)
+        if keep:
+            self.G[prefix + ".weight"].copy_(dg)
+            self.G[prefix + ".bias"].copy_(db)
+        return dx
+
+    def _wgrad(self, name, x, dy, k, stride=1, dil=1, pad=0):
+        T.conv_wgrad(x, dy, k, stride, dil, pad, out=self.G[name])
+
+    # ---- forward -------------------------------------------------------------------------------------------------
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """x f32 [B,3,H,W] normalised (the model.forward argument) -> head f32 [B,7605,H/16,W/16]; train-mode BN."""
+        lib = L.load()
+        if x.dtype != torch.float32 or x.dim() != 4 or x.shape[1] != 3 or not x.is_cuda:
+            raise ValueError("x must be a float32 [B,3,H,W] device tensor")
+        x = x.contiguous()
+        B, _, H, W = x.shape
+        tape = []
+        # the 7x7 stem reads NCHW f32; its weight gradient reads an 8-channel NHWC copy (channels 3..7 zero)
+        xin8 = torch.zeros(B, H, W, 8, dtype=self.tdt, device=self.device)
+        xin8[..., :3] = x.permute(0, 2, 3, 1)
+        cur = None
+        for u in self.units:
+            if u.kind == "cbr":
+                wn = f"{u.prefix}.{u.conv_idx}.weight"
+                bnp = f"{u.prefix}.{u.conv_idx + 1}"
+                d = u.dil[0]
+                if u.k == 7:
+                    y = torch.empty(B, H, W, u.cout, dtype=self.tdt, device=self.device)
+                    L.check(lib.ppn_stem7x7(self.compute_dtype, 0, x.data_ptr(), B, H, W, self.P[wn].data_ptr(), None,
+                                            None, None, None, y.data_ptr(), L.current_stream_ptr()), "ppn_stem7x7")
+                    src = xin8
+                else:
+                    src = cur
+                    y = T.conv2d_nhwc(cur, self.P[wn], u.stride, d, d)
+                z, saved = self._bn(y, bnp, "relu")
+                tape.append(("cbr", u, dict(x=src, y=y, saved=saved)))
+                cur = z
+            elif u.kind == "basic":
+                p = u.prefix
+                a, s1 = self._bn(cur, p + ".bn1", "relu")
+                c1 = T.conv2d_nhwc(a, self.P[p + ".conv1.weight"], u.stride, u.dil[0], u.dil[0])
+                b, s2 = self._bn(c1, p + ".bn2", "relu")
+                ctx = dict(x=cur, a=a, s1=s1, c1=c1, b=b, s2=s2)
+                if u.downsample:
+                    dsy = T.conv2d_nhwc(cur, self.P[p + ".downsample.0.weight"], u.stride, 1, 0)
+                    r, s3 = self._bn(dsy, p + ".downsample.1", "none")
+                    ctx.update(dsy=dsy, s3=s3)
+                else:
+                    r = cur
+                out = T.conv2d_nhwc(b, self.P[p + ".conv2.weight"], 1, u.dil[1], u.dil[1], add=r)
+                tape.append(("basic", u, ctx))
+                cur = out
+            else:                                                     # PPN head, model.py:113-136
+                R = cur
+                h0, s0 = self._bn(R, "bn0_1", "lrelu")
+                a1 = T.conv2d_nhwc(h0, self.P["conv1x1_1.weight"])
+                h1, s1 = self._bn(a1, "bn1", "lrelu")
+                a2 = T.conv2d_nhwc(h1, self.P["conv1.weight"], 1, 1, 1)
+                h2, s2 = self._bn(a2, "bn0_2", "lrelu")
+                a3 = T.conv2d_nhwc(h2, self.P["conv1x1_2.weight"], add=R)
+                c2 = T.conv2d_nhwc(a3, self.P["conv2.weight"], 1, 1, 1, bias=self.P["conv2.bias"])
+                h3, s3 = self._bn(c2, "bn2", "lrelu")
+                head = T.conv2d_nhwc(h3, self.P["conv3.weight"], bias=self.P["conv3.bias"], act=L.PPN_ACT_SIGMOID,
+                                     nchw_f32=True)
+                tape.append(("head", u, dict(R=R, h0=h0, s0=s0, a1=a1, h1=h1, s1=s1, a2=a2, h2=h2, s2=s2, a3=a3,
+                                             c2=c2, h3=h3, s3=s3, head=head)))
+                cur = head
+        self.num_batches_tracked += 1
+        self._tape = tape
+        return cur
+
+    # ---- backward ------------------------------------------------------------------------------------------------
+    def _head_backward(self, c, grad_head, probe_only: bool):
+        """Backward of the head unit.  probe_only: stop at conv1.weight and return its gradient (GradNorm)."""
+        lib = L.load()
+        keep = not probe_only
+        head = c["head"]
+        B, Ch, Ho, Wo = head.shape
+        cpad = (Ch + 63) // 64 * 64
+        dz = torch.empty(B, Ho, Wo, cpad, dtype=self.tdt, device=self.device)
+        dbias3 = self.G["conv3.bias"] if keep else None
+        L.check(lib.ppn_head_grad(self.compute_dtype, head.data_ptr(), grad_head.data_ptr(), B, Ch, Ho * Wo, cpad,
+                                  dz.data_ptr(), dbias3.data_ptr() if keep else None, L.current_stream_ptr()),
+                "ppn_head_grad")
+        w3 = self.P["conv3.weight"]
+        w3p = torch.zeros(cpad, w3.shape[1], 1, 1, dtype=torch.float32, device=self.device)
+        w3p[:Ch] = w3
+        if keep:
+            dw3 = T.conv_wgrad(c["h3"], dz, 1)
+            self.G["conv3.weight"].copy_(dw3[:Ch])
+        dh3 = T.conv_dgrad(dz, w3p, (Ho, Wo))
+        dc2 = self._bn_bwd(c["c2"], dh3, "bn2", "lrelu", c["s3"], keep=keep)
+        if keep:
+            ws = T._workspace(dc2.shape[-1], self.device)
+            L.check(lib.ppn_colsum(self.compute_dtype, dc2.data_ptr(), dc2.numel() // dc2.shape[-1], dc2.shape[-1],
+                                   self.G["conv2.bias"].data_ptr(), ws.data_ptr(), L.current_stream_ptr()),
+                    "ppn_colsum")
+            self._wgrad("conv2.weight", c["a3"], dc2, 3, 1, 1, 1)
+        da3 = T.conv_dgrad(dc2, self.P["conv2.weight"], (Ho, Wo), 1, 1, 1)
+        if keep:
+            self._wgrad("conv1x1_2.weight", c["h2"], da3, 1)
+        dh2 = T.conv_dgrad(da3, self.P["conv1x1_2.weight"], (Ho, Wo))
+        da2 = self._bn_bwd(c["a2"], dh2, "bn0_2", "lrelu", c["s2"], keep=keep)
+        if probe_only:
+            return T.conv_wgrad(c["h1"], da2, 3, 1, 1, 1)
+        self._wgrad("conv1.weight", c["h1"], da2, 3, 1, 1, 1)
+        dh1 = T.conv_dgrad(da2, self.P["conv1.weight"], (Ho, Wo), 1, 1, 1)
+        da1 = self._bn_bwd(c["a1"], dh1, "bn1", "lrelu", c["s1"])
+        self._wgrad("conv1x1_1.weight", c["h0"], da1, 1)
+        dh0 = T.conv_dgrad(da1, self.P["conv1x1_1.weight"], (Ho, Wo))
+        return self._bn_bwd(c["R"], dh0, "bn0_1", "lrelu", c["s0"], dx_add=da3)
+
+    def backward(self, grad_head: torch.Tensor):
+        """d(sum_i coeff_i L_i)/d(theta) into self.grad, given d/d(head) from the loss kernel."""
+        if self._tape is None:
+            raise RuntimeError("backward() needs a forward() first")
+        g = grad_head
+        for kind, u, c in reversed(self._tape):
+            if kind == "head":
+                g = self._head_backward(c, g, probe_only=False)
+            elif kind == "basic":
+                p = u.prefix
+                hw = c["x"].shape[1:3]
+                self._wgrad(p + ".conv2.weight", c["b"], g, 3, 1, u.dil[1], u.dil[1])
+                db = T.conv_dgrad(g, self.P[p + ".conv2.weight"], c["b"].shape[1:3], 1, u.dil[1], u.dil[1])
+                dc1 = self._bn_bwd(c["c1"], db, p + ".bn2", "relu", c["s2"])
+                self._wgrad(p + ".conv1.weight", c["a"], dc1, 3, u.stride, u.dil[0], u.dil[0])
+                da = T.conv_dgrad(dc1, self.P[p + ".conv1.weight"], hw, u.stride, u.dil[0], u.dil[0])
+                if u.downsample:
+                    dds = self._bn_bwd(c["dsy"], g, p + ".downsample.1", "none", c["s3"])
+                    self._wgrad(p + ".downsample.0.weight", c["x"], dds, 1, u.stride, 1, 0)
+                    dxr = T.conv_dgrad(dds, self.P[p + ".downsample.0.weight"], hw, u.stride, 1, 0)
+                else:
+                    dxr = g
+                g = self._bn_bwd(c["x"], da, p + ".bn1", "relu", c["s1"], dx_add=dxr)
+            else:  # cbr
+                wn = f"{u.prefix}.{u.conv_idx}.weight"
+                bnp = f"{u.prefix}.{u.conv_idx + 1}"
+                d = u.dil[0]
+                dy = self._bn_bwd(c["y"], g, bnp, "relu", c["saved"])
+                if u.k == 7:
+                    dw8 = T.conv_wgrad(c["x"], dy, 7, 1, 1, 3)            # [16, 8, 7, 7]; input channels 3..7 are zero
+                    self.G[wn].copy_(dw8[:, :3])
+                    g = None                                               # the input needs no gradient
+                else:
+                    self._wgrad(wn, c["x"], dy, 3, u.stride, d, d)
+                    g = T.conv_dgrad(dy, self.P[wn], c["x"].shape[1:3], u.stride, d, d)
+        return self.grad
+
+    def probe_grad(self, grad_head: torch.Tensor) -> torch.Tensor:
+        """dL/dW for W = head conv1.weight (params[-13]) from d L/d(head): the partial backward of main.py:704-708."""
+        kind, _, c = self._tape[-1]
+        assert kind == "head"
+        return self._head_backward(c, grad_head, probe_only=True)
+
+    # ---- one iteration ------------------------------------------------------------------------------------------
+    def train_step(self, x: torch.Tensor, targets: Dict[str, torch.Tensor], group=None):
+        """main.py:664-777 for one minibatch shard.  Returns (losses f32[5], task weights f32[5]) device tensors."""
+        head = self.forward(x)
+        w = self.task.w.tolist()                                         # 5 floats D2H (coefficients of the loss kernel)
+        losses, ghead = self.criterion.forward_backward(head, targets, coeff=[v / 5.0 for v in w])
+        if self.base is None:
+            self.base = losses.clone()                                   # get_baseloss stand-in: L_i(step 0)
+        self.backward(ghead)
+        gn = torch.empty(5, dtype=torch.float32, device=self.device)
+        for i in range(5):
+            onehot = [1.0 if j == i else 0.0 for j in range(5)]
+            _, gi = self.criterion.forward_backward(head, targets, coeff=onehot)
+            gw = self.probe_grad(gi)
+            gn[i:i + 1] = T.sumsq(gw.view(-1)).sqrt()
+        self.task.step(losses, gn, self.base, group=group)               # optimizerR.step + all-reduce + renormalise
+        scale = T.allreduce_mean_(self.grad, group=group)                # one RCCL call for every gradient
+        self.opt.step(self.grad, grad_scale=scale)                       # optimizerM.step
+        self._tape = None
+        return losses, self.task.w

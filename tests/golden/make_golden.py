@@ -302,6 +302,103 @@ def make_loss():
     np.savez_compressed(os.path.join(HERE, "loss_cases.npz"), **out)
 
 
+def make_train(drn, model):
+    """One training iteration of the reference itself (main.py:664-777) on D-22 at 96x96, batch 2: the imported
+    PoseProposalNet in train() mode, the imported PPNLoss, loss.backward(), the five create_graph probe gradients,
+    GradNorm, Lgrad.backward(), Adam on the task weights.  Stored: losses, gradient fingerprints of every parameter
+    (L2 norm + 24 sampled values) for BOTH d loss/d theta alone (after main.py:683) and the reference's final
+    .grad (after main.py:759, with the second-order term), G_i, C_i, Lgrad, d Lgrad/d w, w after
+    optimizerR.step() and after the clamp/renormalise, and the BN running stats after the forward."""
+    from oracle import targets_ref as T, train_ref
+    main_mod = import_reference_main()
+    arch_name, size, batch, seed_w, seed_in, seed_t = "drn_d_22", 96, 2, 3, 5, 11
+    alpha, lr_w = 0.12, 0.025
+    sd_np = synth.make_state_dict(arch_name, seed_w)
+    net = build_ref_model(drn, model, arch_name, sd_np)
+    net.train()
+    x = Fr.normalize_u8(prng.u8_frames(seed_in, batch, (size, size)))
+    tg = T.synthetic_batch(seed_t, batch, insize=(size, size), outsize=(size // 16, size // 16))
+    tt = {k: torch.from_numpy(v) for k, v in tg.items()}
+    crit = main_mod.PPNLoss(insize=(size, size), outsize=(size // 16, size // 16))
+    weight_model = torch.nn.Linear(5, 1, bias=False)
+    weight_model.weight.data = torch.tensor([[1.2, 0.7, 1.1, 0.9, 1.1]])
+    optR = torch.optim.Adam(weight_model.parameters(), lr=lr_w)
+    base = np.array([150.0, 0.5, 0.9, 0.6, 200.0], np.float32)
+    output = net(x)
+    losses = crit(x, output, tt["delta"], tt["weight"], tt["weight_ij"], tt["tx_half"], tt["ty_half"], tt["tx"],
+                  tt["ty"], tt["tw"], tt["th"], tt["te"])
+    l = [torch.mul(weight_model.weight[0][i], losses[i]) for i in range(5)]
+    loss = torch.div(l[0] + l[1] + l[2] + l[3] + l[4], 5)
+    net.zero_grad()
+    loss.backward(retain_graph=True)
+    names = [n for n, _ in net.named_parameters()]
+    first = {n: p.grad.detach().clone().numpy() for n, p in net.named_parameters()}
+    param = list(net.parameters())
+    assert names[-13] == "conv1.weight"
+    GR = [torch.autograd.grad(l[i], param[-13], retain_graph=True, create_graph=True) for i in range(5)]
+    G = [torch.norm(GR[i][0], 2) for i in range(5)]
+    G_avg = torch.div(G[0] + G[1] + G[2] + G[3] + G[4], 5)
+    lhat = [torch.div(l[i], float(base[i])) for i in range(5)]
+    lhat_avg = torch.div(lhat[0] + lhat[1] + lhat[2] + lhat[3] + lhat[4], 5)
+    C = [(G_avg * (torch.div(lhat[i], lhat_avg)) ** alpha).detach().squeeze() for i in range(5)]
+    optR.zero_grad()
+    gl = torch.nn.L1Loss()
+    Lgrad = gl(G[0], C[0]) + gl(G[1], C[1]) + gl(G[2], C[2]) + gl(G[3], C[3]) + gl(G[4], C[4])
+    Lgrad.backward()
+    dw = weight_model.weight.grad.detach().clone().numpy()[0]
+    w_before = weight_model.weight.detach().clone().numpy()[0]
+    optR.step()
+    w_adam = weight_model.weight.detach().clone().numpy()[0]
+    with torch.no_grad():
+        weight_model.weight.clamp_(min=0.0)
+        weight_model.weight.div_(torch.mean(weight_model.weight))
+    w_final = weight_model.weight.detach().clone().numpy()[0]
+    total = {n: p.grad.detach().clone().numpy() for n, p in net.named_parameters()}
+
+    # The CPU restatement run in f32 executes the same torch ops in the same order as the reference: it must agree
+    # to rounding in both modes.  Run in f64 it gives the noise-free values; the f32-vs-f64 gap of this randomly
+    # initialised network in train mode (tiny BN batches, ReLU gates) reaches several per cent on some tensors --
+    # that gap, not 1e-6, is the honest tolerance for any f32 implementation of this step.
+    f64 = {}
+    for so, ref in ((False, first), (True, total)):
+        r = train_ref.train_iteration_ref(sd_np, x, tg, w_before, base, arch_name, (size, size), alpha,
+                                          dtype=torch.float32, second_order=so)
+        assert np.allclose(r["losses"], [float(v.detach()) for v in losses], rtol=1e-6)
+        errs = {n: np.abs(r["grads"][n] - ref[n]).max() / max(1e-3, np.abs(ref[n]).max()) for n in names}
+        worst = max(errs.values())
+        assert worst < 1e-5, (so, sorted(errs.items(), key=lambda kv: -kv[1])[:6])
+        assert np.allclose(r["G"], [float(g.detach()) for g in G], rtol=1e-5)
+        assert np.allclose(r["C"], [float(c) for c in C], rtol=1e-5)
+        assert np.allclose(r["dw"], dw, rtol=1e-5, atol=1e-6)
+        print(f"train oracle f32 (second_order={so}) == reference: worst relative gradient error {worst:.2e}")
+        f64[so] = train_ref.train_iteration_ref(sd_np, x, tg, w_before, base, arch_name, (size, size), alpha,
+                                                second_order=so)
+        noise = {n: np.abs(f64[so]["grads"][n] - ref[n]).max() / max(1e-3, np.abs(ref[n]).max()) for n in names}
+        print(f"  reference f32 vs restatement f64: worst {max(noise.values()):.3f}, "
+              f"median {np.median(list(noise.values())):.4f}")
+
+    out = dict(arch=arch_name, size=size, batch=batch, seed_w=seed_w, seed_in=seed_in, seed_t=seed_t, alpha=alpha,
+               lr_w=lr_w, base=base, w_before=w_before, w_adam=w_adam, w_final=w_final, dw=dw,
+               losses=np.array([float(v.detach()) for v in losses], np.float32),
+               G=np.array([float(g.detach()) for g in G], np.float32), C=np.array([float(c) for c in C], np.float32),
+               Lgrad=np.float32(float(Lgrad.detach())), names=np.array(names))
+    out["G_f64"], out["C_f64"], out["dw_f64"] = f64[False]["G"], f64[False]["C"], f64[False]["dw"]
+    out["gnorm_f64"], out["losses_f64"] = f64[False]["gnorm"], f64[False]["losses"]
+    for tag, gd in (("g1", first), ("g2", total), ("g1_f64", f64[False]["grads"]), ("g2_f64", f64[True]["grads"])):
+        out[tag + "/norm"] = np.array([np.sqrt((gd[n].astype(np.float64) ** 2).sum()) for n in names])
+        idx, val = [], []
+        for i, n in enumerate(names):
+            k = (prng.raw_u64(prng.stream_seed(1000 + i, 1), 24) % np.uint64(gd[n].size)).astype(np.int64)
+            idx.append(k)
+            val.append(gd[n].reshape(-1)[k])
+        out[tag + "/idx"], out[tag + "/val"] = np.stack(idx), np.stack(val).astype(np.float64 if "f64" in tag else np.float32)
+    for n, v in net.state_dict().items():
+        if n.endswith("running_mean") or n.endswith("running_var"):
+            out["buf/" + n] = v.numpy().copy()
+    np.savez_compressed(os.path.join(HERE, "train_d22_96.npz"), **out)
+    print("train fixture written: losses", out["losses"], "G", out["G"], "w_final", w_final)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -316,6 +413,8 @@ def main():
         make_forward(drn, model)
     if args.only in (None, "loss"):
         make_loss()
+    if args.only in (None, "train"):
+        make_train(drn, model)
 
 
 if __name__ == "__main__":

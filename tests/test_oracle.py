@@ -182,3 +182,32 @@ def test_target_encoder_roundtrip():
     roots = {(int(p["bbox"][1] // 16), int(p["bbox"][0] // 16)) for p in people}
     got = {divmod(int(c), 24) for c in res["root_cell"]}
     assert got <= roots and len(got) >= 1
+
+
+def test_train_oracle_golden(golden_dir):
+    """oracle/train_ref.py (one training iteration, main.py:664-777, restated with CPU autograd) replays the values
+    the imported reference produced (tests/golden/train_d22_96.npz).  Run in f32 the restatement was bit-identical
+    to the reference when the fixture was made (asserted by make_golden.py); the stable f64 run is compared here,
+    and the reference's own f32 numbers must lie within the f32-vs-f64 noise recorded beside them."""
+    from oracle import train_ref, targets_ref as T
+    g = _load(golden_dir, "train_d22_96.npz")
+    size, batch = int(g["size"]), int(g["batch"])
+    sd = synth.make_state_dict(str(g["arch"]), int(g["seed_w"]))
+    x = Fr.normalize_u8(prng.u8_frames(int(g["seed_in"]), batch, (size, size)))
+    tg = T.synthetic_batch(int(g["seed_t"]), batch, insize=(size, size), outsize=(size // 16, size // 16))
+    names = [str(n) for n in g["names"]]
+    assert names[-13] == "conv1.weight" and len(names) == 105
+    for so, tag in ((False, "g1_f64"), (True, "g2_f64")):
+        r = train_ref.train_iteration_ref(sd, x, tg, g["w_before"], g["base"], str(g["arch"]), (size, size),
+                                          float(g["alpha"]), second_order=so)
+        for i, n in enumerate(names):
+            got = r["grads"][n].reshape(-1)[g[tag + "/idx"][i]]
+            scale = max(1e-6, float(g[tag + "/norm"][i]))
+            assert np.abs(got - g[tag + "/val"][i]).max() <= 1e-6 * scale, (n, so)
+            assert abs(np.sqrt((r["grads"][n] ** 2).sum()) - g[tag + "/norm"][i]) <= 1e-6 * scale, (n, so)
+    assert np.allclose(r["losses"], g["losses"], rtol=2e-5)
+    assert np.allclose(r["G"], g["G_f64"], rtol=1e-6) and np.allclose(r["C"], g["C_f64"], rtol=1e-6)
+    # the reference's f32 run vs the f64 values: G, C within a few per cent, and so the task weights
+    assert np.allclose(g["G"], g["G_f64"], rtol=0.2) and np.allclose(g["dw"], g["dw_f64"], rtol=0.2)
+    rel = np.abs(g["g1/norm"] - g["g1_f64/norm"]) / np.maximum(g["g1_f64/norm"], 1e-6)
+    assert np.median(rel) < 0.02 and rel[g["g1_f64/norm"] > 1e-4].max() < 0.5    # conv2.bias: exactly 0 in theory

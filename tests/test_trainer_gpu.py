@@ -1,0 +1,117 @@
+"""End-to-end GPU parity of the training step (PPNTrainer: train-mode forward, loss, backward, GradNorm task
+weights, Adam) against the CPU restatement of main.py:664-777 (oracle/train_ref.py), which the golden fixture
+train_d22_96.npz pins to the imported reference.
+
+Tolerance: this randomly initialised network in train mode amplifies f32 rounding strongly (BN over 72 samples,
+ReLU gates): the reference's own f32 gradients differ from the exact (f64) ones by up to ~5 % of a tensor's
+largest entry (isolated entries; in L2 norm the gap is ~1e-4).  The HIP f32 path is therefore held, per tensor and
+in relative L2 norm, to max(3 x that measured noise, 1e-2) against the f64 values (a ReLU gate that flips in one
+implementation but not in the other moves a 72-sample BN-bias gradient by ~0.3 %) -- wiring errors (a missing skip-path gradient, a wrong saved tensor) are O(1) and still fail."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _setup():
+    from pytorch_pose_proposal_network_amd import synth, prng
+    from oracle import forward_ref as Fr, targets_ref as T
+    g = np.load(os.path.join(GOLDEN, "train_d22_96.npz"))
+    size, batch = int(g["size"]), int(g["batch"])
+    sd = synth.make_state_dict(str(g["arch"]), int(g["seed_w"]))
+    x = Fr.normalize_u8(prng.u8_frames(int(g["seed_in"]), batch, (size, size)))
+    tg = T.synthetic_batch(int(g["seed_t"]), batch, insize=(size, size), outsize=(size // 16, size // 16))
+    return g, sd, x, tg, size
+
+
+def _rel(a, b):
+    """relative L2 error; a tensor whose exact value is ~0 (conv2.bias: BN removes its effect) is measured absolutely"""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.sqrt(((a - b) ** 2).sum()) / max(1e-4, np.sqrt((b ** 2).sum())))
+
+
+def test_trainer_f32_matches_oracle():
+    from pytorch_pose_proposal_network_amd import lib as L
+    from pytorch_pose_proposal_network_amd.trainer import PPNTrainer
+    from oracle import train_ref
+    g, sd, x, tg, size = _setup()
+    w0, base = g["w_before"], g["base"]
+    torch.set_num_threads(8)
+    r64 = train_ref.train_iteration_ref(sd, x, tg, w0, base, "drn_d_22", (size, size), float(g["alpha"]))
+    r32 = train_ref.train_iteration_ref(sd, x, tg, w0, base, "drn_d_22", (size, size), float(g["alpha"]),
+                                        dtype=torch.float32)
+    dev = torch.device("cuda")
+    tr = PPNTrainer("drn_d_22", sd, compute_dtype=L.PPN_F32, insize=(size, size), lr_weights=float(g["lr_w"]),
+                    alpha=float(g["alpha"]))
+    tr.task.w.copy_(torch.from_numpy(w0))
+    xd = torch.as_tensor(x).to(dev)
+    tgd = {k: torch.from_numpy(v).to(dev) for k, v in tg.items()}
+    head = tr.forward(xd)
+    assert np.abs(head.cpu().numpy() - r64["head"]).max() <= 1e-4          # BASELINE north_star tolerance
+    for n, b in tr.buffers.items():                                        # running stats after one train-mode pass
+        assert np.allclose(b.cpu().numpy(), r64["buffers"][n], rtol=2e-4, atol=2e-5), n
+    losses, ghead = tr.criterion.forward_backward(head, tgd, coeff=[float(v) / 5 for v in w0])
+    assert np.allclose(losses.cpu().numpy(), r64["losses"], rtol=1e-4)
+    tr.backward(ghead)
+    torch.cuda.synchronize()
+    bad = []
+    for n in tr.param_names:
+        mine = tr.G[n].cpu().numpy().astype(np.float64)
+        noise = _rel(r32["grads"][n], r64["grads"][n])
+        err = _rel(mine, r64["grads"][n])
+        if err > max(3 * noise, 1e-2):
+            bad.append((n, err, noise))
+    assert not bad, bad[:8]
+    # probe gradients of the five losses (GradNorm, main.py:704-717)
+    gn = []
+    for i in range(5):
+        onehot = [1.0 if j == i else 0.0 for j in range(5)]
+        _, gi = tr.criterion.forward_backward(head, tgd, coeff=onehot)
+        gn.append(float(tr.probe_grad(gi).double().norm().cpu()))
+    noise = np.abs(r32["gnorm"] - r64["gnorm"]) / r64["gnorm"]
+    assert np.all(np.abs(np.array(gn) - r64["gnorm"]) / r64["gnorm"] <= np.maximum(3 * noise, 1e-2)), (gn, r64["gnorm"])
+
+
+@pytest.mark.parametrize("dtype_name", ["f32", "bf16"])
+def test_train_step_updates(dtype_name):
+    """A full iteration: task weights follow the reference's (fixture values from the reference itself), every
+    parameter moves by an Adam step of its gradient, BN statistics advance, a second step runs on the new state."""
+    from pytorch_pose_proposal_network_amd import lib as L
+    from pytorch_pose_proposal_network_amd.trainer import PPNTrainer
+    g, sd, x, tg, size = _setup()
+    dev = torch.device("cuda")
+    dt = L.PPN_F32 if dtype_name == "f32" else L.PPN_BF16
+    lr = 7e-4
+    tr = PPNTrainer("drn_d_22", sd, compute_dtype=dt, insize=(size, size), lr=lr, lr_weights=float(g["lr_w"]),
+                    alpha=float(g["alpha"]))
+    tr.task.w.copy_(torch.from_numpy(g["w_before"]))
+    tr.base = torch.from_numpy(g["base"]).to(dev)
+    xd = torch.as_tensor(x).to(dev)
+    tgd = {k: torch.from_numpy(v).to(dev) for k, v in tg.items()}
+    p0 = tr.flat.clone()
+    losses, w = tr.train_step(xd, tgd)
+    torch.cuda.synchronize()
+    tol = 2e-4 if dtype_name == "f32" else 3e-2
+    assert np.allclose(losses.cpu().numpy(), g["losses"], rtol=tol)
+    # G_i carry the f32 noise of this network (see module docstring); the weights move by at most lr_w per step
+    assert np.allclose(tr.task.log[:5].cpu().numpy(), g["G_f64"], rtol=0.15 if dtype_name == "f32" else 0.3)
+    assert np.allclose(w.cpu().numpy(), g["w_final"], atol=2e-3 if dtype_name == "f32" else 2e-2)
+    assert abs(float(w.mean().cpu()) - 1.0) < 1e-6
+    # Adam, step 1: |delta| = lr * |g| / (|g| + eps) <= lr, and == lr wherever the gradient is not tiny
+    delta = (tr.flat - p0).abs()
+    gabs = tr.grad.abs()
+    assert float(delta.max()) <= lr * 1.0001
+    big = gabs > 1e-4
+    assert float(big.float().mean()) > 0.5
+    assert torch.allclose(delta[big], torch.full_like(delta[big], lr), rtol=2e-3)
+    assert torch.equal(torch.sign(tr.flat - p0)[big], -torch.sign(tr.grad)[big])
+    assert tr.num_batches_tracked == 1
+    losses2, _ = tr.train_step(xd, tgd)
+    assert torch.isfinite(losses2).all() and torch.isfinite(tr.flat).all()
+    sd2 = tr.state_dict()
+    assert len(sd2) == 207 and "backbone.0.1.num_batches_tracked" in sd2
