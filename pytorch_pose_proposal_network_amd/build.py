@@ -28,6 +28,7 @@ SOURCES = [
     ("loss.hip", []),
     ("train.hip", []),
     ("wgrad.hip", []),
+    ("stem_wgrad.hip", []),
 ]
 
 

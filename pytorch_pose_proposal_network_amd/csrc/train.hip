@@ -115,13 +115,21 @@ __global__ void bn_fwd_finalize_kernel(const double* __restrict__ partial, int n
                                        float* __restrict__ running_var, float* __restrict__ save_mean,
                                        float* __restrict__ save_rstd, float* __restrict__ scale,
                                        float* __restrict__ shift) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    // one wave per channel: lanes stride over the workgroup partials, then a fixed-order butterfly
+    const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
     if (c >= C) return;
     double S = 0.0, Q = 0.0;
-    for (int b = 0; b < nblocks; ++b) {
+    for (int b = lane; b < nblocks; b += 64) {
         S += partial[((size_t)b * C + c) * 2];
         Q += partial[((size_t)b * C + c) * 2 + 1];
     }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        S += __shfl_xor(S, off, 64);
+        Q += __shfl_xor(Q, off, 64);
+    }
+    if (lane != 0) return;
     const double n = (double)P;
     const double m = S / n;
     double var = Q / n - m * m;
@@ -176,13 +184,20 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ partial, int n
                                        const float* __restrict__ gamma, const float* __restrict__ mean,
                                        const float* __restrict__ rstd, float* __restrict__ dgamma,
                                        float* __restrict__ dbeta, float* __restrict__ coef) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
     if (c >= C) return;
     double db = 0.0, dg = 0.0;
-    for (int b = 0; b < nblocks; ++b) {
+    for (int b = lane; b < nblocks; b += 64) {
         db += partial[((size_t)b * C + c) * 2];
         dg += partial[((size_t)b * C + c) * 2 + 1];
     }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        db += __shfl_xor(db, off, 64);
+        dg += __shfl_xor(dg, off, 64);
+    }
+    if (lane != 0) return;
     dgamma[c] = (float)dg;
     dbeta[c] = (float)db;
     const double n = (double)P, g = gamma[c], r = rstd[c], m = mean[c];
@@ -345,11 +360,14 @@ __global__ void gradnorm_renorm_kernel(float* __restrict__ w, float world) {
 
 // ---- column sums (bias gradient of a convolution that feeds NHWC) ----------------------------------------------
 __global__ void colsum_finalize_kernel(const double* __restrict__ partial, int nblocks, int C, float* __restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
     if (c >= C) return;
     double S = 0.0;
-    for (int b = 0; b < nblocks; ++b) S += partial[((size_t)b * C + c) * 2];
-    out[c] = (float)S;
+    for (int b = lane; b < nblocks; b += 64) S += partial[((size_t)b * C + c) * 2];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) S += __shfl_xor(S, off, 64);
+    if (lane == 0) out[c] = (float)S;
 }
 
 // ---- head: gradient through the sigmoid + NCHW f32 -> NHWC relayout ---------------------------------------------
@@ -460,7 +478,7 @@ int ppn_bn_train_fwd(const ppn_bn_desc* d, void* stream) {
         bn_reduce_kernel<__bf16, 0><<<s.nblocks, kThreads, 0, st>>>((const __bf16*)d->x, nullptr, nullptr, nullptr,
                                                                     nullptr, nullptr, 0, d->pixels, C, s, partial);
     PPN_LAUNCH_CHECK();
-    bn_fwd_finalize_kernel<<<(C + 63) / 64, 64, 0, st>>>(partial, s.nblocks, C, d->pixels, d->gamma, d->beta, d->eps,
+    bn_fwd_finalize_kernel<<<(C + 3) / 4, 256, 0, st>>>(partial, s.nblocks, C, d->pixels, d->gamma, d->beta, d->eps,
                                                          d->momentum, d->running_mean, d->running_var, d->save_mean,
                                                          d->save_rstd, d->scale, d->shift);
     PPN_LAUNCH_CHECK();
@@ -500,7 +518,7 @@ int ppn_bn_train_bwd(const ppn_bn_bwd_desc* d, void* stream) {
                                                                     d->gamma, d->beta, d->save_mean, d->save_rstd,
                                                                     d->act, d->pixels, C, s, partial);
     PPN_LAUNCH_CHECK();
-    bn_bwd_finalize_kernel<<<(C + 63) / 64, 64, 0, st>>>(partial, s.nblocks, C, d->pixels, d->gamma, d->save_mean,
+    bn_bwd_finalize_kernel<<<(C + 3) / 4, 256, 0, st>>>(partial, s.nblocks, C, d->pixels, d->gamma, d->save_mean,
                                                          d->save_rstd, d->dgamma, d->dbeta, coef);
     PPN_LAUNCH_CHECK();
     if (d->dtype == PPN_F32)
@@ -530,7 +548,7 @@ int ppn_colsum(int32_t dtype, const void* x, int64_t pixels, int32_t channels, f
         bn_reduce_kernel<__bf16, 0><<<s.nblocks, kThreads, 0, st>>>((const __bf16*)x, nullptr, nullptr, nullptr,
                                                                     nullptr, nullptr, 0, pixels, channels, s, partial);
     PPN_LAUNCH_CHECK();
-    colsum_finalize_kernel<<<(channels + 63) / 64, 64, 0, st>>>(partial, s.nblocks, channels, out);
+    colsum_finalize_kernel<<<(channels + 3) / 4, 256, 0, st>>>(partial, s.nblocks, channels, out);
     PPN_LAUNCH_CHECK();
     return PPN_OK;
 }

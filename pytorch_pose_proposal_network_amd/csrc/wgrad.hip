@@ -19,6 +19,12 @@
 #include "common.h"
 #include "conv_common.h"
 
+namespace ppn {   // stem_wgrad.hip: dedicated kernel for the small-channel stem layers (bf16)
+bool stem_wgrad_supported(const ppn_wgrad_desc* d);
+size_t stem_wgrad_workspace_bytes(const ppn_wgrad_desc* d);
+int stem_wgrad_launch(const ppn_wgrad_desc* d, hipStream_t st);
+}  // namespace ppn
+
 namespace {
 
 using namespace ppnconv;
@@ -275,6 +281,7 @@ extern "C" {
 size_t ppn_conv_wgrad_workspace_bytes(const ppn_wgrad_desc* d) {
     Geom g;
     if (geometry(d, &g) != PPN_OK) return 0;
+    if (ppn::stem_wgrad_supported(d)) return ppn::stem_wgrad_workspace_bytes(d);
     return (size_t)g.nsplit * g.ntaps * d->cout * d->cin * sizeof(float);
 }
 
@@ -282,6 +289,11 @@ int ppn_conv_wgrad(const ppn_wgrad_desc* d, void* stream) {
     Geom g;
     if (int rc = geometry(d, &g)) return rc;
     if (!d->x || !d->dy || !d->dw || !d->workspace) return ppn::fail(PPN_E_INVALID, "ppn_conv_wgrad: NULL pointer");
+    if (ppn::stem_wgrad_supported(d)) {
+        if (d->workspace_bytes < ppn::stem_wgrad_workspace_bytes(d))
+            return ppn::fail(PPN_E_INVALID, "ppn_conv_wgrad: workspace too small");
+        return ppn::stem_wgrad_launch(d, (hipStream_t)stream);
+    }
     const size_t need = (size_t)g.nsplit * g.ntaps * d->cout * d->cin * sizeof(float);
     if (d->workspace_bytes < need)
         return ppn::fail(PPN_E_INVALID, "ppn_conv_wgrad: workspace %zu < %zu bytes", (size_t)d->workspace_bytes, need);

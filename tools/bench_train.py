@@ -1,0 +1,97 @@
+"""Time one training iteration (PPNTrainer.train_step: SURVEY 8d config 4, per-GPU shard of 32 frames) on cuda:0.
+
+    python tools/bench_train.py [--batch 32] [--size 384] [--dtype bf16] [--steps 5] [--warmup 2] [--phases]
+
+Prints ms/step, images/s and the achieved fraction of the bf16 MFMA roofline on the 3 x 95.3 GFLOP/img
+(fwd + dgrad + wgrad) figure of SURVEY 8d; --phases times forward / loss / backward / GradNorm probes / optimiser
+separately with HIP events.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pytorch_pose_proposal_network_amd import arch as A, lib as L, prng, synth  # noqa: E402
+from pytorch_pose_proposal_network_amd.trainer import PPNTrainer  # noqa: E402
+
+
+def device_targets(batch, size, dev, seed=99):
+    """Synthetic targets with the shapes of dataset.py:233-248 built on the device (values: sparse positives)."""
+    g = torch.Generator(device=dev).manual_seed(seed)
+    o = size // 16
+    K, E, s = 18, 17, 21
+    t = {}
+    delta = (torch.rand(batch, K, o, o, device=dev, generator=g) > 0.97).float()
+    t["delta"] = delta
+    t["weight"] = torch.clamp(delta + (delta < 0.5) * 0.0005, max=1.0)
+    for k in ("tx", "ty"):
+        t[k] = torch.rand(batch, K, o, o, device=dev, generator=g)
+    t["tx_half"] = t["tx"] + (delta < 0.5) * 0.5
+    t["ty_half"] = t["ty"] + (delta < 0.5) * 0.5
+    for k in ("tw", "th"):
+        t[k] = torch.rand(batch, K, o, o, device=dev, generator=g) * 0.3 + 0.02
+    te = (torch.rand(batch, E, s, s, o, o, device=dev, generator=g) > 0.999).float()
+    t["te"] = te
+    t["weight_ij"] = torch.clamp(te + (te < 0.5) * 0.0005, max=1.0)
+    return {k: v.contiguous() for k, v in t.items()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--size", type=int, default=384)
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--phases", action="store_true")
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    sd = synth.make_state_dict("drn_d_22", 0)
+    dt = L.PPN_BF16 if args.dtype == "bf16" else L.PPN_F32
+    tr = PPNTrainer("drn_d_22", sd, compute_dtype=dt, insize=(args.size, args.size))
+    frames = prng.u8_frames(99, args.batch, (args.size, args.size))
+    x = torch.from_numpy(synth.normalized_frames(frames)).to(dev)
+    tg = device_targets(args.batch, args.size, dev)
+    for _ in range(args.warmup):
+        tr.train_step(x, tg)
+    torch.cuda.synchronize()
+    if args.phases:
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+        ev[0].record()
+        head = tr.forward(x)
+        ev[1].record()
+        w = tr.task.w.tolist()
+        losses, gh = tr.criterion.forward_backward(head, tg, coeff=[v / 5 for v in w])
+        ev[2].record()
+        tr.backward(gh)
+        ev[3].record()
+        for i in range(5):
+            _, gi = tr.criterion.forward_backward(head, tg, coeff=[1.0 if j == i else 0.0 for j in range(5)])
+            tr.probe_grad(gi)
+        ev[4].record()
+        tr.opt.step(tr.grad)
+        ev[5].record()
+        torch.cuda.synchronize()
+        names = ["forward", "loss fwd+bwd", "backward", "5 GradNorm probes", "adam"]
+        for i, n in enumerate(names):
+            print(f"{n:20s} {ev[i].elapsed_time(ev[i + 1]):9.3f} ms")
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tr.train_step(x, tg)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3 / args.steps
+    flops = 3 * A.conv_flops(A.build_program("drn_d_22"), args.size, args.size) * args.batch
+    peak = 2.5e15 if args.dtype == "bf16" else 157.3e12
+    print(json.dumps({"metric": "training images/sec (fwd+bwd+GradNorm+Adam), 1 GPU", "value": round(args.batch / ms * 1e3, 2),
+                      "ms_per_step": round(ms, 3), "batch": args.batch, "dtype": args.dtype,
+                      "roofline_frac_3x_fwd_flops": round(flops / (ms * 1e-3) / peak, 4)}))
+
+
+if __name__ == "__main__":
+    main()
