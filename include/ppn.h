@@ -118,6 +118,17 @@ int ppn_loss_fwd_bwd(const ppn_loss_cfg* cfg, const float* head, int32_t batch, 
                      const float* tx, const float* ty, const float* tw, const float* th, const float* te,
                      const float* coeff, float* losses, float* grad_head, void* workspace, void* stream);
 
+/*
+ * Gradient of the four unary losses only: d(sum_{i<4} coeff4_i L_i)/d(head[:, 0:6K]) into grad_head (head layout;
+ * the limb channels are not touched, no loss values are produced).  The GradNorm probe passes for losses 0..3
+ * (main.py:704-707) need nothing else: their gradients live in the first 6K of the 7605 channels.  coeff4 is a
+ * HOST pointer to 4 floats.
+ */
+int ppn_loss_unary_bwd(const ppn_loss_cfg* cfg, const float* head, int32_t batch, const float* delta,
+                       const float* weight, const float* tx_half, const float* ty_half, const float* tx,
+                       const float* ty, const float* tw, const float* th, const float* coeff4, float* grad_head,
+                       void* workspace, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Convolution stack: one fused launch per convolution of PoseProposalNet.forward
  * (model.py:104-136, drn.py:42-57,77-97,192-202).
@@ -306,11 +317,12 @@ int ppn_colsum(int32_t dtype, const void* x, int64_t pixels, int32_t channels, f
 /*
  * Backward through the head's sigmoid (model.py:134) + relayout for the conv3 backward kernels:
  *     dz[b][hw][c] = grad_head[b][c][hw] * s*(1-s),  s = head[b][c][hw]          (NCHW f32 -> NHWC `dtype`)
- * dz has channels_pad (multiple of 64 >= channels) channels, the padding is written as zeros;
+ * Only the first channels_used (<= channels) channels of every image are converted (a probe pass of a unary loss
+ * uses 6K of the 7605); dz has channels_pad (multiple of 64 >= channels_used) channels, the padding is zeros;
  * dbias (optional, f32[channels]) = sum over b,hw of the same quantity = d/d(conv3.bias).
  */
 int ppn_head_grad(int32_t dtype, const float* head, const float* grad_head, int32_t batch, int32_t channels,
-                  int32_t hw, int32_t channels_pad, void* dz, float* dbias, void* stream);
+                  int32_t hw, int32_t channels_used, int32_t channels_pad, void* dz, float* dbias, void* stream);
 
 /*
  * A15: one torch.optim.Adam step (main.py:278-279: betas (0.9, 0.999), eps 1e-8, weight_decay 0, no amsgrad)

@@ -226,3 +226,25 @@ extern "C" int ppn_loss_fwd_bwd(const ppn_loss_cfg* cfg, const float* head, int3
     PPN_LAUNCH_CHECK();
     return PPN_OK;
 }
+
+// Gradient of the four unary losses only (resp, iou, coor, size): d(sum_i coeff_i L_i)/d(head[:, 0:6K]) written
+// into grad_head (head layout; the limb channels are NOT touched).  This is what a GradNorm probe pass needs for
+// losses 0..3 (main.py:704-707) -- their gradients live in the first 6K of 7605 channels.
+extern "C" int ppn_loss_unary_bwd(const ppn_loss_cfg* cfg, const float* head, int32_t batch, const float* delta,
+                                  const float* weight, const float* tx_half, const float* ty_half, const float* tx,
+                                  const float* ty, const float* tw, const float* th, const float* coeff4,
+                                  float* grad_head, void* workspace, void* stream) {
+    LossArgs a;
+    if (int rc = fill(a, cfg, batch)) return rc;
+    if (!head || !delta || !weight || !tx_half || !ty_half || !tx || !ty || !tw || !th || !coeff4 || !grad_head ||
+        !workspace)
+        return ppn::fail(PPN_E_INVALID, "ppn_loss_unary_bwd: NULL pointer");
+    a.head = head; a.delta = delta; a.weight = weight; a.weight_ij = nullptr; a.tx_half = tx_half; a.ty_half = ty_half;
+    a.tx = tx; a.ty = ty; a.tw = tw; a.th = th; a.te = nullptr;
+    a.grad = grad_head; a.partial = static_cast<float*>(workspace); a.losses = nullptr;
+    for (int i = 0; i < 4; ++i) a.coeff[i] = coeff4[i];
+    a.coeff[4] = 0.f;
+    hipLaunchKernelGGL(unary_kernel, dim3(a.nblk_unary), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    PPN_LAUNCH_CHECK();
+    return PPN_OK;
+}

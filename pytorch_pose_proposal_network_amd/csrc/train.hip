@@ -374,7 +374,7 @@ __global__ void colsum_finalize_kernel(const double* __restrict__ partial, int n
 // dz[b][hw][c] = g[b][c][hw] * s*(1-s),  s = head[b][c][hw]   (channels c >= C of the padded output are zero)
 template <typename T>
 __global__ void __launch_bounds__(256) head_grad_kernel(const float* __restrict__ head, const float* __restrict__ grad,
-                                                        int C, int HW, int Cpad, T* __restrict__ dz) {
+                                                        int Ctot, int C, int HW, int Cpad, T* __restrict__ dz) {
     __shared__ float tile[64][65];
     const int c0 = blockIdx.x * 64, p0 = blockIdx.y * 64, b = blockIdx.z;
     const int t = threadIdx.x;
@@ -385,7 +385,7 @@ __global__ void __launch_bounds__(256) head_grad_kernel(const float* __restrict_
         const int c = c0 + cl, p = p0 + px;
         float v = 0.f;
         if (c < C && p < HW) {
-            const size_t o = ((size_t)b * C + c) * HW + p;
+            const size_t o = ((size_t)b * Ctot + c) * HW + p;
             const float sg = head[o];
             v = grad[o] * (sg * (1.f - sg));
         }
@@ -554,17 +554,23 @@ int ppn_colsum(int32_t dtype, const void* x, int64_t pixels, int32_t channels, f
 }
 
 int ppn_head_grad(int32_t dtype, const float* head, const float* grad_head, int32_t batch, int32_t channels,
-                  int32_t hw, int32_t channels_pad, void* dz, float* dbias, void* stream) {
+                  int32_t hw, int32_t channels_used, int32_t channels_pad, void* dz, float* dbias, void* stream) {
     if (!head || !grad_head || !dz) return ppn::fail(PPN_E_INVALID, "ppn_head_grad: NULL argument");
     if (dtype != PPN_F32 && dtype != PPN_BF16) return ppn::fail(PPN_E_INVALID, "bad dtype %d", dtype);
-    if (batch < 1 || channels < 1 || hw < 1 || channels_pad < channels || channels_pad % 64)
-        return ppn::fail(PPN_E_INVALID, "ppn_head_grad: channels_pad must be a multiple of 64 >= channels");
+    if (batch < 1 || channels < 1 || hw < 1 || channels_used < 1 || channels_used > channels ||
+        channels_pad < channels_used || channels_pad % 64)
+        return ppn::fail(PPN_E_INVALID, "ppn_head_grad: need channels_used <= channels and channels_pad a multiple "
+                                        "of 64 >= channels_used");
+    if (dbias && channels_used != channels)
+        return ppn::fail(PPN_E_INVALID, "ppn_head_grad: dbias needs all channels");
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(channels_pad / 64, (hw + 63) / 64, batch);
     if (dtype == PPN_F32)
-        head_grad_kernel<float><<<grid, 256, 0, st>>>(head, grad_head, channels, hw, channels_pad, (float*)dz);
+        head_grad_kernel<float><<<grid, 256, 0, st>>>(head, grad_head, channels, channels_used, hw, channels_pad,
+                                                      (float*)dz);
     else
-        head_grad_kernel<__bf16><<<grid, 256, 0, st>>>(head, grad_head, channels, hw, channels_pad, (__bf16*)dz);
+        head_grad_kernel<__bf16><<<grid, 256, 0, st>>>(head, grad_head, channels, channels_used, hw, channels_pad,
+                                                       (__bf16*)dz);
     PPN_LAUNCH_CHECK();
     if (dbias) {
         head_bias_grad_kernel<<<(channels + 3) / 4, 256, 0, st>>>(head, grad_head, batch, channels, hw, dbias);

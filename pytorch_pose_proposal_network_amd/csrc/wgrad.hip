@@ -263,7 +263,7 @@ int geometry(const ppn_wgrad_desc* d, Geom* g) {
     g->n_nt = (d->cin + BN - 1) / BN;
     g->ntaps = d->ksize * d->ksize;
     const int tiles = g->n_mt * g->n_nt * g->ntaps;
-    int ns = (2048 + tiles - 1) / tiles;                 // aim at >= 2048 workgroups ...
+    int ns = (1024 + tiles - 1) / tiles;                 // aim at ~1024 workgroups (2 resident per CU x 2 rounds) ...
     const int max_ns = g->total_steps / 8 > 0 ? g->total_steps / 8 : 1;   // ... of at least 8 depth steps
     ns = ns > max_ns ? max_ns : ns;
     ns = ns > 64 ? 64 : ns;

@@ -121,7 +121,9 @@ _SIGNATURES.update({
     "ppn_gradnorm_renorm": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "ppn_colsum": (C.c_int, [C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ppn_head_grad": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
-                                C.c_void_p, C.c_void_p, C.c_void_p]),
+                                C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ppn_loss_unary_bwd": (C.c_int, [C.POINTER(LossCfg), C.c_void_p, C.c_int32] + [C.c_void_p] * 8 +
+                           [C.POINTER(C.c_float), C.c_void_p, C.c_void_p, C.c_void_p]),
     "ppn_conv_wgrad_workspace_bytes": (C.c_size_t, [C.POINTER(WgradDesc)]),
     "ppn_conv_wgrad": (C.c_int, [C.POINTER(WgradDesc), C.c_void_p]),
 })

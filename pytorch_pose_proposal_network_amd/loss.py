@@ -78,6 +78,30 @@ class PPNLoss:
                                      L.current_stream_ptr()), "ppn_loss_fwd_bwd")
         return losses, grad
 
+    def unary_backward(self, feature_map: torch.Tensor, targets: Dict[str, torch.Tensor], coeff4: Sequence[float],
+                       out: torch.Tensor) -> torch.Tensor:
+        """d(sum_{i<4} coeff4_i L_i)/d(feature_map[:, :6K]) written into `out` (a tensor like feature_map; its limb
+        channels are left untouched).  The cheap seed of the GradNorm probe passes for losses 0..3."""
+        lib = self._lib = self._lib or L.load()
+        c = self._cfg
+        B = feature_map.shape[0]
+        C_ = 6 * c.K + c.E * c.sH * c.sW
+        feature_map = self._check("feature_map", feature_map, (B, C_, c.H, c.W))
+        if out.shape != feature_map.shape or out.dtype != torch.float32 or not out.is_contiguous():
+            raise ValueError("out must be a contiguous float32 tensor like feature_map")
+        t = {k: self._check(k, targets[k], (B, c.K, c.H, c.W)) for k in TARGET_KEYS if k not in ("weight_ij", "te")}
+        ws = self._ws.get(B)
+        if ws is None or ws.device != feature_map.device:
+            n = lib.ppn_loss_workspace_bytes(C.byref(c), B)
+            ws = self._ws[B] = torch.empty(max(n, 16) // 4, dtype=torch.float32, device=feature_map.device)
+        cf = (C.c_float * 4)(*[float(v) for v in coeff4])
+        L.check(lib.ppn_loss_unary_bwd(C.byref(c), feature_map.data_ptr(), B, t["delta"].data_ptr(),
+                                       t["weight"].data_ptr(), t["tx_half"].data_ptr(), t["ty_half"].data_ptr(),
+                                       t["tx"].data_ptr(), t["ty"].data_ptr(), t["tw"].data_ptr(), t["th"].data_ptr(),
+                                       cf, out.data_ptr(), ws.data_ptr(), L.current_stream_ptr()),
+                "ppn_loss_unary_bwd")
+        return out
+
     def forward(self, image, feature_map, delta, weight, weight_ij, tx_half, ty_half, tx, ty, tw, th, te):
         """Reference signature (main.py:180); `image` is only used for its batch size there and is ignored here."""
         targets = dict(delta=delta, weight=weight, weight_ij=weight_ij, tx_half=tx_half, ty_half=ty_half, tx=tx, ty=ty,

@@ -178,21 +178,24 @@ class PPNTrainer:
         return cur
 
     # ---- backward ------------------------------------------------------------------------------------------------
-    def _head_backward(self, c, grad_head, probe_only: bool):
-        """Backward of the head unit.  probe_only: stop at conv1.weight and return its gradient (GradNorm)."""
+    def _head_backward(self, c, grad_head, probe_only: bool, channels_used: Optional[int] = None):
+        """Backward of the head unit.  probe_only: stop at conv1.weight and return its gradient (GradNorm);
+        channels_used: only the first so many head channels carry a gradient (6K for the unary losses)."""
         lib = L.load()
         keep = not probe_only
         head = c["head"]
         B, Ch, Ho, Wo = head.shape
-        cpad = (Ch + 63) // 64 * 64
+        used = Ch if channels_used is None else channels_used
+        assert not keep or used == Ch
+        cpad = (used + 63) // 64 * 64
         dz = torch.empty(B, Ho, Wo, cpad, dtype=self.tdt, device=self.device)
         dbias3 = self.G["conv3.bias"] if keep else None
-        L.check(lib.ppn_head_grad(self.compute_dtype, head.data_ptr(), grad_head.data_ptr(), B, Ch, Ho * Wo, cpad,
-                                  dz.data_ptr(), dbias3.data_ptr() if keep else None, L.current_stream_ptr()),
+        L.check(lib.ppn_head_grad(self.compute_dtype, head.data_ptr(), grad_head.data_ptr(), B, Ch, Ho * Wo, used,
+                                  cpad, dz.data_ptr(), dbias3.data_ptr() if keep else None, L.current_stream_ptr()),
                 "ppn_head_grad")
         w3 = self.P["conv3.weight"]
         w3p = torch.zeros(cpad, w3.shape[1], 1, 1, dtype=torch.float32, device=self.device)
-        w3p[:Ch] = w3
+        w3p[:used] = w3[:used]
         if keep:
             dw3 = T.conv_wgrad(c["h3"], dz, 1)
             self.G["conv3.weight"].copy_(dw3[:Ch])
@@ -255,11 +258,34 @@ class PPNTrainer:
                     g = T.conv_dgrad(dy, self.P[wn], c["x"].shape[1:3], u.stride, d, d)
         return self.grad
 
-    def probe_grad(self, grad_head: torch.Tensor) -> torch.Tensor:
+    def probe_grad(self, grad_head: torch.Tensor, channels_used: Optional[int] = None) -> torch.Tensor:
         """dL/dW for W = head conv1.weight (params[-13]) from d L/d(head): the partial backward of main.py:704-708."""
         kind, _, c = self._tape[-1]
         assert kind == "head"
-        return self._head_backward(c, grad_head, probe_only=True)
+        return self._head_backward(c, grad_head, probe_only=True, channels_used=channels_used)
+
+    def probe_norms(self, head, targets, coeff, ghead) -> torch.Tensor:
+        """gnorm_i = ||dL_i/dW||_2, i = 0..4, AFTER backward() ran with `coeff` (so self.G['conv1.weight'] holds
+        sum_i coeff_i dL_i/dW).  The four unary losses touch only the first 6K head channels, so their probe passes
+        cost a 128-channel conv3 backward instead of a 7616-channel one; the backward pass is linear in the head
+        gradient (BN statistics are fixed by the forward), hence the limb loss's probe gradient is what remains:
+            dL_4/dW = (sum_i coeff_i dL_i/dW - sum_{i<4} coeff_i dL_i/dW) / coeff_4
+        -- no fifth pass.  Falls back to the direct pass when coeff_4 is too small to divide by."""
+        k6 = 6 * cfg.K
+        gn = torch.empty(5, dtype=torch.float32, device=self.device)
+        rest = self.G["conv1.weight"].clone()
+        for i in range(4):
+            self.criterion.unary_backward(head, targets, [1.0 if j == i else 0.0 for j in range(4)], out=ghead)
+            gw = self.probe_grad(ghead, channels_used=k6)
+            gn[i:i + 1] = T.sumsq(gw.view(-1)).sqrt()
+            rest.sub_(gw, alpha=float(coeff[i]))
+        if coeff[4] > 1e-3 * max(coeff):
+            rest.div_(float(coeff[4]))
+        else:
+            _, g4 = self.criterion.forward_backward(head, targets, coeff=[0.0, 0.0, 0.0, 0.0, 1.0])
+            rest = self.probe_grad(g4)
+        gn[4:5] = T.sumsq(rest.contiguous().view(-1)).sqrt()
+        return gn
 
     # ---- one iteration ------------------------------------------------------------------------------------------
     def train_step(self, x: torch.Tensor, targets: Dict[str, torch.Tensor], group=None):
@@ -269,13 +295,9 @@ class PPNTrainer:
         losses, ghead = self.criterion.forward_backward(head, targets, coeff=[v / 5.0 for v in w])
         if self.base is None:
             self.base = losses.clone()                                   # get_baseloss stand-in: L_i(step 0)
+        coeff = [v / 5.0 for v in w]
         self.backward(ghead)
-        gn = torch.empty(5, dtype=torch.float32, device=self.device)
-        for i in range(5):
-            onehot = [1.0 if j == i else 0.0 for j in range(5)]
-            _, gi = self.criterion.forward_backward(head, targets, coeff=onehot)
-            gw = self.probe_grad(gi)
-            gn[i:i + 1] = T.sumsq(gw.view(-1)).sqrt()
+        gn = self.probe_norms(head, targets, coeff, ghead)               # ghead is free to be overwritten now
         self.task.step(losses, gn, self.base, group=group)               # optimizerR.step + all-reduce + renormalise
         scale = T.allreduce_mean_(self.grad, group=group)                # one RCCL call for every gradient
         self.opt.step(self.grad, grad_scale=scale)                       # optimizerM.step

@@ -73,6 +73,10 @@ def test_trainer_f32_matches_oracle():
         onehot = [1.0 if j == i else 0.0 for j in range(5)]
         _, gi = tr.criterion.forward_backward(head, tgd, coeff=onehot)
         gn.append(float(tr.probe_grad(gi).double().norm().cpu()))
+    # the production path: four 6K-channel probes + the limb probe by linearity of the backward pass
+    coeff = [float(v) / 5 for v in w0]
+    gn2 = tr.probe_norms(head, tgd, coeff, ghead).cpu().numpy()
+    assert np.allclose(gn2, np.array(gn), rtol=2e-3), (gn2, gn)
     noise = np.abs(r32["gnorm"] - r64["gnorm"]) / r64["gnorm"]
     assert np.all(np.abs(np.array(gn) - r64["gnorm"]) / r64["gnorm"] <= np.maximum(3 * noise, 1e-2)), (gn, r64["gnorm"])
 

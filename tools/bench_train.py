@@ -71,14 +71,12 @@ def main():
         ev[2].record()
         tr.backward(gh)
         ev[3].record()
-        for i in range(5):
-            _, gi = tr.criterion.forward_backward(head, tg, coeff=[1.0 if j == i else 0.0 for j in range(5)])
-            tr.probe_grad(gi)
+        tr.probe_norms(head, tg, [v / 5 for v in w], gh)
         ev[4].record()
         tr.opt.step(tr.grad)
         ev[5].record()
         torch.cuda.synchronize()
-        names = ["forward", "loss fwd+bwd", "backward", "5 GradNorm probes", "adam"]
+        names = ["forward", "loss fwd+bwd", "backward", "GradNorm probes", "adam"]
         for i, n in enumerate(names):
             print(f"{n:20s} {ev[i].elapsed_time(ev[i + 1]):9.3f} ms")
     t0 = time.perf_counter()
