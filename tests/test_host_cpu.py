@@ -116,3 +116,41 @@ def test_two_rank_gloo_sharding_matches_single_process(tmp_path):
     line = [l for l in outs[0].splitlines() if l.startswith("RESULT")][0]
     expected = [int(D.decode_ref(synth.planted_crowd_head(7 + i))["n"]) for i in range(6)]
     assert eval(line[len("RESULT "):]) == expected
+
+
+_TRAIN_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as dist
+from pytorch_pose_proposal_network_amd import train as T
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+g = torch.Generator().manual_seed(100 + rank)
+flat = torch.randn(1000, generator=g)            # this rank's flat gradient buffer
+w = torch.tensor([1.0, 2.0, 0.5, 1.5, 0.25]) * (rank + 1)
+scale = T.allreduce_mean_(flat)                  # SUM over ranks, 1/world handed to the optimiser kernel
+dist.all_reduce(w)                               # main.py:769-771
+if rank == 0:
+    print("RESULT", scale, float((flat * scale).sum()), (w / world).tolist())
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def test_two_rank_gloo_gradient_exchange(tmp_path):
+    """world_size-2 rehearsal of the training exchange step on CPU (gloo): one SUM all-reduce of the flat gradient
+    buffer, the 1/world factor folded into the Adam launch, task weights averaged (main.py:769-771, 1233-1238)."""
+    import torch
+    script = tmp_path / "train_worker.py"
+    script.write_text(_TRAIN_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29619", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    line = [l for l in outs[0].splitlines() if l.startswith("RESULT")][0]
+    parts = line.split(" ", 3)
+    scale, total, w = float(parts[1]), float(parts[2]), eval(parts[3])
+    grads = [torch.randn(1000, generator=torch.Generator().manual_seed(100 + r)) for r in range(2)]
+    assert scale == 0.5
+    assert abs(total - float(((grads[0] + grads[1]) / 2).sum())) < 1e-4
+    assert w == [1.5, 3.0, 0.75, 2.25, 0.375]

@@ -50,14 +50,20 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--phases", action="store_true")
     args = ap.parse_args()
-    dev = torch.device("cuda:0")
+    # one process per GPU under torchrun (RANK / LOCAL_RANK / WORLD_SIZE): gradients and task weights are
+    # exchanged over RCCL inside train_step; each rank works on its own 32-frame shard (weak scaling)
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
     torch.cuda.set_device(dev)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
     sd = synth.make_state_dict("drn_d_22", 0)
     dt = L.PPN_BF16 if args.dtype == "bf16" else L.PPN_F32
     tr = PPNTrainer("drn_d_22", sd, compute_dtype=dt, insize=(args.size, args.size))
-    frames = prng.u8_frames(99, args.batch, (args.size, args.size))
+    frames = prng.u8_frames(99 + rank, args.batch, (args.size, args.size))
     x = torch.from_numpy(synth.normalized_frames(frames)).to(dev)
-    tg = device_targets(args.batch, args.size, dev)
+    tg = device_targets(args.batch, args.size, dev, seed=99 + rank)
     for _ in range(args.warmup):
         tr.train_step(x, tg)
     torch.cuda.synchronize()
@@ -79,16 +85,33 @@ def main():
         names = ["forward", "loss fwd+bwd", "backward", "GradNorm probes", "adam"]
         for i, n in enumerate(names):
             print(f"{n:20s} {ev[i].elapsed_time(ev[i + 1]):9.3f} ms")
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         tr.train_step(x, tg)
     torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
     ms = (time.perf_counter() - t0) * 1e3 / args.steps
+    if world > 1:
+        t = torch.tensor([ms], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ms = float(t.item())
+        if rank != 0:
+            dist.destroy_process_group()
+            return
     flops = 3 * A.conv_flops(A.build_program("drn_d_22"), args.size, args.size) * args.batch
     peak = 2.5e15 if args.dtype == "bf16" else 157.3e12
-    print(json.dumps({"metric": "training images/sec (fwd+bwd+GradNorm+Adam), 1 GPU", "value": round(args.batch / ms * 1e3, 2),
-                      "ms_per_step": round(ms, 3), "batch": args.batch, "dtype": args.dtype,
+    print(json.dumps({"metric": "training images/sec (fwd+bwd+GradNorm+Adam)", "n_gpus": world,
+                      "value": round(world * args.batch / ms * 1e3, 2),
+                      "ms_per_step": round(ms, 3), "batch_per_gpu": args.batch, "dtype": args.dtype,
                       "roofline_frac_3x_fwd_flops": round(flops / (ms * 1e-3) / peak, 4)}))
+
+
+    if world > 1:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
