@@ -186,7 +186,7 @@ def build_program(arch: str = "drn_d_22", head_channels: Optional[int] = None, f
     16x384x384 tensor between them never goes to HBM.  Off by default: measured on MI355X the fused kernel is
     instruction-bound (235 us vs 83 + 133 us for the two separate launches at batch 32), see DESIGN.md."""
     # fuse_shortcut: a BasicBlock's 1x1 projection shortcut (+BN) becomes extra GEMM depth of its second conv
-    # (no separate launch, no residual tensor) whenever its input width is a multiple of 64.
+    # (no separate launch, no residual tensor) when its input width is a multiple of 64 and the block is narrow.
     hc = head_channels or cfg.lastsize()
     units = _units(arch)
     ops: List[ConvOp] = []
@@ -232,7 +232,10 @@ def build_program(arch: str = "drn_d_22", head_channels: Optional[int] = None, f
             p = u.prefix
             assert act is not None, "pre-activation tensor missing for BasicBlock"
             res = raw
-            fuse_ds = u.downsample and fuse_shortcut and u.cin % 64 == 0 and u.cout >= 64
+            # measured on MI355X (batch 32): fusing wins 10-12 us for the 128/256-wide blocks, whose separate 1x1
+            # launch under-fills the GPU, and loses 6-30 us for the 512-wide ones (the two-source loader slows
+            # every K step of a launch that is already efficient) -> fuse only up to 256 output channels
+            fuse_ds = u.downsample and fuse_shortcut and u.cin % 64 == 0 and 64 <= u.cout <= 256
             if u.downsample and not fuse_ds:
                 res = t(p.replace(".", "_") + "_ds")
                 ops.append(ConvOp(f"{p}.downsample", raw, f"{p}.downsample.0.weight", u.cin, u.cout, 1,

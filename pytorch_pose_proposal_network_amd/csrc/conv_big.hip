@@ -77,7 +77,9 @@ __device__ __forceinline__ void bufload_lds16(__amdgpu_buffer_rsrc_t rsrc, char*
 
 // NW waves per workgroup as 2 (channels) x NW/2 (pixels): NW = 4 -> one wave per SIMD with 8x8 MFMA tiles,
 // NW = 8 -> two waves per SIMD (each hides the other's LDS-DMA issue stalls) with 8 x TP<=4 tiles.
-template <typename T, int BP, int BC, int NW>
+// SC: the launch carries a fused 1x1 projection shortcut (second activation source, ConvKArgs.src2); compiled out
+// of the plain instantiation -- its extra loader state costs the main loop a few per cent.
+template <typename T, int BP, int BC, int NW, bool SC>
 __global__ void __launch_bounds__(64 * NW, NW / 4)
 conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
     constexpr int EPC = Elem<T>::EPC;
@@ -110,7 +112,7 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.wgt, 0, wgt_bytes, 0x00020000);
     // second activation source: the block input of a fused 1x1 projection shortcut (zero records when unused)
     const __amdgpu_buffer_rsrc_t xrs2 =
-        __builtin_amdgcn_make_buffer_rsrc((void*)(a.src2 ? a.src2 : a.src), 0, a.src2 ? a.src2_bytes : 0u, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc((void*)(SC ? a.src2 : a.src), 0, SC ? a.src2_bytes : 0u, 0x00020000);
 
     // ---- per-lane loader state: 32-bit byte offsets ----------------------------------------------
     const int lrow = lane >> 3;
@@ -136,7 +138,10 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
             if (vm && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) mk |= (1u << t);
         }
         xmask[j] = mk | (vm ? 0x80000000u : 0u);
-        xbase2[j] = (((b * a.H2 + oy * a.stride2) * a.W2 + ox * a.stride2) * a.Cin2 + chunk * EPC) * ES;
+        if constexpr (SC)
+            xbase2[j] = (((b * a.H2 + oy * a.stride2) * a.W2 + ox * a.stride2) * a.Cin2 + chunk * EPC) * ES;
+        else
+            xbase2[j] = 0;
     }
     unsigned woff[NWI];
 #pragma unroll
@@ -161,7 +166,7 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
         ++ld_step;
         live = ld_step < nsteps;
         ksoff = live ? ksoff + BK * ES : 0u;
-        const bool now2 = ld_step >= a.nsteps_main;               // past the main convolution: shortcut slabs
+        const bool now2 = SC && ld_step >= a.nsteps_main;         // past the main convolution: shortcut slabs
         if (!now2) {
             ++u_tap; ++u_dx;
             tapoff += dx_bytes;
@@ -186,7 +191,7 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
         constexpr int g = decltype(gc)::value;
         char* xs = smem + buf * STAGE;
         if constexpr (g < NXI) {
-            if (!phase2) {
+            if (!SC || !phase2) {
                 const unsigned voff = (xmask[g] & tapbit) ? (unsigned)(xbase[g] + tapoff) : kOOB;
                 bufload_lds16(xrs, xs + (g * NW + wave) * 1024, voff, 0);
             } else {
@@ -514,17 +519,17 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
 #endif
 }
 
-template <typename T, int BP, int BC, int NW>
-int launch_one(const ConvKArgs& a, hipStream_t st, const char** kname) {
+template <typename T, int BP, int BC, int NW, bool SC>
+int launch_sc(const ConvKArgs& a, hipStream_t st, const char** kname) {
     constexpr size_t lds = 2 * (size_t)(BP + BC) * 128;
     static char name[96];
     if (!name[0])
-        snprintf(name, sizeof(name), "conv_igemm_big_kernel<%s, %d, %d, %d>", sizeof(T) == 4 ? "float" : "__bf16", BP,
-                 BC, NW);
+        snprintf(name, sizeof(name), "conv_igemm_big_kernel<%s, %d, %d, %d, %s>", sizeof(T) == 4 ? "float" : "__bf16",
+                 BP, BC, NW, SC ? "true" : "false");
     if (kname) *kname = name;
     const size_t src_bytes = (size_t)a.B * a.H * a.W * a.Cin * sizeof(T);
     const size_t wgt_bytes = (size_t)a.n_ctiles * BC * a.Ktot * sizeof(T);
-    auto k = conv_igemm_big_kernel<T, BP, BC, NW>;
+    auto k = conv_igemm_big_kernel<T, BP, BC, NW, SC>;
     {
         static int max_lds_set = 0;   // the attribute sticks to the function: set it when it grows
         PPN_LDS_ONCE(max_lds_set, reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -534,6 +539,16 @@ int launch_one(const ConvKArgs& a, hipStream_t st, const char** kname) {
                        (unsigned)wgt_bytes);
     PPN_LAUNCH_CHECK();
     return PPN_OK;
+}
+
+template <typename T, int BP, int BC, int NW>
+int launch_one(const ConvKArgs& a, hipStream_t st, const char** kname) {
+    if constexpr (NW == 8 && BC >= 128) {
+        if (a.src2) return launch_sc<T, BP, BC, NW, true>(a, st, kname);
+    } else {
+        if (a.src2) return ppn::fail(PPN_E_UNSUPPORTED, "fused shortcut needs the 8-wave 128/256-channel tiles");
+    }
+    return launch_sc<T, BP, BC, NW, false>(a, st, kname);
 }
 
 template <typename T>

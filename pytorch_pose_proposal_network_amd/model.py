@@ -12,6 +12,8 @@ mode (1e-4 on the head), ``'bfloat16'`` the performance mode (bf16 operands, f32
 """
 from __future__ import annotations
 
+import os
+
 import ctypes as C
 from typing import Dict, List, Optional
 
@@ -58,7 +60,7 @@ class _Plan:
 class PoseProposalNet:
     def __init__(self, backbone="drn_d_22", insize=(384, 384), outsize=(24, 24),
                  keypoint_names=cfg.KEYPOINT_NAMES, local_grid_size=(21, 21), edges=cfg.EDGES,
-                 compute_dtype: str = "float32", fuse_stem: bool = False):
+                 compute_dtype: str = "float32", fuse_stem: bool = False, fuse_shortcut: Optional[bool] = None):
         self.arch = _arch_of(backbone)
         self.insize = insize
         self.outsize = outsize
@@ -74,7 +76,10 @@ class PoseProposalNet:
                               "bf16": L.PPN_BF16}[compute_dtype]
         self.training = False
         self.device = torch.device("cuda")
-        self._ops: List[A.ConvOp] = A.build_program(self.arch, self.lastsize, fuse_stem=fuse_stem)
+        if fuse_shortcut is None:                             # tuning knob: PPN_FUSE_SHORTCUT=0 keeps the 1x1 shortcuts apart
+            fuse_shortcut = os.environ.get("PPN_FUSE_SHORTCUT", "1") != "0"
+        self._ops: List[A.ConvOp] = A.build_program(self.arch, self.lastsize, fuse_stem=fuse_stem,
+                                                    fuse_shortcut=fuse_shortcut)
         self._spec = dict(A.param_spec(self.arch, self.lastsize))
         self._sd: Dict[str, torch.Tensor] = {}
         self._dev: Dict[str, torch.Tensor] = {}      # packed weights / folded BN on the device

@@ -1,0 +1,20 @@
+#!/bin/bash
+# Re-measure everything profiles/ holds, on the GPU box (run through gpurun).  Output: gpurun_out/<tag>/...
+#   tools/refresh_profiles.sh r01
+set -e
+R=${GRAFT_REPO_ROOT:-/root/repo}; T=${1:-r01}; O="$R/gpurun_out/$T"; mkdir -p "$O"
+cd /tmp; export TMPDIR=/tmp
+echo "[1/6] bench (unprofiled, with per-launch table and CPU baseline)"
+python3 $R/bench.py --layers > $O/bench.json 2> $O/bench_layers.txt
+echo "[2/6] rocprofv3 kernel stats of bench.py"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_profiled.json 2> $O/bench_profiled.err
+echo "[3/6] PMC pass FETCH_SIZE"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/fetch.json 2> $O/fetch.err
+echo "[4/6] PMC pass WRITE_SIZE"
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/write.json 2> $O/write.err
+echo "[5/6] training step (phases + JSON)"
+python3 $R/tools/bench_train.py --phases > $O/train_bench.txt 2>&1
+echo "[6/6] rocprofv3 kernel stats of the training step"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/train_stats -o train -- python3 $R/tools/bench_train.py --steps 3 --warmup 1 > $O/train_profiled.txt 2>&1
+find $O -name "*.csv" -size +3M -delete
+echo done
