@@ -224,6 +224,22 @@ def main():
                         "ms": round(dec_ms, 4), "gbps": round(head_bytes / dec_ms / 1e6, 1),
                         "frac_of_hbm_peak": round(head_bytes / dec_ms / 1e6 / 8000.0, 4), "people": people}),
         }
+        if world == 1:
+            # PCIe-inclusive rate (NOT `value`): every step first copies the u8 frames from pinned host memory and
+            # ends with the compact decode result (counts, cells, boxes, scores) back on the host.
+            host = torch.from_numpy(prng.u8_frames(1234, B, (S, S))).pin_memory()
+            n = max(5, args.steps // 2)
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for _ in range(n):
+                frames.copy_(host, non_blocking=True)
+                res = step()
+                hosted = res.to_host()
+            torch.cuda.synchronize(dev)
+            dt1 = time.perf_counter() - t1
+            result["pcie_inclusive"] = {"value": round(B * n / dt1, 2), "unit": "images/sec",
+                                        "ms_per_step": round(dt1 / n * 1e3, 4), "h2d_bytes_per_step": host.numel(),
+                                        "note": "serial H2D (pinned) + step + D2H of the compact result; no overlap"}
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args.arch, 4, S)
     if dist is not None:

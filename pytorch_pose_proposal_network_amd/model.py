@@ -99,7 +99,8 @@ class PoseProposalNet:
 
     def train(self, mode: bool = True):
         if mode:
-            raise NotImplementedError("train-mode BatchNorm (SURVEY.md 8 A16) is not built yet: inference only")
+            raise NotImplementedError("this class runs the folded-BN inference plan; training (train-mode BN, "
+                                      "backward, GradNorm, Adam) lives in trainer.PPNTrainer")
         self.training = False
         return self
 
