@@ -149,7 +149,15 @@ __global__ void __launch_bounds__(256) stem_wgrad_fold_kernel(const float* __res
     const int o = blockIdx.x * 256 + threadIdx.x;
     if (o >= n) return;
     float acc = 0.f;
-    for (int w = 0; w < nwg; ++w) acc += partial[(size_t)w * n + o];
+    int w = 0;
+    for (; w + 8 <= nwg; w += 8) {                      // eight loads in flight, summed in a fixed order
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = partial[(size_t)(w + j) * n + o];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc += v[j];
+    }
+    for (; w < nwg; ++w) acc += partial[(size_t)w * n + o];
     dw[o] = beta != 0.f ? beta * dw[o] + acc : acc;
 }
 

@@ -8,10 +8,12 @@
 // operands are fetched with gfx950's transposing LDS read ds_read_b64_tr_b16 (bf16) -- no shuffle, no second image.
 // The f32 parity mode uses v_mfma_f32_16x16x4_f32, whose operands are one scalar per lane (plain ds_read_b32).
 //
-//   workgroup tile 128 (cout) x 128 (cin) for one tap, 4 waves as 2 x 2, each 64 x 64 = 4 x 4 MFMA tiles
-//   depth step 64 pixels (bf16) / 32 pixels (f32): 2 x 16 KB per stage, 2 stages
-//   LDS image: 256-byte pixel rows, 16-byte chunk c of row r at chunk slot c ^ (((r&3)<<2) | ((r>>2)&3)), applied on
-//              the SOURCE side of the DMA (the DMA destination is lane-linear); conflict-free for the transposed reads
+//   workgroup tile (cout x cin, one tap): 256 x 256 with 8 waves (4 x 2, each 64 x 128) for >= 256-wide layers,
+//              128 x 128 with 4 waves (2 x 2, each 64 x 64) otherwise
+//   depth step 64 pixels (bf16) / 32 pixels (f32), 2 LDS stages (128 KB / 64 KB)
+//   LDS image: pixel rows of 256 or 512 bytes, 16-byte chunk c of row r at slot c ^ (((r&3)<<2) | ((r>>2)&3)) inside
+//              its 256-byte window, applied on the SOURCE side of the DMA (the DMA destination is lane-linear);
+//              conflict-free for the transposed reads
 //   split over pixels: grid.y slices; every slice writes its own f32 partial, a second launch folds them in a fixed
 //              order (bitwise reproducible, no atomics) into the reference layout [cout][cin][k][k].
 //
@@ -30,9 +32,6 @@ namespace {
 using namespace ppnconv;
 
 constexpr unsigned kOOB = 0x80000000u;
-constexpr int BM = 128, BN = 128;
-constexpr int kTileBytes = 16384;     // one operand tile of one stage
-constexpr int kThreads = 256;
 
 struct WgArgs {
     const char* x;
@@ -63,18 +62,32 @@ __device__ __forceinline__ int fdiv(int q, int d, float inv, int* rem) {
     return t;
 }
 
-template <typename T>
-__global__ void __launch_bounds__(kThreads) wgrad_kernel(WgArgs a) {
+// LDS image of a [pixel rows][channels] tile: 16-byte chunk `ch` of row `row` sits at chunk slot
+// (ch & ~15) | ((ch & 15) ^ (((row&3)<<2) | ((row>>2)&3))) -- rows are a multiple of 256 B apart, i.e. they alias
+// to the same banks; the XOR permutes the chunks of every 256-byte window per row so that the transposed reads
+// (4 rows x 32 B per 16 lanes) are conflict-free.  f32 tiles are read with scalar ds_read_b32 and stay linear.
+__device__ __forceinline__ int swz(int row, int ch) { return (ch & ~15) | ((ch & 15) ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
+
+// WM x WN waves, each TM x TN MFMA tiles of 16 x 16:  workgroup tile BM = WM*TM*16 (cout) x BN = WN*TN*16 (cin).
+//   <2,2,4,4>: 128 x 128, 4 waves, 64 KB LDS (two workgroups per CU)  -- narrow layers
+//   <4,2,4,8>: 256 x 256, 8 waves, 128 KB LDS (two waves per SIMD)    -- >= 256-wide layers: twice the FLOP per
+//              byte staged through LDS, half the L2 re-reads of x and dy
+template <typename T, int WM, int WN, int TM, int TN>
+__global__ void __launch_bounds__(64 * WM * WN) wgrad_kernel(WgArgs a) {
     constexpr int ES = sizeof(T), EPC = Elem<T>::EPC;
     constexpr bool BF = ES == 2;
-    constexpr int CPR = BM / EPC;                    // 16-byte chunks per pixel row: 16 (bf16) / 32 (f32)
-    constexpr int ROWB = BM * ES;                    // 256 / 512
-    constexpr int BKP = kTileBytes / ROWB;           // pixels per depth step: 64 / 32
-    constexpr int NPIECE = kTileBytes / (kThreads * 16);   // 4 DMA instructions per operand per step
+    constexpr int NWAVE = WM * WN, NTHR = 64 * NWAVE;
+    constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
+    constexpr int BKP = BF ? 64 : 32;                                 // pixels per depth step
+    constexpr int CPRA = BM / EPC, CPRB = BN / EPC;                   // 16-byte chunks per pixel row
+    constexpr int ROWA = BM * ES, ROWB = BN * ES;
+    constexpr int TILEA = BKP * ROWA, TILEB = BKP * ROWB;
+    constexpr int NPA = TILEA / (NTHR * 16), NPB = TILEB / (NTHR * 16);   // DMA instructions per operand and step
+    static_assert(TILEA % (NTHR * 16) == 0 && TILEB % (NTHR * 16) == 0, "tile must split into whole DMA pieces");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
 
     // tile -> (tap, cin tile, cout tile); taps fastest so that concurrent workgroups share the same pixel rows in L2
     int tix = blockIdx.x;
@@ -92,68 +105,78 @@ __global__ void __launch_bounds__(kThreads) wgrad_kernel(WgArgs a) {
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, a.dy_bytes, 0x00020000);
 
-    // per-lane DMA geometry: piece i fills rows [i*RPP, +RPP) of the tile; this lane owns row prow[i], chunk pch[i]
-    int prow[NPIECE];
-    unsigned a_choff[NPIECE], b_choff[NPIECE];       // channel byte offset of the chunk, or kOOB when past C
+    // per-lane DMA geometry: piece i covers the lane-linear LDS range [(i*NWAVE + wave)*1024, +1024)
+    int arow[NPA], brow[NPB];
+    unsigned a_choff[NPA], b_choff[NPB];              // channel byte offset of the lane's chunk, or kOOB when past C
 #pragma unroll
-    for (int i = 0; i < NPIECE; ++i) {
-        const int q = (i * 4 + wave) * 64 + lane;
-        const int row = q / CPR, slot = q % CPR;
-        const int ch = BF ? (slot ^ (((row & 3) << 2) | ((row >> 2) & 3))) : slot;
-        prow[i] = row;
+    for (int i = 0; i < NPA; ++i) {
+        const int q = (i * NWAVE + wave) * 64 + lane;
+        const int row = q / CPRA, slot = q % CPRA;
+        const int ch = BF ? swz(row, slot) : slot;     // the XOR is an involution: slot -> logical chunk
+        arow[i] = row;
         a_choff[i] = (m0 + ch * EPC) < a.Cout ? (unsigned)((m0 + ch * EPC) * ES) : kOOB;
+    }
+#pragma unroll
+    for (int i = 0; i < NPB; ++i) {
+        const int q = (i * NWAVE + wave) * 64 + lane;
+        const int row = q / CPRB, slot = q % CPRB;
+        const int ch = BF ? swz(row, slot) : slot;
+        brow[i] = row;
         b_choff[i] = (n0 + ch * EPC) < a.Cin ? (unsigned)((n0 + ch * EPC) * ES) : kOOB;
     }
 
     auto issue = [&](int step, int stage) {
-        char* sa = smem + stage * 2 * kTileBytes;
-        char* sb = sa + kTileBytes;
+        char* sa = smem + stage * (TILEA + TILEB);
+        char* sb = sa + TILEA;
         const int pbase = (step0 + step) * BKP;
 #pragma unroll
-        for (int i = 0; i < NPIECE; ++i) {
-            const int p = pbase + prow[i];
-            const bool pv = p < a.P;
-            unsigned va = kOOB, vb = kOOB;
-            if (pv && a_choff[i] != kOOB) va = (unsigned)p * (unsigned)(a.Cout * ES) + a_choff[i];
+        for (int i = 0; i < NPA; ++i) {
+            const int p = pbase + arow[i];
+            unsigned va = kOOB;
+            if (p < a.P && a_choff[i] != kOOB) va = (unsigned)p * (unsigned)(a.Cout * ES) + a_choff[i];
+            bufload_lds16(yrs, sa + (i * NWAVE + wave) * 1024, va);
+        }
+#pragma unroll
+        for (int i = 0; i < NPB; ++i) {
+            const int p = pbase + brow[i];
+            unsigned vb = kOOB;
             int rem, rx;
             const int b = fdiv(p, a.HoWo, a.inv_howo, &rem);
             const int oy = fdiv(rem, a.Wo, a.inv_wo, &rx);
             const int iy = oy * a.stride + oy_off, ix = rx * a.stride + ox_off;
-            if (pv && b_choff[i] != kOOB && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
+            if (p < a.P && b_choff[i] != kOOB && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
                 vb = (unsigned)((b * a.H + iy) * a.W + ix) * (unsigned)(a.Cin * ES) + b_choff[i];
-            bufload_lds16(yrs, sa + (i * 4 + wave) * 1024, va);
-            bufload_lds16(xrs, sb + (i * 4 + wave) * 1024, vb);
+            bufload_lds16(xrs, sb + (i * NWAVE + wave) * 1024, vb);
         }
     };
 
-    f32x4 acc[4][4];
+    f32x4 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // fragment read addresses (relative to the operand tile of a stage)
     const int g = lane >> 4, li = lane & 15;
-    unsigned ra[4][2], rb[4][2];                      // bf16: [tile][half of the 8-pixel group]
-    unsigned fa[4], fb[4];                            // f32 : [tile]
+    unsigned ra[TM][2], rb[TN][2];                    // bf16: [tile][half of the 8-pixel group]
+    unsigned fa[TM], fb[TN];                          // f32 : [tile]
     if (BF) {
         const int q = li >> 2, p = li & 3;
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int h = 0; h < 2; ++h) {
+            const int row = 8 * g + 4 * h + q;                            // + 32*substep (the XOR is invariant)
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int row = 8 * g + 4 * h + q;                       // + 32*substep
-                const int x = ((row & 3) << 2) | ((row >> 2) & 3);       // invariant under row += 32
-                const int ca = (wm * 8 + t * 2 + (p >> 1)) ^ x, cb = (wn * 8 + t * 2 + (p >> 1)) ^ x;
-                ra[t][h] = row * ROWB + ca * 16 + 8 * (p & 1);
-                rb[t][h] = row * ROWB + cb * 16 + 8 * (p & 1);
-            }
+            for (int t = 0; t < TM; ++t)
+                ra[t][h] = row * ROWA + swz(row, (wm * TM + t) * 2 + (p >> 1)) * 16 + 8 * (p & 1);
+#pragma unroll
+            for (int t = 0; t < TN; ++t)
+                rb[t][h] = row * ROWB + swz(row, (wn * TN + t) * 2 + (p >> 1)) * 16 + 8 * (p & 1);
+        }
     } else {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            fa[t] = g * ROWB + (wm * 64 + t * 16 + li) * 4;              // + 4 rows per substep
-            fb[t] = g * ROWB + (wn * 64 + t * 16 + li) * 4;
-        }
+        for (int t = 0; t < TM; ++t) fa[t] = g * ROWA + ((wm * TM + t) * 16 + li) * 4;   // + 4 rows per substep
+#pragma unroll
+        for (int t = 0; t < TN; ++t) fb[t] = g * ROWB + ((wn * TN + t) * 16 + li) * 4;
     }
 
     if (nsteps > 0) issue(0, 0);
@@ -161,46 +184,46 @@ __global__ void __launch_bounds__(kThreads) wgrad_kernel(WgArgs a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (s + 1 < nsteps) issue(s + 1, (s + 1) & 1);
-        const char* sa = smem + (s & 1) * 2 * kTileBytes;
-        const char* sb = sa + kTileBytes;
+        const char* sa = smem + (s & 1) * (TILEA + TILEB);
+        const char* sb = sa + TILEA;
         if (BF) {
 #pragma unroll
             for (int sub = 0; sub < BKP / 32; ++sub) {
-                bf16x8 af[4], bfr[4];
+                bf16x8 af[TM], bfr[TN];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
+                for (int t = 0; t < TM; ++t) {
                     const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (s16x4 __attribute__((address_space(3)))*)(sa + ra[t][0] + sub * 32 * ROWB));
+                        (s16x4 __attribute__((address_space(3)))*)(sa + ra[t][0] + sub * 32 * ROWA));
                     const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (s16x4 __attribute__((address_space(3)))*)(sa + ra[t][1] + sub * 32 * ROWB));
+                        (s16x4 __attribute__((address_space(3)))*)(sa + ra[t][1] + sub * 32 * ROWA));
+                    af[t] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
+                }
+#pragma unroll
+                for (int t = 0; t < TN; ++t) {
                     const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                         (s16x4 __attribute__((address_space(3)))*)(sb + rb[t][0] + sub * 32 * ROWB));
                     const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                         (s16x4 __attribute__((address_space(3)))*)(sb + rb[t][1] + sub * 32 * ROWB));
-                    const s16x8 av = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
-                    const s16x8 bv = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
-                    af[t] = __builtin_bit_cast(bf16x8, av);
-                    bfr[t] = __builtin_bit_cast(bf16x8, bv);
+                    bfr[t] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
                 }
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
+                    for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
             }
         } else {
 #pragma unroll 2
             for (int sub = 0; sub < BKP / 4; ++sub) {
-                float af[4], bfr[4];
+                float af[TM], bfr[TN];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    af[t] = *reinterpret_cast<const float*>(sa + fa[t] + sub * 4 * ROWB);
-                    bfr[t] = *reinterpret_cast<const float*>(sb + fb[t] + sub * 4 * ROWB);
-                }
+                for (int t = 0; t < TM; ++t) af[t] = *reinterpret_cast<const float*>(sa + fa[t] + sub * 4 * ROWA);
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int t = 0; t < TN; ++t) bfr[t] = *reinterpret_cast<const float*>(sb + fb[t] + sub * 4 * ROWB);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bfr[j], acc[i][j], 0, 0, 0);
             }
         }
@@ -209,34 +232,44 @@ __global__ void __launch_bounds__(kThreads) wgrad_kernel(WgArgs a) {
     // partial[split][tap][co][ci]
     float* out = a.partial + ((size_t)blockIdx.y * a.ntaps + tap) * (size_t)a.Cout * a.Cin;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int ci = n0 + wn * 64 + j * 16 + li;
+        for (int j = 0; j < TN; ++j) {
+            const int ci = n0 + (wn * TN + j) * 16 + li;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int co = m0 + wm * 64 + i * 16 + 4 * g + r;
+                const int co = m0 + (wm * TM + i) * 16 + 4 * g + r;
                 if (co < a.Cout && ci < a.Cin) out[(size_t)co * a.Cin + ci] = acc[i][j][r];
             }
         }
 }
 
-// dw[co][ci][tap] = beta*dw + sum_s partial[s][tap][co][ci]   (fixed order)
+// dw[co][ci][tap] = beta*dw + sum_s partial[s][tap][co][ci]   (fixed order; one thread per output element, the
+// loads of four splits in flight at a time -- a serial chain of nsplit*taps loads per thread was latency-bound)
 __global__ void __launch_bounds__(256) wgrad_fold_kernel(const float* __restrict__ partial, int nsplit, int ntaps,
                                                          int Cout, int Cin, float beta, float* __restrict__ dw) {
     const long long n = (long long)Cout * Cin;
-    const long long o = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (o >= n) return;
-    for (int t = 0; t < ntaps; ++t) {
-        float acc = 0.f;
-        for (int s = 0; s < nsplit; ++s) acc += partial[((size_t)s * ntaps + t) * n + o];
-        float* d = dw + o * ntaps + t;
-        *d = beta != 0.f ? beta * *d + acc : acc;
+    const long long w = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (w >= n * ntaps) return;
+    const int t = (int)(w / n);
+    const long long o = w - (long long)t * n;
+    const float* p = partial + (size_t)t * n + o;
+    const size_t stride = (size_t)ntaps * n;
+    float acc = 0.f;
+    int s = 0;
+    for (; s + 4 <= nsplit; s += 4) {
+        const float v0 = p[(size_t)s * stride], v1 = p[(size_t)(s + 1) * stride];
+        const float v2 = p[(size_t)(s + 2) * stride], v3 = p[(size_t)(s + 3) * stride];
+        acc = (((acc + v0) + v1) + v2) + v3;
     }
+    for (; s < nsplit; ++s) acc += p[(size_t)s * stride];
+    float* d = dw + o * ntaps + t;
+    *d = beta != 0.f ? beta * *d + acc : acc;
 }
 
 struct Geom {
     int bkp, total_steps, nsplit, steps_per_split, n_mt, n_nt, ntaps;
+    int big;     // 256 x 256 tile (8 waves) instead of 128 x 128 (4 waves)
 };
 
 int geometry(const ppn_wgrad_desc* d, Geom* g) {
@@ -259,11 +292,18 @@ int geometry(const ppn_wgrad_desc* d, Geom* g) {
         return ppn::fail(PPN_E_UNSUPPORTED, "ppn_conv_wgrad: tensor too large (pixels < 2^24, bytes < 2 GiB)");
     g->bkp = d->dtype == PPN_F32 ? 32 : 64;
     g->total_steps = (int)((P + g->bkp - 1) / g->bkp);
-    g->n_mt = (d->cout + BM - 1) / BM;
-    g->n_nt = (d->cin + BN - 1) / BN;
+    static const char* force = getenv("PPN_WGRAD_TILE");                 // tuning knob: "128" / "256"
+    g->big = force ? atoi(force) == 256 : (d->cout >= 256 && d->cin >= 256);
+    const int bm = g->big ? 256 : 128;
+    g->n_mt = (d->cout + bm - 1) / bm;
+    g->n_nt = (d->cin + bm - 1) / bm;
     g->ntaps = d->ksize * d->ksize;
     const int tiles = g->n_mt * g->n_nt * g->ntaps;
-    int ns = (1024 + tiles - 1) / tiles;                 // aim at ~1024 workgroups (2 resident per CU x 2 rounds) ...
+    // 512 workgroups fill the GPU for two rounds (256-tile: one resident workgroup per CU) or one round (128-tile:
+    // two per CU); round DOWN so that the count never spills a nearly empty extra round (540 workgroups measured
+    // 1.3x slower than 504 on the 512x512x9 layers).
+    int ns = 512 / tiles;
+    ns = ns < 1 ? 1 : ns;
     const int max_ns = g->total_steps / 8 > 0 ? g->total_steps / 8 : 1;   // ... of at least 8 depth steps
     ns = ns > max_ns ? max_ns : ns;
     ns = ns > 64 ? 64 : ns;
@@ -272,7 +312,17 @@ int geometry(const ppn_wgrad_desc* d, Geom* g) {
     return PPN_OK;
 }
 
-int lds_limit_f32 = 0, lds_limit_bf16 = 0;
+template <typename T, int WM, int WN, int TM, int TN>
+int launch(const WgArgs& a, dim3 grid, hipStream_t st) {
+    static int lds_set = 0;
+    constexpr int bkp = sizeof(T) == 2 ? 64 : 32;
+    constexpr int lds = 2 * bkp * (WM * TM + WN * TN) * 16 * (int)sizeof(T);
+    auto k = wgrad_kernel<T, WM, WN, TM, TN>;
+    PPN_LDS_ONCE(lds_set, reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    k<<<grid, 64 * WM * WN, lds, st>>>(a);
+    PPN_LAUNCH_CHECK();
+    return PPN_OK;
+}
 
 }  // namespace
 
@@ -316,16 +366,11 @@ int ppn_conv_wgrad(const ppn_wgrad_desc* d, void* stream) {
     a.dy_bytes = (unsigned)((size_t)a.P * d->cout * es);
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(g.n_mt * g.n_nt * g.ntaps, g.nsplit);
-    const int lds = 4 * kTileBytes;
-    if (d->dtype == PPN_F32) {
-        PPN_LDS_ONCE(lds_limit_f32, reinterpret_cast<const void*>(&wgrad_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        wgrad_kernel<float><<<grid, kThreads, lds, st>>>(a);
-    } else {
-        PPN_LDS_ONCE(lds_limit_bf16, reinterpret_cast<const void*>(&wgrad_kernel<__bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        wgrad_kernel<__bf16><<<grid, kThreads, lds, st>>>(a);
-    }
-    PPN_LAUNCH_CHECK();
-    const long long n = (long long)d->cout * d->cin;
+    int rc;
+    if (d->dtype == PPN_F32) rc = g.big ? launch<float, 4, 2, 4, 8>(a, grid, st) : launch<float, 2, 2, 4, 4>(a, grid, st);
+    else rc = g.big ? launch<__bf16, 4, 2, 4, 8>(a, grid, st) : launch<__bf16, 2, 2, 4, 4>(a, grid, st);
+    if (rc) return rc;
+    const long long n = (long long)d->cout * d->cin * g.ntaps;
     wgrad_fold_kernel<<<(int)((n + 255) / 256), 256, 0, st>>>(a.partial, g.nsplit, g.ntaps, d->cout, d->cin, d->beta,
                                                               d->dw);
     PPN_LAUNCH_CHECK();

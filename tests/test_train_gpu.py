@@ -147,6 +147,9 @@ CONV_CASES = [
     (2, 64, 128, 16, 1, 2, 1, 0),         # strided 1x1 projection shortcut
     (1, 160, 72, 7, 3, 1, 4, 4),          # channel counts that are not tile multiples; dilation > image/2
     (3, 32, 64, 20, 3, 2, 1, 1),          # layer3.0.conv1: 32 input channels
+    (1, 256, 512, 10, 3, 1, 2, 2),        # >= 256-wide: the 256 x 256 tile (8 waves)
+    (2, 512, 256, 6, 1, 1, 1, 0),
+    (1, 264, 320, 7, 3, 1, 1, 1),         # 256-tile with ragged channel counts
     (2, 8, 16, 70, 7, 1, 1, 3),           # layer0 7x7 on the 8-channel padded input (bf16: dedicated stem kernel)
     (2, 16, 16, 70, 3, 1, 1, 1),          # layer1
     (2, 16, 32, 141, 3, 2, 1, 1),         # layer2, stride 2, odd input size
