@@ -7,7 +7,8 @@ import csv, glob, json, sys, collections
 src, out = sys.argv[1], sys.argv[2]
 res = collections.defaultdict(dict)
 for kind, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
-    f = glob.glob(f"{src}/{kind}/*/*counter_collection.csv")[0]
+    import os
+    f = max(glob.glob(f"{src}/{kind}/*/*counter_collection.csv"), key=os.path.getmtime)   # newest pass
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == ctr:

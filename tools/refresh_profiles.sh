@@ -2,7 +2,7 @@
 # Re-measure everything profiles/ holds, on the GPU box (run through gpurun).  Output: gpurun_out/<tag>/...
 #   tools/refresh_profiles.sh r01
 set -e
-R=${GRAFT_REPO_ROOT:-/root/repo}; T=${1:-r01}; O="$R/gpurun_out/$T"; mkdir -p "$O"
+R=${GRAFT_REPO_ROOT:-/root/repo}; T=${1:-r01}; O="$R/gpurun_out/$T"; rm -rf "$O"; mkdir -p "$O"
 cd /tmp; export TMPDIR=/tmp
 echo "[1/6] bench (unprofiled, with per-launch table and CPU baseline)"
 python3 $R/bench.py --layers > $O/bench.json 2> $O/bench_layers.txt
