@@ -119,6 +119,21 @@ int ppn_loss_fwd_bwd(const ppn_loss_cfg* cfg, const float* head, int32_t batch, 
                      const float* coeff, float* losses, float* grad_head, void* workspace, void* stream);
 
 /*
+ * Training-target encoder (dataset.py:96-185) on the device: person lists -> the ten target tensors of
+ * ppn_loss_fwd_bwd, bit-exact with the host encoder.  Replaces the per-sample host encoding + 2 x 17.3 MB/sample
+ * H2D of main.py:649-661.
+ *   edges    HOST i32 [E][2]  (src, dst keypoint of every limb, config.py:44-62)
+ *   people   f32 [B][pmax][5 + 2*(K-1)] device: cx, cy, w, h (instance box, centre format), size (side of a part box,
+ *            pixels), then x, y of keypoints 1..K-1 in input pixels
+ *   visible  i32 [B][pmax] device: bit k-1 set = keypoint k is labeled;  count i32 [B]: people per image (<= pmax)
+ * People are applied in list order (a later person overwrites a grid cell an earlier one claimed).
+ */
+int ppn_encode_targets(const ppn_loss_cfg* cfg, const int32_t* edges, const float* people, const int32_t* visible,
+                       const int32_t* count, int32_t batch, int32_t pmax, float* delta, float* weight,
+                       float* weight_ij, float* tx_half, float* ty_half, float* tx, float* ty, float* tw, float* th,
+                       float* te, void* stream);
+
+/*
  * Gradient of the four unary losses only: d(sum_{i<4} coeff4_i L_i)/d(head[:, 0:6K]) into grad_head (head layout;
  * the limb channels are not touched, no loss values are produced).  The GradNorm probe passes for losses 0..3
  * (main.py:704-707) need nothing else: their gradients live in the first 6K of the 7605 channels.  coeff4 is a

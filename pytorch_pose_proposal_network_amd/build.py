@@ -27,6 +27,7 @@ SOURCES = [
     ("plan.hip", []),
     ("loss.hip", []),
     ("train.hip", []),
+    ("encode.hip", ["-ffp-contract=off"]),
     ("wgrad.hip", []),
     ("stem_wgrad.hip", []),
 ]

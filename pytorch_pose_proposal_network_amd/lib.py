@@ -124,6 +124,8 @@ _SIGNATURES.update({
                                 C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ppn_loss_unary_bwd": (C.c_int, [C.POINTER(LossCfg), C.c_void_p, C.c_int32] + [C.c_void_p] * 8 +
                            [C.POINTER(C.c_float), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ppn_encode_targets": (C.c_int, [C.POINTER(LossCfg), C.POINTER(C.c_int32), C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_int32, C.c_int32] + [C.c_void_p] * 11),
     "ppn_conv_wgrad_workspace_bytes": (C.c_size_t, [C.POINTER(WgradDesc)]),
     "ppn_conv_wgrad": (C.c_int, [C.POINTER(WgradDesc), C.c_void_p]),
 })

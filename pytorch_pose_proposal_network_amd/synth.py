@@ -155,3 +155,22 @@ def planted_crowd_head(seed: int, n_people: int = 16, n_decoys: int = 4, out_hw=
             head[5 * K + d, jh, jw] = np.float32(0.02 + 0.08 * rnd())
             pos[d] = (jh, jw)
     return head
+
+
+def synthetic_people(seed: int, insize=(384, 384), max_people: int = 4):
+    """List of people: dict(bbox=(cx,cy,w,h), points f32[17,2] (x,y), visible bool[17], size float)."""
+    inW, inH = insize
+    r = prng.uniform01(prng.stream_seed(seed, 0), 1 + max_people * 64).astype(np.float64)
+    n = 1 + int(r[0] * max_people)
+    n = min(n, max_people)
+    people, p = [], 1
+    for _ in range(n):
+        cx, cy = 40 + r[p] * (inW - 80), 40 + r[p + 1] * (inH - 80)
+        w, h = 60 + r[p + 2] * 140, 60 + r[p + 3] * 140
+        size = 8 + r[p + 4] * 16
+        pts = np.stack([r[p + 5:p + 22] * (inW - 1), r[p + 22:p + 39] * (inH - 1)], 1).astype(np.float32)
+        vis = r[p + 39:p + 56] > 0.15
+        people.append(dict(bbox=(np.float32(cx), np.float32(cy), np.float32(w), np.float32(h)), points=pts,
+                           visible=vis, size=np.float32(size)))
+        p += 64
+    return people

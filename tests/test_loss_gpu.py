@@ -67,3 +67,21 @@ def test_loss_argument_validation():
     fm = torch.zeros(1, cfg.lastsize(), 24, 24, device="cuda")
     with pytest.raises((ValueError, KeyError)):
         crit.forward_backward(fm, {}, [1] * 5)
+
+
+@pytest.mark.parametrize("size,batch,seed", [(384, 3, 11), (96, 4, 50), (384, 2, 1234)])
+def test_target_encoder_bit_exact(size, batch, seed):
+    """csrc/encode.hip vs the NumPy restatement of dataset.py:96-185: every one of the ten tensors identical."""
+    from pytorch_pose_proposal_network_amd import targets, synth
+    outsize = (size // 16, size // 16)
+    lists = [synth.synthetic_people(seed + i, insize=(size, size)) for i in range(batch)]
+    # overlapping people exercise the "later person overwrites" rule: duplicate the first person with another size
+    twin = dict(lists[0][0])
+    twin["size"] = np.float32(19.5)
+    lists[0] = list(lists[0]) + [twin]
+    ref = [T.encode_targets(p, insize=(size, size), outsize=outsize) for p in lists]
+    got = targets.encode_targets(targets.pack_people(lists), (size, size), outsize)
+    for k in targets.TARGET_KEYS:
+        exp = np.stack([r[k] for r in ref])
+        assert np.array_equal(got[k].cpu().numpy(), exp), k
+    assert float(got["te"].sum()) > 0 and float(got["delta"].sum()) > 0

@@ -16,29 +16,8 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from pytorch_pose_proposal_network_amd import arch as A, lib as L, prng, synth  # noqa: E402
+from pytorch_pose_proposal_network_amd import arch as A, lib as L, prng, synth, targets  # noqa: E402
 from pytorch_pose_proposal_network_amd.trainer import PPNTrainer  # noqa: E402
-
-
-def device_targets(batch, size, dev, seed=99):
-    """Synthetic targets with the shapes of dataset.py:233-248 built on the device (values: sparse positives)."""
-    g = torch.Generator(device=dev).manual_seed(seed)
-    o = size // 16
-    K, E, s = 18, 17, 21
-    t = {}
-    delta = (torch.rand(batch, K, o, o, device=dev, generator=g) > 0.97).float()
-    t["delta"] = delta
-    t["weight"] = torch.clamp(delta + (delta < 0.5) * 0.0005, max=1.0)
-    for k in ("tx", "ty"):
-        t[k] = torch.rand(batch, K, o, o, device=dev, generator=g)
-    t["tx_half"] = t["tx"] + (delta < 0.5) * 0.5
-    t["ty_half"] = t["ty"] + (delta < 0.5) * 0.5
-    for k in ("tw", "th"):
-        t[k] = torch.rand(batch, K, o, o, device=dev, generator=g) * 0.3 + 0.02
-    te = (torch.rand(batch, E, s, s, o, o, device=dev, generator=g) > 0.999).float()
-    t["te"] = te
-    t["weight_ij"] = torch.clamp(te + (te < 0.5) * 0.0005, max=1.0)
-    return {k: v.contiguous() for k, v in t.items()}
 
 
 def main():
@@ -63,7 +42,8 @@ def main():
     tr = PPNTrainer("drn_d_22", sd, compute_dtype=dt, insize=(args.size, args.size))
     frames = prng.u8_frames(99 + rank, args.batch, (args.size, args.size))
     x = torch.from_numpy(synth.normalized_frames(frames)).to(dev)
-    tg = device_targets(args.batch, args.size, dev, seed=99 + rank)
+    # 1..4 synthetic people per frame, targets built by the on-device encoder (csrc/encode.hip)
+    tg = targets.synthetic_targets(99 + 1000 * rank, args.batch, (args.size, args.size), device=dev)
     for _ in range(args.warmup):
         tr.train_step(x, tg)
     torch.cuda.synchronize()
