@@ -86,8 +86,98 @@ def cpu_baseline(arch, sample, size):
             "sample": f"{reps} x {sample} frames {size}x{size}: torch-CPU fp32 oracle forward + NumPy decode, {dt:.1f} s"}
 
 
+def cpu_baseline_train(arch, size):
+    """One training iteration of the oracle (torch-CPU autograd restatement of main.py:664-777, f32) at batch 2 on
+    this host's cores, repeated for ~10 s; reported per image."""
+    from oracle import forward_ref as Fr, targets_ref as Tg, train_ref
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    sd = synth.make_state_dict(arch, 0)
+    b = 2
+    x = Fr.normalize_u8(prng.u8_frames(99, b, (size, size)))
+    tg = Tg.synthetic_batch(99, b, insize=(size, size), outsize=(size // 16, size // 16))
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        train_ref.train_iteration_ref(sd, x, tg, [1.0] * 5, [1.0] * 5, arch, (size, size), dtype=torch.float32)
+        reps += 1
+        if time.perf_counter() - t0 > 10.0:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": round(b * reps / dt, 3), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{reps} x {b} frames {size}x{size}: torch-CPU fp32 oracle train step "
+                      f"(train-mode forward, loss, backward, 5 GradNorm probe gradients), {dt:.1f} s"}
+
+
+def main_train(args):
+    """--workload train: BASELINE configs[3] per-GPU shard -- one PPNTrainer.train_step per step (train-mode forward,
+    PPNLoss fwd+bwd, backward, GradNorm probes + task-weight step, gradient all-reduce over RCCL, Adam)."""
+    from pytorch_pose_proposal_network_amd import arch as A, lib as L, targets
+    from pytorch_pose_proposal_network_amd.trainer import PPNTrainer
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    B, S = args.batch, args.size
+    tr = PPNTrainer(args.arch, synth.make_state_dict(args.arch, 0),
+                    compute_dtype=L.PPN_BF16 if args.dtype == "bf16" else L.PPN_F32, insize=(S, S), device=dev)
+    x = torch.from_numpy(synth.normalized_frames(prng.u8_frames(99 + rank, B, (S, S)))).to(dev)
+    tg = targets.synthetic_targets(99 + 1000 * rank, B, (S, S), device=dev)      # encoded on the device
+    for _ in range(args.warmup):
+        tr.train_step(x, tg)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses, w = tr.train_step(x, tg)
+    fence()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        flops = 3 * A.conv_flops(A.build_program(args.arch), S, S) * B          # fwd + dgrad + wgrad, SURVEY 8d
+        peak = BF16_DENSE_PEAK_TFLOPS if args.dtype == "bf16" else F32_MFMA_PEAK_TFLOPS
+        ach = flops / (dt / args.steps) / 1e12
+        result = {
+            "metric": "training images/sec (384x384, DRN-D-22, fwd/bwd + GradNorm + Adam)",
+            "value": round(world * B * args.steps / dt, 2), "unit": "images/sec", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"{args.arch} PPN training step {args.dtype}, batch {B}/GPU synthetic {S}x{S} frames, "
+                                   "targets of 1-4 synthetic people per frame encoded on the device "
+                                   "(BASELINE configs[3] per-GPU shard; model gradient first-order, DESIGN.md section 7)",
+                       "frames_per_gpu": B, "parallelism": f"minibatch sharded over {world} GPU(s), one all-reduce of "
+                                                           "the flat 128.5 MB gradient buffer + 20 B of task weights"},
+            "roofline": {"bound": "mfma", "kernel": "whole step (3 x forward conv FLOPs / step time)",
+                         "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                         "traffic": None},
+            "losses": [round(float(v), 4) for v in losses.tolist()], "task_weights": [round(float(v), 4) for v in w.tolist()],
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline_train(args.arch, S)
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="inference", choices=["inference", "train"],
+                    help="inference = BASELINE configs[1] (the headline metric, default); train = configs[3] shard")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
@@ -101,6 +191,8 @@ def main():
                     help="write the f32 head tensor [B,7605,24,24] and decode it with the stand-alone arg-max kernel "
                          "(model.forward + get_humans_by_feature path) instead of the fused inference path")
     args = ap.parse_args()
+    if args.workload == "train":
+        return main_train(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
