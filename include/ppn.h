@@ -259,6 +259,11 @@ int ppn_plan_destroy(ppn_plan* p);
  * depth order/step reported by ppn_conv_tiling. */
 int ppn_pack_weight(int32_t dtype, const float* w, int32_t cout, int32_t cin, int32_t ksize, int32_t cout_pad,
                     int32_t k_total, int32_t k_order, int32_t k_step, void* out, void* stream);
+/* Same, for the input-gradient convolution of a layer whose FORWARD weight is w f32 [cin,cout,k,k]: packs
+ * w'[co][ci][ky][kx] = w[ci][co][k-1-ky][k-1-kx] (cout/cin are those of the gradient convolution, i.e. the
+ * forward layer's cin/cout).  ppn_conv2d_fused on dy with this weight is autograd's conv input gradient. */
+int ppn_pack_weight_dgrad(int32_t dtype, const float* w, int32_t cout, int32_t cin, int32_t ksize, int32_t cout_pad,
+                          int32_t k_total, int32_t k_order, int32_t k_step, void* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Training building blocks (main.py:623-777).  Activations are NHWC

@@ -337,7 +337,7 @@ int ilog2_exact(int v) {
 // weight packing: [cout,cin,k,k] f32 -> [cout_pad][k_total] T with k = (ky*ks+kx)*cin + ci
 template <typename T>
 __global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ out, int cout, int cin, int ks,
-                                   int cout_pad, int ktot, int korder, int kstep) {
+                                   int cout_pad, int ktot, int korder, int kstep, int transposed) {
     const size_t n = (size_t)cout_pad * ktot;
     const int ntaps = ks * ks;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -347,11 +347,16 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ 
             int tap, ci;
             if (korder == 0) {
                 tap = k / cin; ci = k % cin;
+            } else if (korder == 2) {                              // reference layout [cout][cin][k][k]
+                ci = k / ntaps; tap = k % ntaps;
             } else {
                 const int blk = k / kstep, within = k % kstep;     // blk = cchunk*ntaps + tap
                 tap = blk % ntaps; ci = (blk / ntaps) * kstep + within;
             }
-            v = w[((size_t)co * cin + ci) * ntaps + tap];
+            // transposed: the input-gradient convolution's weight w'[co][ci][tap] = w[ci][co][last - tap] of the
+            // forward weight w [cin][cout][k][k] (channel roles swapped, filter rotated by 180 degrees)
+            v = transposed ? w[((size_t)ci * cout + co) * ntaps + (ntaps - 1 - tap)]
+                           : w[((size_t)co * cin + ci) * ntaps + tap];
         }
         out[i] = (T)v;
     }
@@ -487,30 +492,50 @@ extern "C" int ppn_conv2d_fused(const ppn_conv_desc* d, void* stream) {
     return ppn::conv_launch(d, static_cast<hipStream_t>(stream), nullptr);
 }
 
-extern "C" int ppn_pack_weight(int32_t dtype, const float* w, int32_t cout, int32_t cin, int32_t ksize,
-                               int32_t cout_pad, int32_t k_total, int32_t k_order, int32_t k_step, void* out,
-                               void* stream) {
+static int pack_weight_impl(int32_t dtype, const float* w, int32_t cout, int32_t cin, int32_t ksize,
+                            int32_t cout_pad, int32_t k_total, int32_t k_order, int32_t k_step, void* out,
+                            void* stream, int transposed) {
     if (!w || !out || cout < 1 || cin < 1 || ksize < 1 || cout_pad < cout || k_total < ksize * ksize * cin)
         return ppn::fail(PPN_E_INVALID, "ppn_pack_weight: bad arguments");
-    hipStream_t st0 = static_cast<hipStream_t>(stream);
-    if (k_order == 2) {   // reference layout, f32, as is
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (k_order == 2 && !transposed) {   // reference layout, f32, as is
         PPN_HIP_CHECK(hipMemcpyAsync(out, w, sizeof(float) * (size_t)cout * cin * ksize * ksize,
-                                     hipMemcpyDeviceToDevice, st0));
+                                     hipMemcpyDeviceToDevice, st));
+        return PPN_OK;
+    }
+    if (k_order == 2) {                  // reference layout f32 of the transposed filter: [cout][cin*k*k] rows
+        if (cout_pad != cout || k_total != cin * ksize * ksize)
+            return ppn::fail(PPN_E_INVALID, "ppn_pack_weight: k_order 2 is unpadded");
+        const size_t n = (size_t)cout * k_total;
+        hipLaunchKernelGGL(pack_weight_kernel<float>, dim3((int)((n + 255) / 256)), dim3(256), 0, st, w,
+                           static_cast<float*>(out), cout, cin, ksize, cout_pad, k_total, 2, 1, 1);
+        PPN_LAUNCH_CHECK();
         return PPN_OK;
     }
     if (k_order != 0 && (k_order != 1 || k_step < 1 || cin % k_step != 0))
         return ppn::fail(PPN_E_INVALID, "ppn_pack_weight: k_order %d needs cin %% k_step == 0", k_order);
     const size_t n = (size_t)cout_pad * k_total;
     const int blocks = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
-    hipStream_t st = static_cast<hipStream_t>(stream);
     if (dtype == PPN_F32)
         hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(blocks), dim3(256), 0, st, w, static_cast<float*>(out), cout,
-                           cin, ksize, cout_pad, k_total, k_order, k_step);
+                           cin, ksize, cout_pad, k_total, k_order, k_step, transposed);
     else if (dtype == PPN_BF16)
         hipLaunchKernelGGL(pack_weight_kernel<__bf16>, dim3(blocks), dim3(256), 0, st, w, static_cast<__bf16*>(out),
-                           cout, cin, ksize, cout_pad, k_total, k_order, k_step);
+                           cout, cin, ksize, cout_pad, k_total, k_order, k_step, transposed);
     else
         return ppn::fail(PPN_E_INVALID, "bad dtype %d", dtype);
     PPN_LAUNCH_CHECK();
     return PPN_OK;
+}
+
+extern "C" int ppn_pack_weight(int32_t dtype, const float* w, int32_t cout, int32_t cin, int32_t ksize,
+                               int32_t cout_pad, int32_t k_total, int32_t k_order, int32_t k_step, void* out,
+                               void* stream) {
+    return pack_weight_impl(dtype, w, cout, cin, ksize, cout_pad, k_total, k_order, k_step, out, stream, 0);
+}
+
+extern "C" int ppn_pack_weight_dgrad(int32_t dtype, const float* w, int32_t cout, int32_t cin, int32_t ksize,
+                                     int32_t cout_pad, int32_t k_total, int32_t k_order, int32_t k_step, void* out,
+                                     void* stream) {
+    return pack_weight_impl(dtype, w, cout, cin, ksize, cout_pad, k_total, k_order, k_step, out, stream, 1);
 }

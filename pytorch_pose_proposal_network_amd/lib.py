@@ -106,6 +106,8 @@ _SIGNATURES = {
     "ppn_plan_destroy": (C.c_int, [C.c_void_p]),
     "ppn_pack_weight": (C.c_int, [C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                   C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "ppn_pack_weight_dgrad": (C.c_int, [C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                  C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
 }
 
 _SIGNATURES.update({

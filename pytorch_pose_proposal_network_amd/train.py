@@ -87,14 +87,18 @@ def bn_train_forward(x: torch.Tensor, gamma, beta, running_mean=None, running_va
 
 
 def bn_train_backward(x: torch.Tensor, dy: torch.Tensor, gamma, beta, saved: BnSaved, act: str = "none",
-                      dx_add: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None):
-    """Returns (dx, dgamma, dbeta) for y = act(batch_norm(x)); dx_add (same shape) is added to dx."""
+                      dx_add: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+                      dgamma: Optional[torch.Tensor] = None, dbeta: Optional[torch.Tensor] = None):
+    """Returns (dx, dgamma, dbeta) for y = act(batch_norm(x)); dx_add (same shape) is added to dx.
+    dgamma / dbeta: optional f32[C] destinations (e.g. views of the flat gradient buffer), overwritten."""
     lib = L.load()
     c = x.shape[-1]
     if dy.shape != x.shape or dy.dtype != x.dtype or not dy.is_contiguous():
         raise ValueError("dy must match x")
-    dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
-    dbeta = torch.empty(c, dtype=torch.float32, device=x.device)
+    if dgamma is None:
+        dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
+    if dbeta is None:
+        dbeta = torch.empty(c, dtype=torch.float32, device=x.device)
     dx = out if out is not None else torch.empty_like(x)
     d = L.BnBwdDesc()
     d.dtype, d.channels, d.pixels, d.act = _dtype_code(x), c, x.numel() // c, ACT[act]
@@ -105,7 +109,7 @@ def bn_train_backward(x: torch.Tensor, dy: torch.Tensor, gamma, beta, saved: BnS
         d.dx_add = dx_add.data_ptr()
     d.gamma, d.beta = _f32(gamma, c, "gamma"), _f32(beta, c, "beta")
     d.save_mean, d.save_rstd = saved.mean.data_ptr(), saved.rstd.data_ptr()
-    d.dgamma, d.dbeta, d.dx = dgamma.data_ptr(), dbeta.data_ptr(), dx.data_ptr()
+    d.dgamma, d.dbeta, d.dx = _f32(dgamma, c, "dgamma"), _f32(dbeta, c, "dbeta"), dx.data_ptr()
     d.workspace = _workspace(c, x.device).data_ptr()
     L.check(lib.ppn_bn_train_bwd(C.byref(d), L.current_stream_ptr()), "ppn_bn_train_bwd")
     return dx, dgamma, dbeta
@@ -202,14 +206,17 @@ class GradNormWeights:
 
 def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, stride: int = 1, dilation: int = 1, pad: int = 0,
                 add: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None, act: int = 0,
-                nchw_f32: bool = False) -> torch.Tensor:
+                nchw_f32: bool = False, dgrad_of: bool = False) -> torch.Tensor:
     """Raw convolution (no folded BN: train mode keeps BN separate) of an NHWC tensor with a reference-layout
     f32 weight [cout,cin,k,k] on the device, + `add` (NHWC, the residual).  Packs the weight for the MFMA
     kernels on the fly: in training the weights change every step anyway."""
     lib = L.load()
     dt = _dtype_code(x)
     B, H, W, cin = x.shape
-    cout, cin_w, k, _ = w.shape
+    if dgrad_of:          # w is the FORWARD weight [cin, cout, k, k]: the packer transposes and rotates it
+        cin_w, cout, k, _ = w.shape
+    else:
+        cout, cin_w, k, _ = w.shape
     if cin_w != cin or w.dtype != torch.float32 or not w.is_contiguous() or not x.is_contiguous():
         raise ValueError("conv2d_nhwc: x must be NHWC contiguous and w f32 [cout,cin,k,k] contiguous")
     eff = dilation * (k - 1) + 1
@@ -217,8 +224,8 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, stride: int = 1, dilation: int
     kstep, _, korder, ktot, cpad = L.conv_tiling(dt, cin, cout, k)
     st = L.current_stream_ptr()
     packed = torch.empty(cpad, ktot, dtype=torch.float32 if korder == 2 else x.dtype, device=x.device)
-    L.check(lib.ppn_pack_weight(dt, w.data_ptr(), cout, cin, k, cpad, ktot, korder, kstep, packed.data_ptr(), st),
-            "ppn_pack_weight")
+    pack = lib.ppn_pack_weight_dgrad if dgrad_of else lib.ppn_pack_weight
+    L.check(pack(dt, w.data_ptr(), cout, cin, k, cpad, ktot, korder, kstep, packed.data_ptr(), st), "ppn_pack_weight")
     if nchw_f32:                                  # the head tensor the loss / decode kernels read (model.py:134-136)
         out = torch.empty(B, cout, Ho, Wo, dtype=torch.float32, device=x.device)
     else:
@@ -258,14 +265,13 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, in_hw, stride: int = 1, dilati
     H, W = in_hw
     cout, cin, k, _ = w.shape
     eff = dilation * (k - 1) + 1
-    wt = w.permute(1, 0, 2, 3).flip(2, 3).contiguous()
     B, Ho, Wo, _ = dy.shape
     hup, wup = H + 2 * pad - eff + 1, W + 2 * pad - eff + 1
     if stride > 1 or (hup, wup) != (Ho, Wo):
         up = torch.zeros(B, hup, wup, cout, dtype=dy.dtype, device=dy.device)
         up[:, ::stride, ::stride][:, :Ho, :Wo] = dy
         dy = up
-    return conv2d_nhwc(dy, wt, 1, dilation, eff - 1 - pad, add=add)
+    return conv2d_nhwc(dy, w, 1, dilation, eff - 1 - pad, add=add, dgrad_of=True)
 
 
 def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, ksize: int, stride: int = 1, dilation: int = 1, pad: int = 0,

@@ -104,11 +104,10 @@ class PPNTrainer:
         return y, saved
 
     def _bn_bwd(self, x, dy, prefix, act, saved, dx_add=None, keep=True):
-        dx, dg, db = T.bn_train_backward(x, dy, self.P[prefix + ".weight"], self.P[prefix + ".bias"], saved, act=act,
-                                         dx_add=dx_add)
-        if keep:
-            self.G[prefix + ".weight"].copy_(dg)
-            self.G[prefix + ".bias"].copy_(db)
+        # parameter gradients land directly in the flat gradient buffer (probe passes discard them)
+        dx, _, _ = T.bn_train_backward(x, dy, self.P[prefix + ".weight"], self.P[prefix + ".bias"], saved, act=act,
+                                       dx_add=dx_add, dgamma=self.G[prefix + ".weight"] if keep else None,
+                                       dbeta=self.G[prefix + ".bias"] if keep else None)
         return dx
 
     def _wgrad(self, name, x, dy, k, stride=1, dil=1, pad=0):
