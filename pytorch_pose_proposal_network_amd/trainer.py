@@ -39,7 +39,7 @@ _BUFFER_SUFFIXES = (".running_mean", ".running_var", ".num_batches_tracked")
 
 class PPNTrainer:
     def __init__(self, arch: str = "drn_d_22", state_dict: Optional[Dict] = None, compute_dtype: int = L.PPN_BF16,
-                 lr: float = 7e-4, lr_weights: float = 0.025, alpha: float = 0.12, insize=(384, 384),
+                 lr: float = 7e-4, lr_weights: Optional[float] = None, alpha: float = 0.12, insize=(384, 384),
                  device="cuda"):
         L.load()                                               # fail loudly without libppn.so
         if A.DRN_D[arch][0] != "basic":
@@ -72,7 +72,8 @@ class PPNTrainer:
         if state_dict is not None:
             self.load_state_dict(state_dict)
         self.opt = T.FlatAdam(self.flat, lr=lr)                               # optimizerM, main.py:278
-        self.task = T.GradNormWeights(self.device, lr=lr_weights, alpha=alpha)  # weight_model + optimizerR
+        # weight_model + optimizerR: the reference gives both optimisers args.lr (main.py:278-279)
+        self.task = T.GradNormWeights(self.device, lr=lr if lr_weights is None else lr_weights, alpha=alpha)
         self.criterion = PPNLoss(insize=insize, outsize=(insize[0] // 16, insize[1] // 16))
         self.base: Optional[torch.Tensor] = None
         self._tape = None
@@ -95,6 +96,12 @@ class PPNTrainer:
             if n.endswith(".running_var"):
                 sd[n[:-len("running_var")] + "num_batches_tracked"] = torch.tensor(self.num_batches_tracked)
         return sd
+
+    def adjust_learning_rate(self, epoch: int):
+        """main.py:1222-1231, called on optimizerM once per epoch (main.py:406): halve the rate every 300 epochs."""
+        if epoch % 300 == 0 and epoch > 1:
+            self.opt.lr = 0.5 * self.opt.lr
+        return self.opt.lr
 
     # ---- small helpers ------------------------------------------------------------------------------------------
     def _bn(self, x, prefix, act):
