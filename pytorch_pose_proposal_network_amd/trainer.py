@@ -97,6 +97,27 @@ class PPNTrainer:
                 sd[n[:-len("running_var")] + "num_batches_tracked"] = torch.tensor(self.num_batches_tracked)
         return sd
 
+    def get_baseloss(self, batches):
+        """main.py:578-621: the five losses in EVAL mode (running BN statistics) averaged over `batches`, an iterable
+        of (x f32[B,3,H,W], targets dict); sets and returns self.base (f32[5] on the device)."""
+        from . import drn, model
+        net = model.PoseProposalNet(getattr(drn, self.arch)(), insize=self.insize,
+                                    outsize=(self.insize[0] // 16, self.insize[1] // 16),
+                                    compute_dtype="float32" if self.compute_dtype == L.PPN_F32 else "bfloat16")
+        net = net.cuda(self.device)
+        net.load_state_dict(self.state_dict())
+        net.eval()
+        total = torch.zeros(5, dtype=torch.float32, device=self.device)
+        n = 0
+        for x, targets in batches:
+            losses, _ = self.criterion.forward_backward(net(x), targets, want_grad=False)
+            total += losses
+            n += 1
+        if n == 0:
+            raise ValueError("get_baseloss needs at least one batch")
+        self.base = total / n
+        return self.base
+
     def adjust_learning_rate(self, epoch: int):
         """main.py:1222-1231, called on optimizerM once per epoch (main.py:406): halve the rate every 300 epochs."""
         if epoch % 300 == 0 and epoch > 1:

@@ -178,3 +178,25 @@ def test_bf16_gradients_track_f32():
             assert c_bf >= c_emu - 0.2 and c_bf >= 0.6 and 0.7 <= ratio <= 1.4, (n, c_bf, c_emu, ratio)
         checked += 1
     assert checked > 60 and cos(bf["conv3.weight"], f32["conv3.weight"]) > 0.995
+
+
+def test_get_baseloss_matches_eval_oracle():
+    """main.py:578-621: eval-mode losses averaged over the batches (here two), vs forward_ref (eval BN) + loss_ref."""
+    from pytorch_pose_proposal_network_amd import lib as L, synth, prng
+    from pytorch_pose_proposal_network_amd.trainer import PPNTrainer
+    from oracle import forward_ref as Fr, loss_ref as Lr, targets_ref as Tg
+    g = np.load(os.path.join(GOLDEN, "forward_d22_96.npz"))
+    stats = {k[3:]: g[k] for k in g.files if k.startswith("bn/")}
+    sd = synth.make_state_dict("drn_d_22", int(g["seed_w"]), bn_stats=stats)
+    dev = torch.device("cuda")
+    tr = PPNTrainer("drn_d_22", sd, compute_dtype=L.PPN_F32, insize=(96, 96))
+    batches, ref = [], np.zeros(5)
+    for i in range(2):
+        x = Fr.normalize_u8(prng.u8_frames(40 + i, 2, (96, 96)))
+        tg = Tg.synthetic_batch(60 + 2 * i, 2, insize=(96, 96), outsize=(6, 6))
+        head = Fr.forward_ref(sd, x, "drn_d_22")
+        ref += np.array([float(v) for v in Lr.ppn_loss_ref(head, {k: torch.from_numpy(v) for k, v in tg.items()},
+                                                          insize=(96, 96))])
+        batches.append((torch.as_tensor(x).to(dev), {k: torch.from_numpy(v).to(dev) for k, v in tg.items()}))
+    base = tr.get_baseloss(batches).cpu().numpy()
+    assert np.allclose(base, ref / 2, rtol=2e-4), (base, ref / 2)
