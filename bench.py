@@ -187,6 +187,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--layers", action="store_true", help="print the per-layer table to stderr")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="run the decode kernel on the same stream as the conv stack (no overlap across steps)")
     ap.add_argument("--materialize-head", action="store_true",
                     help="write the f32 head tensor [B,7605,24,24] and decode it with the stand-alone arg-max kernel "
                          "(model.forward + get_humans_by_feature path) instead of the fused inference path")
@@ -226,8 +228,14 @@ def main():
     dec = decode.Decoder(B, (S // 16, S // 16), (S, S), device=dev)
 
     fused = not args.materialize_head
+    pipe = None
+    if fused and not args.no_pipeline:
+        from pytorch_pose_proposal_network_amd import rt
+        pipe = rt.InferencePipeline(net, B, (S, S), device=dev)
 
     def step():
+        if pipe is not None:   # conv stack of step i+1 overlaps the NMS/limb-parse kernel of step i (side stream)
+            return pipe.submit(frames)
         if fused:       # rt_test.inference path: the head conv's epilogue runs the limb arg-max, no head tensor
             unary, keys = net.forward_u8(frames, fused_decode=True)
             return dec.decode_fused(unary, keys)
@@ -297,7 +305,9 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.arch} PPN inference {args.dtype}, batch {B}/GPU synthetic {S}x{S} u8 frames: "
                                    "fused normalise + conv stack + head + decode/NMS/limb-parse (BASELINE configs[1])"
-                                   + ("" if fused else ", head tensor materialised"),
+                                   + ("" if fused else ", head tensor materialised")
+                                   + (", decode of step i on a side stream under the conv stack of step i+1"
+                                      if pipe is not None else ""),
                        "frames_per_gpu": B, "input": f"{S}x{S}x3 u8", "head": f"{cfg.lastsize()}x{S//16}x{S//16} f32",
                        "parallelism": f"frames sharded over {world} GPU(s), no data-path collective"},
             "roofline": {"bound": "mfma", "kernel": dk, "launches_per_step": dn // reps,

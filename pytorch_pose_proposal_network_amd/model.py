@@ -271,14 +271,14 @@ class PoseProposalNet:
         head = (bufs["unary"], bufs["keys"]) if fused else bufs["head"]
         return _Plan(handle, bufs, head, entries, A.conv_flops(self._ops, h, w) * batch)
 
-    def _plan_for(self, x: torch.Tensor, src_is_u8: bool, fused: bool = False) -> _Plan:
+    def _plan_for(self, x: torch.Tensor, src_is_u8: bool, fused: bool = False, slot: int = 0) -> _Plan:
         if not self._dev:
             raise RuntimeError("PoseProposalNet: call load_state_dict() first")
         if src_is_u8:
             b, h, w, _ = x.shape
         else:
             b, _, h, w = x.shape
-        key = (b, h, w, src_is_u8, fused)
+        key = (b, h, w, src_is_u8, fused, slot)       # slot: independent output buffers (pipelined serving)
         plan = self._plans.get(key)
         if plan is None:
             plan = self._plans[key] = self._build_plan(b, h, w, x, src_is_u8, fused)
@@ -301,16 +301,18 @@ class PoseProposalNet:
 
     __call__ = forward
 
-    def forward_u8(self, frames: torch.Tensor, fused_decode: bool = False):
+    def forward_u8(self, frames: torch.Tensor, fused_decode: bool = False, slot: int = 0):
         """Fused rt_test.py:97-101 + forward: u8 [B,H,W,3] RGB frames on the device -> head.
 
         With ``fused_decode=True`` the head conv's epilogue runs the decode's limb arg-max itself and the
         17.5 MB/image head is never written: returns ``(unary f32 [B,6K,H,W], keys i64 [B,E,H,W])`` for
-        ``Decoder.decode_fused`` (results bit-identical to decoding the materialised head)."""
+        ``Decoder.decode_fused`` (results bit-identical to decoding the materialised head).  Plans of different
+        ``slot`` own different output buffers, so a consumer on another stream may still be reading slot 0's
+        outputs while slot 1's forward runs (rt.InferencePipeline)."""
         if not (frames.is_cuda and frames.dtype == torch.uint8 and frames.dim() == 4 and frames.shape[3] == 3):
             raise ValueError("forward_u8 expects a uint8 CUDA tensor [B,H,W,3]")
         x = frames.contiguous()
-        plan = self._plan_for(x, True, fused_decode)
+        plan = self._plan_for(x, True, fused_decode, slot)
         L.check(self._lib.ppn_plan_run(plan.handle, L.current_stream_ptr()), "ppn_plan_run")
         return plan.head
 

@@ -71,3 +71,49 @@ def inference_batch(frames_u8: torch.Tensor, model: PoseProposalNet, decoder: Op
         decoder = D.Decoder(b, (h, w), (frames_u8.shape[1], frames_u8.shape[2]), model.local_grid_size,
                             detection_thresh, device=unary.device)
     return decoder.decode_fused(unary, keys)
+
+
+class InferencePipeline:
+    """Two-deep software pipeline for batched serving: the conv stack of batch i+1 runs on the caller's stream
+    while the latency-bound NMS + limb-parse kernel of batch i (one workgroup per image, 32 of 256 CUs) runs on a
+    side stream.  Each in-flight batch owns its plan outputs and its Decoder (slot 0 / 1); HIP events order the
+    hand-over in both directions, nothing blocks the host.
+
+        pipe = InferencePipeline(model, batch, (S, S))
+        for frames in source:                       # u8 [B,S,S,3] on the device
+            done = pipe.submit(frames)              # DecodeResult of THIS batch, valid once done.ready is reached
+        pipe.flush()                                # or torch.cuda.synchronize()
+
+    `submit` returns the DecodeResult object of the batch just submitted; call `result.ready.synchronize()` (or
+    make a stream wait on it) before reading it.  A slot is reused two submits later."""
+
+    def __init__(self, model: PoseProposalNet, batch: int, insize_hw, detection_thresh: float = 0.15, device=None):
+        self.model = model
+        dev = device if device is not None else model.device
+        h, w = insize_hw[0] // 16, insize_hw[1] // 16
+        self.decoders = [D.Decoder(batch, (h, w), insize_hw, model.local_grid_size, detection_thresh, device=dev)
+                         for _ in range(2)]
+        self.side = torch.cuda.Stream(device=dev)                  # (a high-priority stream measured no better)
+        self.fwd_done = [torch.cuda.Event() for _ in range(2)]
+        self.dec_done = [None, None]
+        self.k = 0
+
+    def submit(self, frames_u8: torch.Tensor) -> D.DecodeResult:
+        k = self.k
+        self.k ^= 1
+        main = torch.cuda.current_stream(frames_u8.device)
+        if self.dec_done[k] is not None:
+            main.wait_event(self.dec_done[k])                  # slot k's previous outputs have been consumed
+        unary, keys = self.model.forward_u8(frames_u8, fused_decode=True, slot=k)
+        self.fwd_done[k].record(main)
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(self.fwd_done[k])
+            res = self.decoders[k].decode_fused(unary, keys)
+            ev = torch.cuda.Event()
+            ev.record(self.side)
+        self.dec_done[k] = ev
+        res.ready = ev
+        return res
+
+    def flush(self):
+        self.side.synchronize()

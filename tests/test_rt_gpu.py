@@ -51,3 +51,33 @@ def test_inference_batch_shards_are_independent(golden_dir):
         assert a["n"] == b["n"]
         for k in ("kp_cell", "limb_arg", "bbox", "score"):
             assert np.array_equal(a[k], b[k])
+
+
+def test_pipelined_inference_equals_serial(golden_dir):
+    """rt.InferencePipeline (decode of batch i on a side stream under the conv stack of batch i+1, two slots of
+    output buffers) must return exactly what the serial path returns, batch after batch, including slot reuse."""
+    from pytorch_pose_proposal_network_amd import rt
+    g = np.load(os.path.join(golden_dir, "forward_d22_96.npz"))
+    stats = {k[3:]: g[k] for k in g.files if k.startswith("bn/")}
+    model, _, _ = rt.network(image_size=96, state_dict=synth.make_state_dict("drn_d_22", 0, bn_stats=stats))
+    batches = [torch.from_numpy(prng.u8_frames(100 + i, 3, (96, 96))).cuda() for i in range(5)]
+    serial = [rt.inference_batch(b, model).to_host() for b in batches]
+    pipe = rt.InferencePipeline(model, 3, (96, 96))
+    results = []
+    # keep two batches in flight: read batch i only after batch i+1 has been submitted
+    prev = None
+    for b in batches:
+        cur = pipe.submit(b)
+        if prev is not None:
+            prev.ready.synchronize()
+            results.append(prev.to_host())
+        prev = cur
+    prev.ready.synchronize()
+    results.append(prev.to_host())
+    pipe.flush()
+    assert sum(r["n"] for res in serial for r in res) > 0
+    for s_, p_ in zip(serial, results):
+        for a, b in zip(s_, p_):
+            assert a["n"] == b["n"]
+            for k in ("kp_cell", "limb_arg", "bbox", "score"):
+                assert np.array_equal(a[k], b[k])
