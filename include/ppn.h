@@ -244,6 +244,9 @@ int ppn_plan_add_stem01(ppn_plan* p, int32_t dtype, int32_t src_is_u8, const voi
                         const float* std_, const float* w1, const float* scale1, const float* shift1, void* out);
 /* Re-point the first layer's input (same shape/dtype as at ppn_plan_add_stem) before a run. */
 int ppn_plan_set_input(ppn_plan* p, const void* src);
+/* Issue every launch of the plan on `stream`.  After two launch-by-launch runs the sequence is captured into a
+ * hipGraph per (input pointer, stream) and later runs are one hipGraphLaunch (PPN_PLAN_GRAPH=0 disables that; a
+ * failed capture falls back to launch-by-launch -- the same kernels either way). */
 int ppn_plan_run(ppn_plan* p, void* stream);
 /* Same as ppn_plan_run but brackets every launch with HIP events on `stream`; ms[i] = duration of launch i.
  * Each launch is issued `repeats` (>= 1) times back to back between its two events and the elapsed time is

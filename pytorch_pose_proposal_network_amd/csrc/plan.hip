@@ -32,7 +32,20 @@ struct ppn_plan {
     };
     std::vector<Op> ops;
     std::vector<hipEvent_t> events;
+    // the launch sequence captured once per (input pointer, stream) into a hipGraph: one graph launch per forward
+    // instead of ~35 kernel launches (smaller inter-kernel gaps on the GPU, no per-launch host work)
+    hipGraphExec_t graph_exec = nullptr;
+    const void* graph_src = nullptr;
+    hipStream_t graph_stream = nullptr;
+    int direct_runs = 0;
+    bool graph_off = false;
 };
+
+static const void* plan_src(const ppn_plan* p) {
+    for (auto& op : p->ops)
+        if (op.kind == 1 || op.kind == 3) return op.src;
+    return nullptr;
+}
 
 static int run_op(ppn_plan::Op& op, hipStream_t st) {
     if (op.kind == 2) {
@@ -119,8 +132,39 @@ extern "C" int ppn_plan_set_input(ppn_plan* p, const void* src) {
 extern "C" int ppn_plan_run(ppn_plan* p, void* stream) {
     if (!p) return ppn::fail(PPN_E_INVALID, "ppn_plan_run: NULL plan");
     hipStream_t st = static_cast<hipStream_t>(stream);
+    static const bool graphs = !(getenv("PPN_PLAN_GRAPH") && atoi(getenv("PPN_PLAN_GRAPH")) == 0);
+    // the first runs go launch by launch (they set kernel attributes, which must not happen inside a capture)
+    if (graphs && !p->graph_off && p->direct_runs >= 2) {
+        const void* src = plan_src(p);
+        if (!p->graph_exec || p->graph_src != src || p->graph_stream != st) {
+            if (p->graph_exec) { (void)hipGraphExecDestroy(p->graph_exec); p->graph_exec = nullptr; }
+            hipGraph_t g = nullptr;
+            bool ok = hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed) == hipSuccess;
+            if (ok) {
+                int rc = PPN_OK;
+                for (auto& op : p->ops)
+                    if ((rc = run_op(op, st))) break;
+                ok = hipStreamEndCapture(st, &g) == hipSuccess && rc == PPN_OK && g;
+            }
+            if (ok) ok = hipGraphInstantiate(&p->graph_exec, g, nullptr, nullptr, 0) == hipSuccess;
+            if (g) (void)hipGraphDestroy(g);
+            if (!ok) {                                   // keep launching directly (same kernels, same results)
+                (void)hipGetLastError();
+                p->graph_exec = nullptr;
+                p->graph_off = true;
+            } else {
+                p->graph_src = src;
+                p->graph_stream = st;
+            }
+        }
+        if (p->graph_exec) {
+            PPN_HIP_CHECK(hipGraphLaunch(p->graph_exec, st));
+            return PPN_OK;
+        }
+    }
     for (auto& op : p->ops)
         if (int rc = run_op(op, st)) return rc;
+    ++p->direct_runs;
     return PPN_OK;
 }
 
@@ -159,6 +203,7 @@ extern "C" const char* ppn_plan_kernel_name(const ppn_plan* p, int32_t i) {
 extern "C" int ppn_plan_destroy(ppn_plan* p) {
     if (!p) return PPN_OK;
     for (auto e : p->events) (void)hipEventDestroy(e);
+    if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
     delete p;
     return PPN_OK;
 }
