@@ -117,3 +117,41 @@ class InferencePipeline:
 
     def flush(self):
         self.side.synchronize()
+
+
+class MultiLaneInference:
+    """Independent inference lanes on separate HIP streams, batches go round-robin: while one lane is in a
+    launch that cannot fill the GPU (the 14-22 us neck convolutions, the last partial round of workgroups of a
+    layer, the one-workgroup-per-image parse kernel, the gap between two dependent launches) the other lane's
+    workgroups take the idle CUs.  Each lane owns its plan outputs (slot) and Decoder; the input hand-over and the
+    result hand-over are HIP events.  Results are bit-identical to the serial path."""
+
+    def __init__(self, model: PoseProposalNet, batch: int, insize_hw, detection_thresh: float = 0.15, device=None,
+                 lanes: int = 2):
+        self.model = model
+        dev = device if device is not None else model.device
+        h, w = insize_hw[0] // 16, insize_hw[1] // 16
+        self.decoders = [D.Decoder(batch, (h, w), insize_hw, model.local_grid_size, detection_thresh, device=dev)
+                         for _ in range(lanes)]
+        self.streams = [torch.cuda.Stream(device=dev) for _ in range(lanes)]
+        self.k = 0
+
+    def submit(self, frames_u8: torch.Tensor) -> D.DecodeResult:
+        k = self.k
+        self.k = (k + 1) % len(self.streams)
+        main = torch.cuda.current_stream(frames_u8.device)
+        ready = torch.cuda.Event()
+        ready.record(main)                                   # the frames are complete on the caller's stream
+        st = self.streams[k]
+        with torch.cuda.stream(st):
+            st.wait_event(ready)
+            unary, keys = self.model.forward_u8(frames_u8, fused_decode=True, slot=k)
+            res = self.decoders[k].decode_fused(unary, keys)
+            ev = torch.cuda.Event()
+            ev.record(st)
+        res.ready = ev
+        return res
+
+    def flush(self):
+        for st in self.streams:
+            st.synchronize()

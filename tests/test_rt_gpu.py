@@ -81,3 +81,32 @@ def test_pipelined_inference_equals_serial(golden_dir):
             assert a["n"] == b["n"]
             for k in ("kp_cell", "limb_arg", "bbox", "score"):
                 assert np.array_equal(a[k], b[k])
+
+
+@pytest.mark.parametrize("lanes", [2, 3])
+def test_multi_lane_inference_equals_serial(golden_dir, lanes):
+    """rt.MultiLaneInference (batches round-robin over independent stream lanes) returns exactly the serial results."""
+    from pytorch_pose_proposal_network_amd import rt
+    g = np.load(os.path.join(golden_dir, "forward_d22_96.npz"))
+    stats = {k[3:]: g[k] for k in g.files if k.startswith("bn/")}
+    model, _, _ = rt.network(image_size=96, state_dict=synth.make_state_dict("drn_d_22", 0, bn_stats=stats))
+    batches = [torch.from_numpy(prng.u8_frames(200 + i, 3, (96, 96))).cuda() for i in range(7)]
+    serial = [rt.inference_batch(b, model).to_host() for b in batches]
+    pipe = rt.MultiLaneInference(model, 3, (96, 96), lanes=lanes)
+    pending, results = [], []
+    for b in batches:
+        pending.append(pipe.submit(b))
+        if len(pending) == lanes:                 # a lane's result must be read before the lane is reused
+            r = pending.pop(0)
+            r.ready.synchronize()
+            results.append(r.to_host())
+    for r in pending:
+        r.ready.synchronize()
+        results.append(r.to_host())
+    pipe.flush()
+    assert len(results) == len(serial)
+    for s_, p_ in zip(serial, results):
+        for a, b in zip(s_, p_):
+            assert a["n"] == b["n"]
+            for k in ("kp_cell", "limb_arg", "bbox", "score"):
+                assert np.array_equal(a[k], b[k])
