@@ -304,7 +304,9 @@ _wgrad_cache = {}
 
 
 def _wgrad_ws(nbytes: int, device) -> torch.Tensor:
-    ws = _wgrad_cache.get(str(device))
+    # one workspace per stream: launches on one stream are ordered, two streams must not share partial sums
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
+    ws = _wgrad_cache.get(key)
     if ws is None or ws.numel() < nbytes:
-        ws = _wgrad_cache[str(device)] = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        ws = _wgrad_cache[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)
     return ws

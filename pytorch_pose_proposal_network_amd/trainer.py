@@ -77,6 +77,9 @@ class PPNTrainer:
         self.criterion = PPNLoss(insize=insize, outsize=(insize[0] // 16, insize[1] // 16))
         self.base: Optional[torch.Tensor] = None
         self._tape = None
+        import os
+        self._side = (torch.cuda.Stream(device=self.device)
+                      if os.environ.get("PPN_TRAIN_SIDE_STREAM", "1") != "0" else None)
 
     # ---- state ------------------------------------------------------------------------------------------------
     def load_state_dict(self, sd):
@@ -138,8 +141,23 @@ class PPNTrainer:
                                        dbeta=self.G[prefix + ".bias"] if keep else None)
         return dx
 
+    def _on_side(self, fn, *tensors):
+        """Run fn() on the side stream once everything queued on the current stream so far is done.  Weight gradients
+        are leaves of the backward graph: nothing downstream waits for them, so they run beside the input-gradient
+        chain and fill the CUs its launches leave idle.  backward() joins the streams at its end."""
+        if self._side is None:
+            return fn()
+        main = torch.cuda.current_stream(self.device)
+        ev = torch.cuda.Event()
+        ev.record(main)
+        for t in tensors:
+            t.record_stream(self._side)                      # the caching allocator must not recycle them early
+        with torch.cuda.stream(self._side):
+            self._side.wait_event(ev)
+            fn()
+
     def _wgrad(self, name, x, dy, k, stride=1, dil=1, pad=0):
-        T.conv_wgrad(x, dy, k, stride, dil, pad, out=self.G[name])
+        self._on_side(lambda: T.conv_wgrad(x, dy, k, stride, dil, pad, out=self.G[name]), x, dy)
 
     # ---- forward -------------------------------------------------------------------------------------------------
     def forward(self, x: torch.Tensor) -> torch.Tensor:
@@ -224,8 +242,10 @@ class PPNTrainer:
         w3p = torch.zeros(cpad, w3.shape[1], 1, 1, dtype=torch.float32, device=self.device)
         w3p[:used] = w3[:used]
         if keep:
-            dw3 = T.conv_wgrad(c["h3"], dz, 1)
-            self.G["conv3.weight"].copy_(dw3[:Ch])
+            def wg3():
+                dw3 = T.conv_wgrad(c["h3"], dz, 1)
+                self.G["conv3.weight"].copy_(dw3[:Ch])
+            self._on_side(wg3, c["h3"], dz)
         dh3 = T.conv_dgrad(dz, w3p, (Ho, Wo))
         dc2 = self._bn_bwd(c["c2"], dh3, "bn2", "lrelu", c["s3"], keep=keep)
         if keep:
@@ -277,12 +297,16 @@ class PPNTrainer:
                 d = u.dil[0]
                 dy = self._bn_bwd(c["y"], g, bnp, "relu", c["saved"])
                 if u.k == 7:
-                    dw8 = T.conv_wgrad(c["x"], dy, 7, 1, 1, 3)            # [16, 8, 7, 7]; input channels 3..7 are zero
-                    self.G[wn].copy_(dw8[:, :3])
+                    def wg0(x8=c["x"], dy=dy, wn=wn):
+                        dw8 = T.conv_wgrad(x8, dy, 7, 1, 1, 3)            # [16, 8, 7, 7]; input channels 3..7 are zero
+                        self.G[wn].copy_(dw8[:, :3])
+                    self._on_side(wg0, c["x"], dy)
                     g = None                                               # the input needs no gradient
                 else:
                     self._wgrad(wn, c["x"], dy, 3, u.stride, d, d)
                     g = T.conv_dgrad(dy, self.P[wn], c["x"].shape[1:3], u.stride, d, d)
+        if self._side is not None:
+            torch.cuda.current_stream(self.device).wait_stream(self._side)   # every weight gradient has landed
         return self.grad
 
     def probe_grad(self, grad_head: torch.Tensor, channels_used: Optional[int] = None) -> torch.Tensor:
