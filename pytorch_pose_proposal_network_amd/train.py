@@ -40,7 +40,7 @@ _ws_cache = {}
 
 
 def _workspace(channels: int, device) -> torch.Tensor:
-    key = (channels, str(device))
+    key = (channels, str(device), torch.cuda.current_stream(device).cuda_stream)     # one per stream (partial sums)
     ws = _ws_cache.get(key)
     if ws is None:
         ws = torch.empty(L.load().ppn_bn_workspace_bytes(channels), dtype=torch.uint8, device=device)

@@ -80,6 +80,8 @@ class PPNTrainer:
         import os
         self._side = (torch.cuda.Stream(device=self.device)
                       if os.environ.get("PPN_TRAIN_SIDE_STREAM", "1") != "0" else None)
+        self._probe_stream = torch.cuda.Stream(device=self.device) if self._side is not None else None
+        self._probe_scratch = None
 
     # ---- state ------------------------------------------------------------------------------------------------
     def load_state_dict(self, sd):
@@ -315,23 +317,31 @@ class PPNTrainer:
         assert kind == "head"
         return self._head_backward(c, grad_head, probe_only=True, channels_used=channels_used)
 
-    def probe_norms(self, head, targets, coeff, ghead) -> torch.Tensor:
+    def _unary_probes(self, head, targets, coeff, scratch):
+        """The four cheap probe passes: (gnorm[0:4] f32[4], sum_{i<4} coeff_i dL_i/dW).  Independent of backward()."""
+        k6 = 6 * cfg.K
+        gn = torch.empty(4, dtype=torch.float32, device=self.device)
+        acc = torch.zeros_like(self.G["conv1.weight"])
+        for i in range(4):
+            self.criterion.unary_backward(head, targets, [1.0 if j == i else 0.0 for j in range(4)], out=scratch)
+            gw = self.probe_grad(scratch, channels_used=k6)
+            gn[i:i + 1] = T.sumsq(gw.view(-1)).sqrt()
+            acc.add_(gw, alpha=float(coeff[i]))
+        return gn, acc
+
+    def probe_norms(self, head, targets, coeff, ghead, unary=None) -> torch.Tensor:
         """gnorm_i = ||dL_i/dW||_2, i = 0..4, AFTER backward() ran with `coeff` (so self.G['conv1.weight'] holds
         sum_i coeff_i dL_i/dW).  The four unary losses touch only the first 6K head channels, so their probe passes
         cost a 128-channel conv3 backward instead of a 7616-channel one; the backward pass is linear in the head
         gradient (BN statistics are fixed by the forward), hence the limb loss's probe gradient is what remains:
             dL_4/dW = (sum_i coeff_i dL_i/dW - sum_{i<4} coeff_i dL_i/dW) / coeff_4
-        -- no fifth pass.  Falls back to the direct pass when coeff_4 is too small to divide by."""
-        k6 = 6 * cfg.K
+        -- no fifth pass.  Falls back to the direct pass when coeff_4 is too small to divide by.
+        `unary`: the result of _unary_probes when it already ran (train_step runs it beside backward())."""
+        gn4, acc = unary if unary is not None else self._unary_probes(head, targets, coeff, ghead)
         gn = torch.empty(5, dtype=torch.float32, device=self.device)
-        rest = self.G["conv1.weight"].clone()
-        for i in range(4):
-            self.criterion.unary_backward(head, targets, [1.0 if j == i else 0.0 for j in range(4)], out=ghead)
-            gw = self.probe_grad(ghead, channels_used=k6)
-            gn[i:i + 1] = T.sumsq(gw.view(-1)).sqrt()
-            rest.sub_(gw, alpha=float(coeff[i]))
+        gn[:4] = gn4
         if coeff[4] > 1e-3 * max(coeff):
-            rest.div_(float(coeff[4]))
+            rest = (self.G["conv1.weight"] - acc) / float(coeff[4])
         else:
             _, g4 = self.criterion.forward_backward(head, targets, coeff=[0.0, 0.0, 0.0, 0.0, 1.0])
             rest = self.probe_grad(g4)
@@ -347,8 +357,24 @@ class PPNTrainer:
         if self.base is None:
             self.base = losses.clone()                                   # get_baseloss stand-in: L_i(step 0)
         coeff = [v / 5.0 for v in w]
+        unary = None
+        if self._probe_stream is not None:
+            # the four unary probe passes are small launches that depend only on the forward: they run on their own
+            # stream underneath the backward pass
+            main = torch.cuda.current_stream(self.device)
+            if self._probe_scratch is None or self._probe_scratch.shape != head.shape:
+                self._probe_scratch = torch.empty_like(head)
+            ev = torch.cuda.Event()
+            ev.record(main)
+            with torch.cuda.stream(self._probe_stream):
+                self._probe_stream.wait_event(ev)
+                unary = self._unary_probes(head, targets, coeff, self._probe_scratch)
         self.backward(ghead)
-        gn = self.probe_norms(head, targets, coeff, ghead)               # ghead is free to be overwritten now
+        if unary is not None:
+            torch.cuda.current_stream(self.device).wait_stream(self._probe_stream)
+            for t in unary:
+                t.record_stream(torch.cuda.current_stream(self.device))
+        gn = self.probe_norms(head, targets, coeff, ghead, unary=unary)
         self.task.step(losses, gn, self.base, group=group)               # optimizerR.step + all-reduce + renormalise
         scale = T.allreduce_mean_(self.grad, group=group)                # one RCCL call for every gradient
         self.opt.step(self.grad, grad_scale=scale)                       # optimizerM.step
