@@ -187,8 +187,13 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--layers", action="store_true", help="print the per-layer table to stderr")
+    ap.add_argument("--lanes", type=int, default=int(os.environ.get("PPN_LANES", "2")),
+                    help="stream lanes successive steps alternate between (rt.MultiLaneInference); 1 = one lane with "
+                         "the same kernels (what the rocprofv3 per-kernel durations are compared with)")
+    ap.add_argument("--tile-policy", type=int, default=0, choices=[0, 1],
+                    help="1 = conv tiles by efficiency alone (ppn_set_conv_tile_policy; +4 %% with two lanes)")
     ap.add_argument("--no-pipeline", action="store_true",
-                    help="run the decode kernel on the same stream as the conv stack (no overlap across steps)")
+                    help="plain serial path on the caller's stream: forward, then decode (single-stream tile policy)")
     ap.add_argument("--materialize-head", action="store_true",
                     help="write the f32 head tensor [B,7605,24,24] and decode it with the stand-alone arg-max kernel "
                          "(model.forward + get_humans_by_feature path) instead of the fused inference path")
@@ -231,9 +236,8 @@ def main():
     pipe = None
     if fused and not args.no_pipeline:
         from pytorch_pose_proposal_network_amd import rt
-        lanes = int(os.environ.get("PPN_LANES", "2"))         # tuning knob: 1 = decode-only overlap
-        pipe = (rt.MultiLaneInference(net, B, (S, S), device=dev, lanes=lanes) if lanes > 1 else
-                rt.InferencePipeline(net, B, (S, S), device=dev))
+        pipe = rt.MultiLaneInference(net, B, (S, S), device=dev, lanes=max(1, args.lanes),
+                                     tile_policy=args.tile_policy)
 
     def step():
         if pipe is not None:   # conv stack of step i+1 overlaps the NMS/limb-parse kernel of step i (side stream)
@@ -245,7 +249,7 @@ def main():
         return dec(head)
 
     if pipe is not None:            # set-up, not measurement: every lane's plan reaches its captured-graph state
-        for _ in range(3 * max(1, int(os.environ.get("PPN_LANES", "2")))):
+        for _ in range(3 * max(1, args.lanes)):
             step()
         torch.cuda.synchronize(dev)
     for _ in range(args.warmup):
@@ -274,6 +278,7 @@ def main():
     result = None
     if rank == 0:
         # ---- per-kernel durations: HIP events on the launch stream around every launch ----------------
+        # per-launch durations with one launch in flight (what rocprofv3 shows for `--lanes 1`)
         agg, table = {}, []
         reps = 5
         for r in range(reps):
@@ -319,6 +324,8 @@ def main():
             "roofline": {"bound": "mfma", "kernel": dk, "launches_per_step": dn // reps,
                          "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4),
+                         "timing": "HIP events on the launch stream, one launch in flight (as `--lanes 1`; with two "
+                                   "lanes two dispatches share the GPU and each one's begin-to-end time doubles)",
                          "traffic": (pmc_traffic(dk) or {}).get("bytes_per_launch"),
                          "traffic_source": (pmc_traffic(dk) or {}).get("source"),
                          "avg_launch_us": round(dms / dn * 1e3, 2),

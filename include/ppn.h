@@ -207,6 +207,12 @@ int ppn_conv_tiling(int32_t dtype, int32_t cin, int32_t cout, int32_t ksize, int
 
 int ppn_conv2d_fused(const ppn_conv_desc* d, void* stream);
 
+/* Process-wide tile choice of the large-tile convolution kernel.  0 (default): one launch at a time -- tiles are
+ * sized so that the workgroup count fills whole rounds of the 256 CUs.  1: several launches are in flight on
+ * different streams (rt.MultiLaneInference) -- a partial last round is filled by the other stream's workgroups, so
+ * the most efficient tile shape is taken regardless of the round count (measured +4..5 % with two lanes). */
+int ppn_set_conv_tile_policy(int32_t policy);
+
 /*
  * First layer (drn.py:123-128 layer0: 7x7 conv 3->16, BN, ReLU) with the input normalisation of
  * rt_test.py:97-101 / aug.py:149-153 fused into the load.

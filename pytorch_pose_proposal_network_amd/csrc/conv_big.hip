@@ -585,6 +585,8 @@ namespace ppnconv {
 // Pick the tile: channels 256 / 128 / 64 by Cout, pixel height so that the fewest CU-rounds are wasted
 // (256 CUs; one workgroup per CU, two for the 64-channel tile whose LDS footprint is 80 KB).
 // PPN_CONV_TILE="bp,bc" overrides the choice for every eligible layer (tuning knob).
+static int g_tile_policy = getenv("PPN_CONV_CONT") ? 1 : 0;
+
 bool big_tile_for(int cout, long long m, BigTile* out) {
     if (cout < 64) return false;
     static const char* ov = getenv("PPN_CONV_TILE");
@@ -615,7 +617,10 @@ bool big_tile_for(int cout, long long m, BigTile* out) {
     for (const Cand& cd : cands) {
         if (cd.bc > bc_max || cd.bc < bc_min) continue;
         const long long tiles = ((m + cd.bp - 1) / cd.bp) * ((cout + cd.bc - 1) / cd.bc);
-        const double cost = (double)((tiles + 255) / 256) * cd.bp * cd.bc / cd.eff;
+        // policy 1 (several launches in flight on different streams, ppn_set_conv_tile_policy): another stream's
+        // workgroups fill a partial last round, so only the tile's efficiency counts
+        const double rounds = g_tile_policy == 1 ? (double)tiles / 256.0 : (double)((tiles + 255) / 256);
+        const double cost = rounds * cd.bp * cd.bc / cd.eff;
         if (cost < best) { best = cost; out->bp = cd.bp; out->bc = cd.bc; }
     }
     return true;
@@ -631,3 +636,9 @@ int launch_big(const ConvKArgs& a, int dtype, BigTile t, hipStream_t st, const c
 }
 
 }  // namespace ppnconv
+
+extern "C" int ppn_set_conv_tile_policy(int32_t policy) {
+    if (policy != 0 && policy != 1) return ppn::fail(PPN_E_INVALID, "ppn_set_conv_tile_policy: 0 or 1");
+    ppnconv::g_tile_policy = policy;
+    return PPN_OK;
+}

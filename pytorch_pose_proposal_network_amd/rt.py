@@ -127,7 +127,7 @@ class MultiLaneInference:
     result hand-over are HIP events.  Results are bit-identical to the serial path."""
 
     def __init__(self, model: PoseProposalNet, batch: int, insize_hw, detection_thresh: float = 0.15, device=None,
-                 lanes: int = 2):
+                 lanes: int = 2, tile_policy: int = 0):
         self.model = model
         dev = device if device is not None else model.device
         h, w = insize_hw[0] // 16, insize_hw[1] // 16
@@ -135,6 +135,17 @@ class MultiLaneInference:
                          for _ in range(lanes)]
         self.streams = [torch.cuda.Stream(device=dev) for _ in range(lanes)]
         self.k = 0
+        # tile_policy 1: conv tiles chosen by efficiency alone instead of whole rounds of workgroups (process-wide
+        # setting of libppn, restored by close()); measured +4 % with two lanes, but the per-launch (one in flight)
+        # durations of those tiles are worse, so the default keeps the single-stream choice
+        from . import lib as L
+        self._policy = tile_policy
+        L.check(L.load().ppn_set_conv_tile_policy(tile_policy), "ppn_set_conv_tile_policy")
+
+    def close(self):
+        from . import lib as L
+        self.flush()
+        L.check(L.load().ppn_set_conv_tile_policy(0), "ppn_set_conv_tile_policy")
 
     def submit(self, frames_u8: torch.Tensor) -> D.DecodeResult:
         k = self.k

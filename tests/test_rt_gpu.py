@@ -103,7 +103,7 @@ def test_multi_lane_inference_equals_serial(golden_dir, lanes):
     for r in pending:
         r.ready.synchronize()
         results.append(r.to_host())
-    pipe.flush()
+    pipe.close()                                  # restores the single-stream tile policy
     assert len(results) == len(serial)
     for s_, p_ in zip(serial, results):
         for a, b in zip(s_, p_):
