@@ -310,3 +310,48 @@ def _wgrad_ws(nbytes: int, device) -> torch.Tensor:
     if ws is None or ws.numel() < nbytes:
         ws = _wgrad_cache[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)
     return ws
+
+
+class BucketedAllReduce:
+    """SUM all-reduce of one flat gradient buffer in a few large buckets, each issued (async) as soon as the
+    backward pass has produced every gradient in it, so the exchange runs underneath the rest of the backward.
+
+    The flat buffer is in forward (named_parameters) order and the backward fills it from the END towards the front:
+    `ready(offset)` says "every element at index >= offset is final".  Buckets are contiguous tail-to-head slices of
+    `bucket_elems` elements (default 8 M f32 = 32 MB: xGMI is point-to-point, a ring all-reduce is bound per link, so
+    a handful of large messages beats many small ones).  `finish()` issues what is left, waits for all buckets and
+    returns the 1/world factor the optimiser kernel applies (reduce_tensor of main.py:1233-1238 without its clone and
+    divide passes).  Without an initialised process group (or world size 1) everything is a no-op."""
+
+    def __init__(self, flat: torch.Tensor, bucket_elems: int = 8 * 1024 * 1024, group=None):
+        import torch.distributed as dist
+        self.flat, self.group = flat, group
+        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.world = dist.get_world_size(group) if self.enabled else 1
+        n = flat.numel()
+        self.bounds = list(range(n, 0, -bucket_elems)) + [0]          # n = b0 > b1 > ... > 0
+        self.next = 0                                                  # bucket [bounds[next+1], bounds[next]) is next
+        self.handles = []
+
+    def ready(self, offset: int, before_issue=None):
+        """Everything at index >= offset is final.  `before_issue()` (optional) is called once before a bucket is
+        issued -- e.g. to make the current stream wait for side streams that also wrote gradients."""
+        if not self.enabled:
+            return
+        import torch.distributed as dist
+        called = False
+        while self.next + 1 < len(self.bounds) and self.bounds[self.next + 1] >= offset:
+            if before_issue is not None and not called:
+                before_issue()
+                called = True
+            lo, hi = self.bounds[self.next + 1], self.bounds[self.next]
+            self.handles.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group,
+                                                async_op=True))
+            self.next += 1
+
+    def finish(self, before_issue=None) -> float:
+        self.ready(0, before_issue)
+        for h in self.handles:
+            h.wait()
+        self.handles, self.next = [], 0
+        return 1.0 / self.world

@@ -2,7 +2,8 @@
 
 `PPNTrainer` keeps every parameter of the reference's PoseProposalNet(arch) in ONE flat f32 buffer (in
 `model.named_parameters()` order, so `params[-13]` is the head's conv1.weight as in main.py:704) with a matching
-flat gradient buffer: the data-parallel exchange is a single RCCL all-reduce and the optimiser a single launch.
+flat gradient buffer: the data-parallel exchange is a few 32 MB RCCL all-reduces of slices of that buffer, issued while
+the backward pass is still running, and the optimiser a single launch.
 Forward and backward are explicit: a tape of saved activations per unit (arch._units), train-mode BatchNorm with
 batch statistics (train.py / csrc/train.hip), convolutions, input gradients and weight gradients on the MFMA
 kernels (csrc/conv*.hip, csrc/wgrad.hip), the loss and its gradient from csrc/loss.hip.  There is no autograd and
@@ -56,11 +57,13 @@ class PPNTrainer:
         self.grad = torch.zeros(n_total, dtype=torch.float32, device=self.device)
         self.P: Dict[str, torch.Tensor] = {}
         self.G: Dict[str, torch.Tensor] = {}
+        self.offset: Dict[str, int] = {}
         o = 0
         for n in self.param_names:
             k = int(np.prod(shapes[n]))
             self.P[n] = self.flat[o:o + k].view(shapes[n])
             self.G[n] = self.grad[o:o + k].view(shapes[n])
+            self.offset[n] = o
             o += k
         self.buffers: Dict[str, torch.Tensor] = {}
         for n, shp in spec:
@@ -82,6 +85,7 @@ class PPNTrainer:
                       if os.environ.get("PPN_TRAIN_SIDE_STREAM", "1") != "0" else None)
         self._probe_stream = torch.cuda.Stream(device=self.device) if self._side is not None else None
         self._probe_scratch = None
+        self._conv1_local = None
 
     # ---- state ------------------------------------------------------------------------------------------------
     def load_state_dict(self, sd):
@@ -222,6 +226,12 @@ class PPNTrainer:
                 cur = head
         self.num_batches_tracked += 1
         self._tape = tape
+        # flat-buffer offset of the unit that follows each unit in forward order (for the bucketed exchange)
+        self._next_offset = {}
+        nxt = self.flat.numel()
+        for kind, u, _ in reversed(tape):
+            self._next_offset[id(u)] = nxt
+            nxt = self._unit_offset(kind, u)
         return cur
 
     # ---- backward ------------------------------------------------------------------------------------------------
@@ -270,14 +280,37 @@ class PPNTrainer:
         dh0 = T.conv_dgrad(da1, self.P["conv1x1_1.weight"], (Ho, Wo))
         return self._bn_bwd(c["R"], dh0, "bn0_1", "lrelu", c["s0"], dx_add=da3)
 
-    def backward(self, grad_head: torch.Tensor):
-        """d(sum_i coeff_i L_i)/d(theta) into self.grad, given d/d(head) from the loss kernel."""
+    def _unit_offset(self, kind, u) -> int:
+        """First element of the flat buffer that belongs to this unit (its parameters are contiguous)."""
+        if kind == "head":
+            return self.offset["conv1x1_1.weight"]
+        if kind == "basic":
+            return self.offset[u.prefix + ".conv1.weight"]
+        return self.offset[f"{u.prefix}.{u.conv_idx}.weight"]
+
+    def backward(self, grad_head: torch.Tensor, exchange: Optional["T.BucketedAllReduce"] = None):
+        """d(sum_i coeff_i L_i)/d(theta) into self.grad, given d/d(head) from the loss kernel.  `exchange`: buckets
+        of the flat buffer are all-reduced as soon as the units that own them are done (the buffer is in forward
+        order, the backward completes it from its end)."""
         if self._tape is None:
             raise RuntimeError("backward() needs a forward() first")
+
+        def join_side():
+            if self._side is not None:
+                torch.cuda.current_stream(self.device).wait_stream(self._side)
+
         g = grad_head
         for kind, u, c in reversed(self._tape):
+            if exchange is not None and kind != "head":
+                # every unit AFTER this one in forward order has been processed: its slice of the buffer is final
+                nxt = self._next_offset[id(u)]
+                exchange.ready(nxt, before_issue=join_side)
             if kind == "head":
                 g = self._head_backward(c, g, probe_only=False)
+                if exchange is not None and exchange.enabled:
+                    # the GradNorm probes need THIS rank's d loss/d conv1.weight; keep it before its bucket is summed
+                    join_side()
+                    self._conv1_local = self.G["conv1.weight"].clone()
             elif kind == "basic":
                 p = u.prefix
                 hw = c["x"].shape[1:3]
@@ -341,7 +374,8 @@ class PPNTrainer:
         gn = torch.empty(5, dtype=torch.float32, device=self.device)
         gn[:4] = gn4
         if coeff[4] > 1e-3 * max(coeff):
-            rest = (self.G["conv1.weight"] - acc) / float(coeff[4])
+            local = self._conv1_local if self._conv1_local is not None else self.G["conv1.weight"]
+            rest = (local - acc) / float(coeff[4])
         else:
             _, g4 = self.criterion.forward_backward(head, targets, coeff=[0.0, 0.0, 0.0, 0.0, 1.0])
             rest = self.probe_grad(g4)
@@ -369,14 +403,17 @@ class PPNTrainer:
             with torch.cuda.stream(self._probe_stream):
                 self._probe_stream.wait_event(ev)
                 unary = self._unary_probes(head, targets, coeff, self._probe_scratch)
-        self.backward(ghead)
+        # gradient exchange: 32 MB buckets of the flat buffer go out over RCCL as the backward completes them
+        exchange = T.BucketedAllReduce(self.grad, group=group)
+        self.backward(ghead, exchange)
+        scale = exchange.finish()
         if unary is not None:
             torch.cuda.current_stream(self.device).wait_stream(self._probe_stream)
             for t in unary:
                 t.record_stream(torch.cuda.current_stream(self.device))
         gn = self.probe_norms(head, targets, coeff, ghead, unary=unary)
         self.task.step(losses, gn, self.base, group=group)               # optimizerR.step + all-reduce + renormalise
-        scale = T.allreduce_mean_(self.grad, group=group)                # one RCCL call for every gradient
         self.opt.step(self.grad, grad_scale=scale)                       # optimizerM.step
         self._tape = None
+        self._conv1_local = None
         return losses, self.task.w

@@ -154,3 +154,43 @@ def test_two_rank_gloo_gradient_exchange(tmp_path):
     assert scale == 0.5
     assert abs(total - float(((grads[0] + grads[1]) / 2).sum())) < 1e-4
     assert w == [1.5, 3.0, 0.75, 2.25, 0.375]
+
+
+_BUCKET_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as dist
+from pytorch_pose_proposal_network_amd import train as T
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+n = 1000
+flat = torch.arange(n, dtype=torch.float32) * (rank + 1)
+ex = T.BucketedAllReduce(flat, bucket_elems=300)           # buckets [700,1000) [400,700) [100,400) [0,100)
+calls = []
+ex.ready(950)                                               # nothing complete yet
+a = len(ex.handles)
+ex.ready(650, before_issue=lambda: calls.append(1))         # first bucket [700,1000) is final
+b = len(ex.handles)
+ex.ready(120)                                               # one more: [400,700); [100,400) still has open entries
+c = len(ex.handles)
+scale = ex.finish()
+if rank == 0:
+    print("RESULT", a, b, c, len(calls), scale, float(flat.sum()))
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def test_two_rank_gloo_bucketed_exchange(tmp_path):
+    """BucketedAllReduce: tail-to-head buckets are issued as `ready(offset)` passes their lower bound, the whole
+    buffer ends up summed over the ranks, the 1/world factor is returned for the optimiser launch."""
+    script = tmp_path / "bucket_worker.py"
+    script.write_text(_BUCKET_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29621", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    line = [l for l in outs[0].splitlines() if l.startswith("RESULT")][0].split()
+    a, b, c, ncalls, scale, total = int(line[1]), int(line[2]), int(line[3]), int(line[4]), float(line[5]), float(line[6])
+    assert (a, b, c, ncalls) == (0, 1, 2, 1)
+    assert scale == 0.5 and total == 3 * sum(range(1000))
