@@ -106,6 +106,67 @@ class PPNTrainer:
                 sd[n[:-len("running_var")] + "num_batches_tracked"] = torch.tensor(self.num_batches_tracked)
         return sd
 
+    # ---- checkpoints in the reference's format (main.py:436-451 save, 302-331 resume) ---------------------------------
+    def checkpoint(self, epoch: int = 0, best_AP: float = 0.0, arch_field: str = "resnet18") -> Dict:
+        """The dict main.py:443-451 hands to torch.save: model state_dict, weight_model state_dict ([1,5] `weight`),
+        and torch.optim.Adam state_dicts of optimizerM / optimizerR (per-parameter step / exp_avg / exp_avg_sq, CPU
+        tensors).  `arch_field` is what the reference stores there: its unused --arch default (main.py:68, 445)."""
+        def adam_state(opt_lr, betas, eps, wd, step, items):
+            state = {i: {"step": torch.tensor(float(step)), "exp_avg": m.detach().cpu().clone(),
+                         "exp_avg_sq": v.detach().cpu().clone()} for i, (m, v) in enumerate(items)} if step > 0 else {}
+            group = {"lr": opt_lr, "betas": tuple(betas), "eps": eps, "weight_decay": wd, "amsgrad": False,
+                     "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                     "params": list(range(len(items)))}
+            return {"state": state, "param_groups": [group]}
+
+        shapes = {n: self.P[n].shape for n in self.param_names}
+        items = []
+        for n in self.param_names:
+            o, k = self.offset[n], self.P[n].numel()
+            items.append((self.opt.exp_avg[o:o + k].view(shapes[n]), self.opt.exp_avg_sq[o:o + k].view(shapes[n])))
+        return {
+            "epoch": epoch, "arch": arch_field, "best_AP": best_AP,
+            "state_dict": {k: v.detach().cpu() for k, v in self.state_dict().items()},
+            "weight_state_dict": {"weight": self.task.w.detach().cpu().view(1, 5).clone()},
+            "optimizerM": adam_state(self.opt.lr, self.opt.betas, self.opt.eps, self.opt.weight_decay,
+                                     self.opt.step_count, items),
+            "optimizerR": adam_state(self.task.lr, self.task.betas, self.task.eps, 0.0, self.task.step_count,
+                                     [(self.task.exp_avg.view(1, 5), self.task.exp_avg_sq.view(1, 5))]),
+        }
+
+    def load_checkpoint(self, ckpt: Dict) -> int:
+        """Resume from a reference-format checkpoint (with or without DDP's `module.` prefixes); returns the epoch."""
+        self.load_state_dict(ckpt["state_dict"])
+        self.task.w.copy_(torch.as_tensor(ckpt["weight_state_dict"]["weight"]).reshape(5).float())
+
+        def restore(sd, items, set_step):
+            st = sd.get("state", {})
+            step = 0
+            for i, (m, v) in enumerate(items):
+                e = st.get(i, st.get(str(i)))
+                if e is None:
+                    m.zero_(); v.zero_()
+                    continue
+                m.copy_(torch.as_tensor(e["exp_avg"]).reshape(m.shape).float())
+                v.copy_(torch.as_tensor(e["exp_avg_sq"]).reshape(v.shape).float())
+                step = max(step, int(float(e["step"])))
+            set_step(step, sd["param_groups"][0])
+
+        items = []
+        for n in self.param_names:
+            o, k = self.offset[n], self.P[n].numel()
+            items.append((self.opt.exp_avg[o:o + k], self.opt.exp_avg_sq[o:o + k]))
+
+        def set_m(step, g):
+            self.opt.step_count, self.opt.lr = step, float(g["lr"])
+
+        def set_r(step, g):
+            self.task.step_count, self.task.lr = step, float(g["lr"])
+
+        restore(ckpt["optimizerM"], items, set_m)
+        restore(ckpt["optimizerR"], [(self.task.exp_avg, self.task.exp_avg_sq)], set_r)
+        return int(ckpt.get("epoch", 0))
+
     def get_baseloss(self, batches):
         """main.py:578-621: the five losses in EVAL mode (running BN statistics) averaged over `batches`, an iterable
         of (x f32[B,3,H,W], targets dict); sets and returns self.base (f32[5] on the device)."""

@@ -200,3 +200,42 @@ def test_get_baseloss_matches_eval_oracle():
         batches.append((torch.as_tensor(x).to(dev), {k: torch.from_numpy(v).to(dev) for k, v in tg.items()}))
     base = tr.get_baseloss(batches).cpu().numpy()
     assert np.allclose(base, ref / 2, rtol=2e-4), (base, ref / 2)
+
+
+def test_checkpoint_roundtrip_and_torch_compatibility(tmp_path):
+    """PPNTrainer.checkpoint() is the dict of main.py:443-451: torch.optim.Adam / nn.Linear / the reference's state_dict
+    names load it; resuming from it continues bit-identically."""
+    from pytorch_pose_proposal_network_amd import lib as L, arch as A
+    from pytorch_pose_proposal_network_amd.trainer import PPNTrainer
+    g, sd, x, tg, size = _setup()
+    dev = torch.device("cuda")
+    xd = torch.as_tensor(x).to(dev)
+    tgd = {k: torch.from_numpy(v).to(dev) for k, v in tg.items()}
+    tr = PPNTrainer("drn_d_22", sd, compute_dtype=L.PPN_F32, insize=(size, size))
+    tr.train_step(xd, tgd)
+    tr.train_step(xd, tgd)
+    path = tmp_path / "PPN_model_2.pth.tar"
+    torch.save(tr.checkpoint(epoch=2, best_AP=0.25), path)
+    ck = torch.load(path, weights_only=False)
+    assert set(ck) == {"epoch", "arch", "state_dict", "weight_state_dict", "best_AP", "optimizerM", "optimizerR"}
+    assert len(ck["state_dict"]) == 207
+    # torch objects of the reference accept it
+    wm = torch.nn.Linear(5, 1, bias=False)
+    wm.load_state_dict(ck["weight_state_dict"])
+    params = [torch.nn.Parameter(torch.zeros(shp)) for n, shp in A.param_spec("drn_d_22")
+              if not n.endswith(("running_mean", "running_var", "num_batches_tracked"))]
+    optM = torch.optim.Adam(params, lr=7e-4)
+    optM.load_state_dict(ck["optimizerM"])
+    assert int(optM.state[params[0]]["step"]) == 2
+    optR = torch.optim.Adam(wm.parameters(), lr=7e-4)
+    optR.load_state_dict(ck["optimizerR"])
+    # resume: a fresh trainer loaded from the checkpoint takes the same third step
+    tr2 = PPNTrainer("drn_d_22", sd, compute_dtype=L.PPN_F32, insize=(size, size))
+    assert tr2.load_checkpoint(ck) == 2
+    tr2.base = tr.base.clone()
+    tr2.num_batches_tracked = tr.num_batches_tracked
+    l1, w1 = tr.train_step(xd, tgd)
+    l2, w2 = tr2.train_step(xd, tgd)
+    torch.cuda.synchronize()
+    assert torch.equal(l1, l2) and torch.equal(w1, w2)
+    assert torch.equal(tr.flat, tr2.flat) and torch.equal(tr.opt.exp_avg_sq, tr2.opt.exp_avg_sq)
