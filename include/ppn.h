@@ -7,6 +7,10 @@
  *     rt_test.inference                  rt_test.py:87-147  (normalise, forward, slice, decode)
  *     datatest.get_humans_by_feature     datatest.py:74-132 (decode + root NMS + limb parse)
  *     datatest.non_maximum_suppression   datatest.py:134-160
+ *     PPNLoss.forward + loss.backward()  main.py:125-216, 664-683 (fused loss forward + gradient)
+ *     train()                            main.py:623-777   (train-mode BN, conv gradients, GradNorm task weights,
+ *                                                           Adam; see "Training building blocks" below)
+ *     KeypointsDataset target encoding   dataset.py:96-185
  * The entry points below are what a ctypes binding for those functions binds
  * (INTEGRATION.md shows the stub).  Conventions:
  *   - every function returns 0 on success, a negative PPN_E_* code on error;
