@@ -66,15 +66,17 @@ __device__ __forceinline__ void vec_to_arr<1>(const float& v, float* a) {
 template <int V>
 __global__ void __launch_bounds__(1024)
 limb_argmax_kernel(const float* __restrict__ head, int* __restrict__ out_arg, int C, int e_chan0, int S,
-                   int ncell, int Q, int NS, int E) {
+                   int ncell, int ncl, int Q, int NS, int E) {
+    // grid = (E, batch, cell groups): a workgroup owns `ncl` consecutive cells of one (edge, image) and streams all S
+    // channels of them; cell groups only exist to cut the work finer than E*batch workgroups (smooth tail)
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* s_val = reinterpret_cast<float*>(smem);                 // [NS][ncell]
-    int* s_idx = reinterpret_cast<int*>(smem + sizeof(float) * NS * ncell);
+    float* s_val = reinterpret_cast<float*>(smem);                 // [NS][ncl]
+    int* s_idx = reinterpret_cast<int*>(smem + sizeof(float) * NS * ncl);
 
-    const int edge = blockIdx.x, b = blockIdx.y;
+    const int edge = blockIdx.x, b = blockIdx.y, cell0 = blockIdx.z * ncl;
     const int t = threadIdx.x;
     const int q = t % Q, r = t / Q;
-    const float* base = head + ((size_t)b * C + e_chan0 + (size_t)edge * S) * ncell;
+    const float* base = head + ((size_t)b * C + e_chan0 + (size_t)edge * S) * ncell + cell0;
     using vec = typename VecT<V>::type;
 
     if (r < NS) {
@@ -99,20 +101,20 @@ limb_argmax_kernel(const float* __restrict__ head, int* __restrict__ out_arg, in
         }
 #pragma unroll
         for (int i = 0; i < V; ++i) {
-            s_val[r * ncell + V * q + i] = best[i];
-            s_idx[r * ncell + V * q + i] = bidx[i];
+            s_val[r * ncl + V * q + i] = best[i];
+            s_idx[r * ncl + V * q + i] = bidx[i];
         }
     }
     __syncthreads();
-    for (int cell = t; cell < ncell; cell += blockDim.x) {
+    for (int cell = t; cell < ncl; cell += blockDim.x) {
         float bv = s_val[cell];
         int bi = s_idx[cell];
         for (int rr = 1; rr < NS; ++rr) {
-            float v = s_val[rr * ncell + cell];
-            int i = s_idx[rr * ncell + cell];
+            float v = s_val[rr * ncl + cell];
+            int i = s_idx[rr * ncl + cell];
             if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }     // lowest s wins ties
         }
-        out_arg[((size_t)b * E + edge) * ncell + cell] = bi;
+        out_arg[((size_t)b * E + edge) * ncell + cell0 + cell] = bi;
     }
 }
 
@@ -285,6 +287,24 @@ parse_kernel(DecodeParams p, const float* __restrict__ head, const int* __restri
         return r;
     };
 
+    // The tree walk at the end needs delta = resp*conf for every (keypoint, cell) and this image's arg-max map in
+    // LDS.  Their global loads are issued HERE, into registers, so that their latency passes under the candidate /
+    // sort / NMS phases (which own the LDS region the tables will overlay); the LDS writes follow the NMS.
+    constexpr int PF = 20;                                            // table entries per thread kept in registers
+    const int nd = K * ncell, na = E * ncell, pstride = blockDim.x;
+    const int* am_img = argmap + (size_t)b * E * ncell;
+    const unsigned long long* key_img = p.keys + (size_t)b * E * ncell;
+    float pf_d[PF];
+    int pf_a[PF];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        const int i = t + u * pstride;
+        const float r_ = i < nd ? img[i] : 0.f, c_ = i < nd ? img[(size_t)nd + i] : 0.f;
+        pf_d[u] = r_ * c_;                                            // rt_test.py:130
+        if (p.keys) pf_a[u] = i < na ? (int)(0xFFFFFFFFu - (unsigned)key_img[i]) : 0;   // key = value<<32 | ~s
+        else pf_a[u] = i < na ? am_img[i] : 0;
+    }
+
     PPN_DT(0);
     // 1. candidates: delta[0] > thr, row-major (datatest.py:89)
     float d0 = 0.0f;
@@ -311,6 +331,12 @@ parse_kernel(DecodeParams p, const float* __restrict__ head, const int* __restri
         s_area[rank] = box_area(bb);
         s_cell[rank] = t;
     }
+    // the arg-max table has its own LDS region: park the prefetched entries there before the NMS needs registers
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        const int i = t + u * pstride;
+        if (i < na) s_am[i] = (unsigned short)pf_a[u];
+    }
     __syncthreads();
     PPN_DT(2);
     // 3./4. greedy NMS on the root boxes (datatest.py:134-160)
@@ -326,9 +352,14 @@ parse_kernel(DecodeParams p, const float* __restrict__ head, const int* __restri
     if (t < nsel) root_cell = s_cell[s_sel[t]];
     __syncthreads();                                                  // everyone is done with box/key/mask
     if (nsel > 0) {
-        // loads are issued in batches of 8 before their first use so that their latencies overlap
-        const int nd = K * ncell, stride = blockDim.x;
-        for (int i0 = t; i0 < nd; i0 += 8 * stride) {
+        // the first PF entries per thread are already in registers; larger grids finish with batched loads
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int i = t + u * pstride;
+            if (i < nd) s_delta[i] = pf_d[u];
+        }
+        const int stride = blockDim.x;
+        for (int i0 = t + PF * stride; i0 < nd; i0 += 8 * stride) {
             float r[8], cf[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -339,18 +370,15 @@ parse_kernel(DecodeParams p, const float* __restrict__ head, const int* __restri
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int i = i0 + u * stride;
-                if (i < nd) s_delta[i] = r[u] * cf[u];               // rt_test.py:130
+                if (i < nd) s_delta[i] = r[u] * cf[u];
             }
         }
-        const int* am_img = argmap + (size_t)b * E * ncell;
-        const unsigned long long* key_img = p.keys + (size_t)b * E * ncell;
-        const int na = E * ncell;
-        for (int i0 = t; i0 < na; i0 += 8 * stride) {
+        for (int i0 = t + PF * stride; i0 < na; i0 += 8 * stride) {
             int v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int i = i0 + u * stride;
-                if (p.keys) v[u] = i < na ? (int)(0xFFFFFFFFu - (unsigned)key_img[i]) : 0;   // key = value<<32 | ~s
+                if (p.keys) v[u] = i < na ? (int)(0xFFFFFFFFu - (unsigned)key_img[i]) : 0;
                 else v[u] = i < na ? am_img[i] : 0;
             }
 #pragma unroll
@@ -371,6 +399,24 @@ parse_kernel(DecodeParams p, const float* __restrict__ head, const int* __restri
     __syncthreads();
     bool keep_h = false;
     const float rcpW = 1.0f / (float)W, rcpS = 1.0f / (float)c.sW;
+    // one hop of the walk (datatest.py:110-127): edge e from keypoint s to d for the human whose rows are kp / la
+    auto hop = [&](int pk, unsigned short* kp, unsigned short* la) -> int {
+        const int e = pk & 0xff, s_ = (pk >> 8) & 0xff, d = (pk >> 16) & 0xff;
+        const unsigned short cs = kp[s_];
+        if (cs == NONE) return 0;                                     // parent chain broke earlier
+        const int am = s_am[e * ncell + cs];
+        la[e] = (unsigned short)am;
+        // exact small-integer division through a float reciprocal ((x+0.5)/d is >= 0.5/d from an integer)
+        const int ch_ = (int)(((float)cs + 0.5f) * rcpW), cw_ = (int)cs - ch_ * W;
+        const int ah_ = (int)(((float)am + 0.5f) * rcpS), aw_ = am - ah_ * c.sW;
+        const int jh = ch_ + ah_ - c.sH / 2;
+        const int jw = cw_ + aw_ - c.sW / 2;
+        if (jh < 0 || jw < 0 || jh >= H || jw >= W) return 0;         // datatest.py:118
+        const int cd = jh * W + jw;
+        if (s_delta[d * ncell + cd] < c.det_thr) return 0;            // datatest.py:121 (== passes)
+        kp[d] = (unsigned short)cd;
+        return 1;
+    };
     if (t < nsel) {
         unsigned short* kp = s_kp + (size_t)t * K;
         unsigned short* la = s_la + (size_t)t * E;
@@ -378,24 +424,7 @@ parse_kernel(DecodeParams p, const float* __restrict__ head, const int* __restri
         for (int e = 0; e < E; ++e) la[e] = NONE;
         kp[0] = (unsigned short)root_cell;
         int found = 0;
-        for (int oi = 0; oi < E; ++oi) {
-            const int pk = s_edge[oi];
-            const int e = pk & 0xff, s = (pk >> 8) & 0xff, d = (pk >> 16) & 0xff;
-            const unsigned short cs = kp[s];
-            if (cs == NONE) continue;                                 // parent chain broke earlier
-            const int am = s_am[e * ncell + cs];
-            la[e] = (unsigned short)am;
-            // exact small-integer division through a float reciprocal ((x+0.5)/d is >= 0.5/d from an integer)
-            const int ch_ = (int)(((float)cs + 0.5f) * rcpW), cw_ = (int)cs - ch_ * W;
-            const int ah_ = (int)(((float)am + 0.5f) * rcpS), aw_ = am - ah_ * c.sW;
-            const int jh = ch_ + ah_ - c.sH / 2;
-            const int jw = cw_ + aw_ - c.sW / 2;
-            if (jh < 0 || jw < 0 || jh >= H || jw >= W) continue;     // datatest.py:118
-            const int cd = jh * W + jw;
-            if (s_delta[d * ncell + cd] < c.det_thr) continue;        // datatest.py:121 (== passes)
-            kp[d] = (unsigned short)cd;
-            ++found;
-        }
+        for (int oi = 0; oi < E; ++oi) found += hop(s_edge[oi], kp, la);
         keep_h = c.min_kp <= found;                                   // datatest.py:129
     }
     PPN_DT(5);
@@ -521,7 +550,13 @@ extern "C" int ppn_limb_argmax(const ppn_decode_cfg* cfg, const float* head, int
     const int ncell = cfg->H * cfg->W, S = cfg->sH * cfg->sW;
     const int C = 6 * cfg->K + cfg->E * S;
     const int V = (ncell % 4 == 0 && (reinterpret_cast<uintptr_t>(head) % 16 == 0)) ? 4 : 1;
-    const int Q = ncell / V;
+    // cell groups: cut every (edge, image) into CS pieces of >= 64 cells so that the grid is several times the
+    // 256 CUs x 3 resident workgroups (17 x 32 = 544 workgroups left a tail of half-empty CUs)
+    static const int cs_env = getenv("PPN_ARGMAX_SPLIT") ? atoi(getenv("PPN_ARGMAX_SPLIT")) : 0;
+    int CS = cs_env > 0 ? cs_env : 3;          // measured at 24x24, batch 32: 105 us (1 group) -> 97 us (3 groups)
+    while (CS > 1 && (ncell % (CS * V) != 0 || ncell / CS < 64)) --CS;
+    const int ncl = ncell / CS;
+    const int Q = ncl / V;
     if (Q > 1024) return ppn::fail(PPN_E_UNSUPPORTED, "grid of %d cells is too large for ppn_limb_argmax", ncell);
     int NS = 576 / Q;
     if (NS < 1) NS = 1;
@@ -529,9 +564,9 @@ extern "C" int ppn_limb_argmax(const ppn_decode_cfg* cfg, const float* head, int
     if (NS > S) NS = S;
     int threads = ((NS * Q + 63) / 64) * 64;
     if (threads > 1024) { NS = 1024 / Q; threads = ((NS * Q + 63) / 64) * 64; }
-    const size_t lds = (size_t)NS * ncell * 8;
+    const size_t lds = (size_t)NS * ncl * 8;
     if (lds > 160 * 1024) return ppn::fail(PPN_E_UNSUPPORTED, "limb_argmax LDS %zu too large", lds);
-    dim3 grid(cfg->E, batch);
+    dim3 grid(cfg->E, batch, CS);
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (V == 4) {
         {
@@ -540,7 +575,7 @@ extern "C" int ppn_limb_argmax(const ppn_decode_cfg* cfg, const float* head, int
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         }
         hipLaunchKernelGGL(limb_argmax_kernel<4>, grid, dim3(threads), lds, st, head, out_arg, C, 6 * cfg->K, S,
-                           ncell, Q, NS, cfg->E);
+                           ncell, ncl, Q, NS, cfg->E);
     } else {
         {
             static int max_lds_set = 0;   // the attribute sticks to the function: set it when it grows
@@ -548,7 +583,7 @@ extern "C" int ppn_limb_argmax(const ppn_decode_cfg* cfg, const float* head, int
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         }
         hipLaunchKernelGGL(limb_argmax_kernel<1>, grid, dim3(threads), lds, st, head, out_arg, C, 6 * cfg->K, S,
-                           ncell, Q, NS, cfg->E);
+                           ncell, ncl, Q, NS, cfg->E);
     }
     PPN_LAUNCH_CHECK();
     return PPN_OK;

@@ -8,7 +8,8 @@ LIB = os.path.join(ROOT, "tools", "bin", "libppn_stamp.so")
 
 def build():
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
-    srcs = ["abi.cpp", "decode.hip", "conv.hip", "conv_big.hip", "stem.hip", "stem3x3.hip", "stem01.hip", "plan.hip", "loss.hip"]
+    from pytorch_pose_proposal_network_amd import build as B
+    srcs = [s_ for s_, _ in B.SOURCES]
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-DPPN_STAMP", "-shared", "-o", LIB]
     for s in srcs:
         cmd += (["-x", "hip"] if s.endswith(".cpp") else []) + [os.path.join(CSRC, s)]
