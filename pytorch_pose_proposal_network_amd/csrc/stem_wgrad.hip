@@ -197,7 +197,10 @@ bool stem_wgrad_supported(const ppn_wgrad_desc* d) {
 
 static int stem_wgrad_grid(const ppn_wgrad_desc* d) {
     const long long tiles = (long long)d->batch * ((d->out_h + TH - 1) / TH) * ((d->out_w + TW - 1) / TW);
-    return (int)(tiles < 512 ? tiles : 512);
+    // persistent workgroups: four per CU for the 3x3 layers (37-103 KB of LDS: two to four co-reside and hide each
+    // other's staging latency; 152 -> 124 us on layer1), two for the 7x7 layer (100 KB of LDS: one resident)
+    const long long cap = d->ksize == 7 ? 512 : 1024;
+    return (int)(tiles < cap ? tiles : cap);
 }
 
 size_t stem_wgrad_workspace_bytes(const ppn_wgrad_desc* d) {
