@@ -174,3 +174,72 @@ def synthetic_people(seed: int, insize=(384, 384), max_people: int = 4):
                            visible=vis, size=np.float32(size)))
         p += 64
     return people
+
+
+def eval_case(seed: int, n_images: int = 12, insize=(384, 384)):
+    """A synthetic `pck_object` (main.py:899-990) for the AP evaluation: per image 0..3 ground-truth people and a set
+    of predicted people made from them -- jittered joints (some beyond the PCKh@0.5 radius), dropped joints, a
+    duplicate detection, false positives -- in the formats the reference hands to datatest.evaluation:
+    [fnames, gt_kps f32[P,17,2], humans [{kp: f32[4] (ymin,xmin,ymax,xmax)}], scores [{kp: f32}], gt_bboxes
+    [(cx,cy,w,h)], is_visible, size]."""
+    inW, inH = insize
+    obj = [[], [], [], [], [], [], []]
+    for im in range(n_images):
+        r = prng.uniform01(prng.stream_seed(seed, 10 + im), 4096).astype(np.float64)
+        q = 0
+
+        def nxt(k=1):
+            nonlocal q
+            v = r[q:q + k]
+            q += k
+            return v if k > 1 else float(v[0])
+
+        n_gt = int(nxt() * 4)                                  # 0..3 (frames without people are dropped by the metric)
+        gt_kps, gt_boxes, vis, sizes = [], [], [], []
+        for _ in range(n_gt):
+            cx, cy = 60 + nxt() * (inW - 120), 60 + nxt() * (inH - 120)
+            w, h = 50 + nxt() * 120, 80 + nxt() * 160
+            pts = np.stack([cx + (nxt(17) - 0.5) * w, cy + (nxt(17) - 0.5) * h], 1).astype(np.float32)
+            gt_kps.append(pts)
+            gt_boxes.append((np.float32(cx), np.float32(cy), np.float32(w), np.float32(h)))
+            vis.append(nxt(17) > 0.2)
+            sizes.append(np.float32(8 + nxt() * 16))
+        humans, scores = [], []
+        preds = []
+        for g in range(n_gt):
+            if nxt() < 0.85:
+                preds.append((g, 0.02 + nxt() * 0.1))          # a detection of person g with small jitter
+            if nxt() < 0.25:
+                preds.append((g, 0.3 + nxt() * 0.5))           # a sloppy duplicate
+        n_fp = int(nxt() * 3)
+        for g, jit in preds:
+            cx, cy, w, h = gt_boxes[g]
+            diag = float(np.hypot(w, h))
+            hm, sm = {0: np.array([cy - h / 2, cx - w / 2, cy + h / 2, cx + w / 2], np.float32)}, {0: np.float32(0.3 + 0.7 * nxt())}
+            for k in range(1, 18):
+                if nxt() < 0.12:
+                    continue                                    # joint not found by the limb parse
+                x = gt_kps[g][k - 1, 0] + (nxt() - 0.5) * 2 * jit * diag
+                y = gt_kps[g][k - 1, 1] + (nxt() - 0.5) * 2 * jit * diag
+                s_ = 6 + nxt() * 10
+                hm[k] = np.array([y - s_, x - s_, y + s_, x + s_], np.float32)
+                sm[k] = np.float32(0.15 + 0.85 * nxt())
+            humans.append(hm)
+            scores.append(sm)
+        for _ in range(n_fp):
+            hm, sm = {0: (nxt(4) * inW).astype(np.float32)}, {0: np.float32(nxt())}
+            for k in range(1, 18):
+                if nxt() < 0.5:
+                    c = nxt(2) * inW
+                    hm[k] = np.array([c[1] - 8, c[0] - 8, c[1] + 8, c[0] + 8], np.float32)
+                    sm[k] = np.float32(0.15 + 0.5 * nxt())
+            humans.append(hm)
+            scores.append(sm)
+        obj[0].append(f"img_{seed}_{im}.jpg")
+        obj[1].append(np.stack(gt_kps) if gt_kps else np.zeros((0, 17, 2), np.float32))
+        obj[2].append(humans)
+        obj[3].append(scores)
+        obj[4].append(gt_boxes)
+        obj[5].append(vis)
+        obj[6].append(sizes)
+    return obj

@@ -399,6 +399,27 @@ def make_train(drn, model):
     print("train fixture written: losses", out["losses"], "G", out["G"], "w_final", w_final)
 
 
+def make_eval(datatest):
+    """AP values of the reference's own datatest.evaluation (-> eval_helpers / evaluateAP) on synthetic pck_objects."""
+    import contextlib
+    import copy
+    import io
+    from pytorch_pose_proposal_network_amd import evaluate
+    seeds = [1, 2, 3, 4, 5, 6]
+    sizes = [12, 12, 20, 6, 30, 1]
+    exp = []
+    for seed, n in zip(seeds, sizes):
+        obj = synth.eval_case(seed, n)
+        with contextlib.redirect_stdout(io.StringIO()):
+            ref = datatest.evaluation(copy.deepcopy(obj))
+        mine = evaluate.evaluation(obj)
+        assert np.allclose(mine, ref, rtol=0, atol=1e-9, equal_nan=True), (seed, mine, ref)
+        exp.append(ref)
+        print(f"eval case seed {seed} ({n} images): AP {np.round(ref, 3).tolist()}; evaluate.py == reference")
+    np.savez_compressed(os.path.join(HERE, "eval_cases.npz"), seeds=np.array(seeds), sizes=np.array(sizes),
+                        ap=np.array(exp, np.float64))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -415,6 +436,8 @@ def main():
         make_loss()
     if args.only in (None, "train"):
         make_train(drn, model)
+    if args.only in (None, "eval"):
+        make_eval(datatest)
 
 
 if __name__ == "__main__":

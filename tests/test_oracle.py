@@ -211,3 +211,33 @@ def test_train_oracle_golden(golden_dir):
     assert np.allclose(g["G"], g["G_f64"], rtol=0.2) and np.allclose(g["dw"], g["dw_f64"], rtol=0.2)
     rel = np.abs(g["g1/norm"] - g["g1_f64/norm"]) / np.maximum(g["g1_f64/norm"], 1e-6)
     assert np.median(rel) < 0.02 and rel[g["g1_f64/norm"] > 1e-4].max() < 0.5    # conv2.bias: exactly 0 in theory
+
+
+def test_ap_evaluation_golden(golden_dir):
+    """evaluate.evaluation == the reference's datatest.evaluation -> eval_helpers.assignGTmulti / computeRPC / VOCap
+    -> getCum on the synthetic pck_objects of synth.eval_case (expected AP values produced by the imported reference,
+    tests/golden/eval_cases.npz)."""
+    from pytorch_pose_proposal_network_amd import evaluate
+    g = _load(golden_dir, "eval_cases.npz")
+    for seed, n, exp in zip(g["seeds"], g["sizes"], g["ap"]):
+        got = evaluate.evaluation(synth.eval_case(int(seed), int(n)))
+        assert np.allclose(got, exp, rtol=0, atol=1e-9), (seed, got, exp)
+    # structural properties: perfect predictions score 100, an empty prediction set scores 0
+    obj = synth.eval_case(3, 8)
+    perfect = [list(o) for o in obj]
+    for i, (kps, boxes) in enumerate(zip(obj[1], obj[4])):
+        hs, ss = [], []
+        for p in range(len(boxes)):
+            hm = {0: np.zeros(4, np.float32)}
+            sm = {0: np.float32(0.9)}
+            for k in range(1, 18):
+                x, y = kps[p][k - 1]
+                hm[k] = np.array([y - 4, x - 4, y + 4, x + 4], np.float32)
+                sm[k] = np.float32(0.9)
+            hs.append(hm)
+            ss.append(sm)
+        perfect[2][i], perfect[3][i] = hs, ss
+    assert np.allclose(evaluate.evaluation(perfect), 100.0)
+    empty = [list(o) for o in obj]
+    empty[2], empty[3] = [[] for _ in obj[2]], [[] for _ in obj[3]]
+    assert np.allclose(evaluate.evaluation(empty), 0.0)
