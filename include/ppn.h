@@ -412,6 +412,41 @@ typedef struct ppn_wgrad_desc {
 size_t ppn_conv_wgrad_workspace_bytes(const ppn_wgrad_desc* d);
 int ppn_conv_wgrad(const ppn_wgrad_desc* d, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Second-order pieces: GradNorm's Lgrad.backward() (main.py:759) differentiates the probe gradients
+ * G_iR = d(w_i L_i)/dW (created with create_graph=True, main.py:704-708) once more.  With v_i = g_i/||g_i||,
+ *     d||g_i||/dtheta = d/dtheta <grad_s L_i(s), sdot_i>,   sdot_i = forward-mode tangent of the head along the
+ * weight direction v_i; only the head's tail (bn0_2 .. sigmoid) carries a tangent.  These entry points are the
+ * non-linear building blocks of the reverse pass over that dual computation (the convolutions reuse
+ * ppn_conv2d_fused / ppn_conv_wgrad on both streams).
+ * ---------------------------------------------------------------------------------------- */
+
+/* dst[b][hw][c] = src[b][c][hw] (f32 NCHW -> NHWC `dtype`, channels_pad a multiple of 64, padding zeroed). */
+int ppn_nchw_to_nhwc(int32_t dtype, const float* src, int32_t batch, int32_t channels, int32_t hw,
+                     int32_t channels_used, int32_t channels_pad, void* dst, void* stream);
+
+/* dx = dy * act'(x*scale + shift) with the BN affine of (gamma, beta, save_mean, save_rstd): the activation mask of
+ * a tangent that has passed the BN (its forward-mode image is ppn_bn_train_bwd with act NONE applied to the
+ * tangent).  Uses x, dy, gamma, beta, save_mean, save_rstd, act, dx of the descriptor. */
+int ppn_bn_act_mask(const ppn_bn_bwd_desc* d, void* stream);
+
+/* Adjoint of the train-mode BN tangent  ydot = gamma*rstd*(xdot - mean(xdot) - xhat*mean(xhat*xdot))  followed by
+ * the activation mask, with respect to x and gamma:  d->dy is the adjoint arriving at the masked tangent, `xdot`
+ * the tangent that entered the BN.  d->dx is ACCUMULATED into (add it to the ordinary ppn_bn_train_bwd result);
+ * dgamma_tan f32[C] is overwritten.  (The adjoint w.r.t. xdot itself is ppn_bn_train_bwd(x, dy, act).dx.)
+ * d->workspace >= ppn_bn_dual_workspace_bytes(channels). */
+size_t ppn_bn_dual_workspace_bytes(int32_t channels);
+int ppn_bn_dual_bwd(const ppn_bn_bwd_desc* d, const void* xdot, float* dgamma_tan, void* stream);
+
+/* Head-space seeds for one coefficient vector c (HOST, 5 floats): with s = head, sdot = s(1-s)*tz,
+ *     tzbar = sdot_bar * sig'          sdot_bar = d(sum c_i L_i)/ds
+ *     zbar  = s_bar*sig' + sdot_bar*sig''*tz,   s_bar = (d2(sum c_i L_i)/ds2) sdot   (dual-number evaluation)
+ * all f32 in the head layout.  unary_only != 0: only the first 6K channels are touched (c[4] must be 0). */
+int ppn_loss_dual(const ppn_loss_cfg* cfg, const float* head, const float* tz, int32_t batch, const float* delta,
+                  const float* weight, const float* weight_ij, const float* tx_half, const float* ty_half,
+                  const float* tx, const float* ty, const float* tw, const float* th, const float* te,
+                  const float* coeff, int32_t unary_only, float* zbar, float* tzbar, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -109,6 +109,129 @@ __global__ void __launch_bounds__(256) unary_kernel(LossArgs a) {
     s = block_sum(l_size, s_red); if (threadIdx.x == 0) out[3] = s;
 }
 
+
+// ---- second order: gradient AND Hessian-vector product of the losses w.r.t. the head -----------------------------------
+// GradNorm's Lgrad.backward() (main.py:759) differentiates <v, dL_i/dW> again; in head space that needs
+//     sdot_bar = c_i * dL_i/ds          and          s_bar = c_i * (d2L_i/ds2) sdot
+// for a tangent sdot = s(1-s) * tz of the sigmoid outputs.  The Hessian-vector product is obtained by evaluating the
+// SAME analytic gradient code on dual numbers (value, derivative along sdot): forward-over-reverse, no hand-derived
+// second derivatives (the IoU term couples conf, x, y, w, h through min / max / ReLU).
+struct Dual {
+    float v, d;
+};
+__device__ __forceinline__ Dual mk(float v, float d = 0.f) { return Dual{v, d}; }
+__device__ __forceinline__ Dual operator+(Dual a, Dual b) { return {a.v + b.v, a.d + b.d}; }
+__device__ __forceinline__ Dual operator-(Dual a, Dual b) { return {a.v - b.v, a.d - b.d}; }
+__device__ __forceinline__ Dual operator-(Dual a) { return {-a.v, -a.d}; }
+__device__ __forceinline__ Dual operator*(Dual a, Dual b) { return {a.v * b.v, a.d * b.v + a.v * b.d}; }
+__device__ __forceinline__ Dual operator/(Dual a, Dual b) { return {a.v / b.v, (a.d * b.v - a.v * b.d) / (b.v * b.v)}; }
+__device__ __forceinline__ Dual operator+(Dual a, float b) { return {a.v + b, a.d}; }
+__device__ __forceinline__ Dual operator-(Dual a, float b) { return {a.v - b, a.d}; }
+__device__ __forceinline__ Dual operator*(Dual a, float b) { return {a.v * b, a.d * b}; }
+__device__ __forceinline__ Dual operator*(float b, Dual a) { return {a.v * b, a.d * b}; }
+__device__ __forceinline__ Dual operator/(Dual a, float b) { return {a.v / b, a.d / b}; }
+__device__ __forceinline__ Dual dsqrt(Dual a) { const float r = sqrtf(a.v); return {r, a.d * 0.5f / r}; }
+// min / max with PyTorch's tie rule for the derivative (half on equality), second operand constant
+__device__ __forceinline__ Dual dmin_c(Dual a, float c) { return {fminf(a.v, c), a.d * pick_lt(a.v, c)}; }
+__device__ __forceinline__ Dual dmax_c(Dual b, float d) { return {fmaxf(b.v, d), b.d * pick_gt(b.v, d)}; }
+__device__ __forceinline__ Dual drelu(Dual a) { return {fmaxf(a.v, 0.f), a.v > 0.f ? a.d : 0.f}; }
+
+// g[0..5] = d(sum_i c_i L_i)/d(resp, conf, x, y, w, h) for one (image, keypoint, cell), on dual numbers.
+// The arithmetic mirrors unary_kernel line by line (same operation order, same tie rules).
+__device__ __forceinline__ void unary_grad_dual(Dual resp, Dual conf, Dual x, Dual y, Dual w, Dual h, float dl, float wt,
+                                                float txh, float tyh, float tx, float ty, float tw, float th, float X,
+                                                float Y, float gW, float gH, float inW, float inH, const float* c,
+                                                Dual* g) {
+    const Dual rx = (x + X) * gW, ry = (y + Y) * gH, rw = inW * w, rh = inH * h;
+    const float rtx = (tx + X) * gW, rty = (ty + Y) * gH, rtw = inW * tw, rth = inH * th;
+    const Dual a1 = rx + rw / 2.f, b1 = rx - rw / 2.f, a2 = ry + rh / 2.f, b2 = ry - rh / 2.f;
+    const float c1 = rtx + rtw / 2, d1 = rtx - rtw / 2, c2 = rty + rth / 2, d2 = rty - rth / 2;
+    const Dual wr = dmin_c(a1, c1) - dmax_c(b1, d1), hr = dmin_c(a2, c2) - dmax_c(b2, d2);
+    const Dual wI = drelu(wr), hI = drelu(hr);
+    const Dual I = wI * hI;
+    const Dual U = rw * rh + (rtw * rth) - I + kEps;
+    const Dual iou = I / U;
+    const Dual dr = resp - dl, dc = conf - iou, dx = x - txh, dy = y - tyh;
+    const Dual sw = dsqrt(w + kEps), sh = dsqrt(h + kEps);
+    const Dual dsw = sw - sqrtf(tw + kEps), dsh = sh - sqrtf(th + kEps);
+    const Dual g_iou = -2.f * dl * dc * c[1];
+    const Dual gI = g_iou * (U + I) / (U * U), gA0 = -(g_iou * I / (U * U));
+    // the selector functions are piecewise constant: no derivative through them
+    const Dual g_wr = wr.v > 0.f ? gI * hI : mk(0.f), g_hr = hr.v > 0.f ? gI * wI : mk(0.f);
+    const float da1 = pick_lt(a1.v, c1), db1 = pick_gt(b1.v, d1), da2 = pick_lt(a2.v, c2), db2 = pick_gt(b2.v, d2);
+    const Dual g_rx = g_wr * (da1 - db1), g_ry = g_hr * (da2 - db2);
+    const Dual g_rw = g_wr * (0.5f * (da1 + db1)) + gA0 * rh, g_rh = g_hr * (0.5f * (da2 + db2)) + gA0 * rw;
+    g[0] = 2.f * dr * c[0];
+    g[1] = 2.f * dl * dc * c[1];
+    g[2] = g_rx * gW + 2.f * wt * dx * c[2];
+    g[3] = g_ry * gH + 2.f * wt * dy * c[2];
+    g[4] = g_rw * inW + wt * dsw / sw * c[3];
+    g[5] = g_rh * inH + wt * dsh / sh * c[3];
+}
+
+// zbar = s_bar*sig' + sdot_bar*sig''*tz,  tzbar = sdot_bar*sig'   (sig' = s(1-s), sig'' = sig'(1-2s)); written in head layout
+__device__ __forceinline__ void sigmoid_dual_adjoint(float s, float tz, float s_bar, float sdot_bar, float* zbar,
+                                                     float* tzbar) {
+    const float s1 = s * (1.f - s), s2 = s1 * (1.f - 2.f * s);
+    *zbar = s_bar * s1 + sdot_bar * s2 * tz;
+    *tzbar = sdot_bar * s1;
+}
+
+struct DualArgs {
+    LossArgs a;
+    const float* tz;      // tangent of the logits, head layout
+    float* zbar;          // adjoint of the logits (primal stream), head layout
+    float* tzbar;         // adjoint of the logit tangents, head layout
+};
+
+__global__ void __launch_bounds__(256) unary_dual_kernel(DualArgs p) {
+    const LossArgs& a = p.a;
+    const int HW = a.H * a.W;
+    const long long n = (long long)a.B * a.K * HW;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int cell = (int)(i % HW);
+    const int k = (int)((i / HW) % a.K);
+    const int b = (int)(i / ((long long)HW * a.K));
+    const size_t hb = (size_t)b * a.C * HW + (size_t)k * HW + cell;
+    const size_t KS = (size_t)a.K * HW;
+    float s[6], tz[6];
+    Dual in[6], g[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        s[j] = a.head[hb + j * KS];
+        tz[j] = p.tz[hb + j * KS];
+        in[j] = mk(s[j], s[j] * (1.f - s[j]) * tz[j]);                    // sdot = sig'(z) * tz
+    }
+    const size_t t = (size_t)i;
+    const float invB = 1.0f / (float)a.B;
+    const float c[4] = {a.coeff[0] * invB, a.coeff[1] * invB, a.coeff[2] * invB, a.coeff[3] * invB};
+    unary_grad_dual(in[0], in[1], in[2], in[3], in[4], in[5], a.delta[t], a.weight[t], a.tx_half[t], a.ty_half[t],
+                    a.tx[t], a.ty[t], a.tw[t], a.th[t], (float)(cell % a.W), (float)(cell / a.W), (float)(a.inW / a.W),
+                    (float)(a.inH / a.H), (float)a.inW, (float)a.inH, c, g);
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+        sigmoid_dual_adjoint(s[j], tz[j], /*s_bar=*/g[j].d, /*sdot_bar=*/g[j].v, &p.zbar[hb + j * KS],
+                             &p.tzbar[hb + j * KS]);
+}
+
+// limb loss: g = 2 c4/B * w_ij * (e - te),  H sdot = 2 c4/B * w_ij * sdot
+__global__ void __launch_bounds__(256) limb_dual_kernel(DualArgs p) {
+    const LossArgs& a = p.a;
+    const int HW = a.H * a.W;
+    const size_t per_img = (size_t)a.E * a.S * HW;
+    const size_t head_img = (size_t)a.C * HW, head_off = (size_t)6 * a.K * HW;
+    const size_t total = (size_t)a.B * per_img;
+    const float g2 = 2.f * a.coeff[4] / (float)a.B;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t b = i / per_img, r = i - b * per_img;
+        const size_t ho = b * head_img + head_off + r;
+        const float s = a.head[ho], tz = p.tz[ho], wj = a.weight_ij[i];
+        const float sdot = s * (1.f - s) * tz;
+        sigmoid_dual_adjoint(s, tz, g2 * wj * sdot, g2 * wj * (s - a.te[i]), &p.zbar[ho], &p.tzbar[ho]);
+    }
+}
+
 template <int V>
 __global__ void __launch_bounds__(256) limb_kernel(LossArgs a) {
     __shared__ float s_red[4];
@@ -246,5 +369,36 @@ extern "C" int ppn_loss_unary_bwd(const ppn_loss_cfg* cfg, const float* head, in
     a.coeff[4] = 0.f;
     hipLaunchKernelGGL(unary_kernel, dim3(a.nblk_unary), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     PPN_LAUNCH_CHECK();
+    return PPN_OK;
+}
+
+// Second-order seeds of GradNorm's Lgrad.backward() (main.py:759) in head space, for ONE coefficient vector:
+//   tz      f32 head layout: forward-mode tangent of the LOGITS (conv3 output before the sigmoid)
+//   zbar    f32 head layout (out): adjoint of the logits            = s_bar*sig' + sdot_bar*sig''*tz
+//   tzbar   f32 head layout (out): adjoint of the logit tangents    = sdot_bar*sig'
+// with sdot = sig'*tz, sdot_bar = d(sum c_i L_i)/ds, s_bar = (d2(sum c_i L_i)/ds2) sdot.  unary_only: only the first 6K
+// channels are read / written (coeff[4] must be 0).
+extern "C" int ppn_loss_dual(const ppn_loss_cfg* cfg, const float* head, const float* tz, int32_t batch,
+                             const float* delta, const float* weight, const float* weight_ij, const float* tx_half,
+                             const float* ty_half, const float* tx, const float* ty, const float* tw, const float* th,
+                             const float* te, const float* coeff, int32_t unary_only, float* zbar, float* tzbar,
+                             void* stream) {
+    DualArgs p;
+    if (int rc = fill(p.a, cfg, batch)) return rc;
+    if (!head || !tz || !delta || !weight || !tx_half || !ty_half || !tx || !ty || !tw || !th || !coeff || !zbar || !tzbar)
+        return ppn::fail(PPN_E_INVALID, "ppn_loss_dual: NULL pointer");
+    if (!unary_only && (!weight_ij || !te)) return ppn::fail(PPN_E_INVALID, "ppn_loss_dual: limb targets required");
+    LossArgs& a = p.a;
+    a.head = head; a.delta = delta; a.weight = weight; a.weight_ij = weight_ij; a.tx_half = tx_half; a.ty_half = ty_half;
+    a.tx = tx; a.ty = ty; a.tw = tw; a.th = th; a.te = te; a.grad = nullptr; a.partial = nullptr; a.losses = nullptr;
+    for (int i = 0; i < 5; ++i) a.coeff[i] = coeff[i];
+    p.tz = tz; p.zbar = zbar; p.tzbar = tzbar;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(unary_dual_kernel, dim3(a.nblk_unary), dim3(256), 0, st, p);
+    PPN_LAUNCH_CHECK();
+    if (!unary_only && a.E > 0) {
+        hipLaunchKernelGGL(limb_dual_kernel, dim3(256 * 16), dim3(256), 0, st, p);
+        PPN_LAUNCH_CHECK();
+    }
     return PPN_OK;
 }

@@ -372,7 +372,7 @@ __global__ void colsum_finalize_kernel(const double* __restrict__ partial, int n
 
 // ---- head: gradient through the sigmoid + NCHW f32 -> NHWC relayout ---------------------------------------------
 // dz[b][hw][c] = g[b][c][hw] * s*(1-s),  s = head[b][c][hw]   (channels c >= C of the padded output are zero)
-template <typename T>
+template <typename T, bool SIG>
 __global__ void __launch_bounds__(256) head_grad_kernel(const float* __restrict__ head, const float* __restrict__ grad,
                                                         int Ctot, int C, int HW, int Cpad, T* __restrict__ dz) {
     __shared__ float tile[64][65];
@@ -386,8 +386,12 @@ __global__ void __launch_bounds__(256) head_grad_kernel(const float* __restrict_
         float v = 0.f;
         if (c < C && p < HW) {
             const size_t o = ((size_t)b * Ctot + c) * HW + p;
-            const float sg = head[o];
-            v = grad[o] * (sg * (1.f - sg));
+            if constexpr (SIG) {
+                const float sg = head[o];
+                v = grad[o] * (sg * (1.f - sg));
+            } else {
+                v = grad[o];                               // plain relayout (the gradient is already w.r.t. the logits)
+            }
         }
         tile[px][cl] = v;
     }
@@ -424,6 +428,145 @@ __global__ void __launch_bounds__(256) head_bias_grad_kernel(const float* __rest
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
     if (lane == 0) dbias[c] = (float)acc;
+}
+
+
+// ---- second-order pieces (GradNorm's Lgrad.backward(), main.py:759) ------------------------------------------------
+// out = in * act'(x*scale + shift): the activation mask of a forward-mode tangent that went through BN first
+template <typename T>
+__global__ void __launch_bounds__(kThreads) bn_act_mask_kernel(const T* __restrict__ x, const T* __restrict__ in,
+                                                               const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta,
+                                                               const float* __restrict__ mean,
+                                                               const float* __restrict__ rstd, int act, long long P,
+                                                               int C, Slab s, T* __restrict__ out) {
+    const int t = threadIdx.x;
+    const int col = t % s.cc, roff = t / s.cc;
+    const long long p0 = (long long)blockIdx.x * s.slab;
+    const long long p1 = p0 + s.slab < P ? p0 + s.slab : P;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = col * 8 + j;
+        sc[j] = gamma[c] * rstd[c];
+        sh[j] = beta[c] - mean[c] * sc[j];
+    }
+    const size_t row_bytes = (size_t)C * sizeof(T), cofs = (size_t)col * 8 * sizeof(T);
+    for (long long p = p0 + roff; p < p1; p += s.rpi) {
+        float v[8], g[8];
+        load8<T>(reinterpret_cast<const char*>(x) + cofs + p * row_bytes, v);
+        load8<T>(reinterpret_cast<const char*>(in) + cofs + p * row_bytes, g);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) g[j] *= act_slope(v[j] * sc[j] + sh[j], act);
+        store8<T>(reinterpret_cast<char*>(out) + cofs + p * row_bytes, g);
+    }
+}
+
+// Adjoint of the train-mode BN forward-mode tangent  ydot = (gamma*rstd) * P(xdot),  P(v) = v - mean(v) - xhat*mean(xhat*v),
+// with respect to x (through xhat and rstd) and gamma.  q = dyt * act'(z) is the adjoint arriving at ydot.
+// Five per-channel sums: Sq, Sqx = sum q*xhat, Sx = sum xdot, Sxx = sum xdot*xhat, Sqd = sum q*xdot.
+template <typename T>
+__global__ void __launch_bounds__(kThreads) bn_dual_reduce_kernel(const T* __restrict__ x, const T* __restrict__ xdot,
+                                                                  const T* __restrict__ dyt,
+                                                                  const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta,
+                                                                  const float* __restrict__ mean,
+                                                                  const float* __restrict__ rstd, int act,
+                                                                  long long P, int C, Slab s,
+                                                                  double* __restrict__ partial) {
+    __shared__ double red[kThreads][5];
+    const int t = threadIdx.x;
+    const int col = t % s.cc, roff = t / s.cc;
+    const long long p0 = (long long)blockIdx.x * s.slab;
+    const long long p1 = p0 + s.slab < P ? p0 + s.slab : P;
+    const size_t row_bytes = (size_t)C * sizeof(T), cofs = (size_t)col * 8 * sizeof(T);
+    for (int j = 0; j < 8; ++j) {                      // one channel of the chunk at a time keeps the accumulators few
+        const int c = col * 8 + j;
+        const float mu = mean[c], rs = rstd[c], sc = gamma[c] * rs, sh = beta[c] - mu * sc;
+        double a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;
+        for (long long p = p0 + roff; p < p1; p += s.rpi) {
+            const float xv = (float)reinterpret_cast<const T*>(reinterpret_cast<const char*>(x) + cofs + p * row_bytes)[j];
+            const float xd = (float)reinterpret_cast<const T*>(reinterpret_cast<const char*>(xdot) + cofs + p * row_bytes)[j];
+            const float dv = (float)reinterpret_cast<const T*>(reinterpret_cast<const char*>(dyt) + cofs + p * row_bytes)[j];
+            const float q = dv * act_slope(xv * sc + sh, act);
+            const float xh = (xv - mu) * rs;
+            a0 += q; a1 += (double)q * xh; a2 += xd; a3 += (double)xd * xh; a4 += (double)q * xd;
+        }
+        red[t][0] = a0; red[t][1] = a1; red[t][2] = a2; red[t][3] = a3; red[t][4] = a4;
+        __syncthreads();
+        for (int o = t; o < s.cc * 5; o += kThreads) {
+            const int c_ = o / 5, k = o % 5;
+            double acc = 0.0;
+            for (int r = 0; r < s.rpi; ++r) acc += red[r * s.cc + c_][k];
+            partial[((size_t)blockIdx.x * C + c_ * 8 + j) * 5 + k] = acc;
+        }
+        __syncthreads();
+    }
+}
+
+// coef[c][0..3]: dx_tan = c0*xhat + c1*q + c2*xdot + c3   (xhat = (x-mean)*rstd), dgamma_tan[c] = A*rstd
+__global__ void bn_dual_finalize_kernel(const double* __restrict__ partial, int nblocks, int C, long long P,
+                                        const float* __restrict__ gamma, const float* __restrict__ rstd,
+                                        float* __restrict__ coef, float* __restrict__ dgamma_tan) {
+    const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (c >= C) return;
+    double S[5] = {0, 0, 0, 0, 0};
+    for (int b = lane; b < nblocks; b += 64)
+        for (int k = 0; k < 5; ++k) S[k] += partial[((size_t)b * C + c) * 5 + k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        for (int k = 0; k < 5; ++k) S[k] += __shfl_xor(S[k], off, 64);
+    if (lane != 0) return;
+    const double n = (double)P, Sq = S[0], Sqx = S[1], Sx = S[2], Sxx = S[3], Sqd = S[4];
+    const double m1 = Sx / n, m2 = Sxx / n, qb = Sq / n;
+    const double A = Sqd - Sq * Sx / n - Sqx * Sxx / n;
+    const double g = gamma[c], r = rstd[c];
+    const double k0 = -g * r * r;
+    // dx_tan = k0 * [ A*xhat/n + m2*(q - qb - xhat*Sqx/n) + (Sqx/n)*(xdot - m1 - xhat*m2) ]
+    coef[c * 4 + 0] = (float)(k0 * (A / n - 2.0 * m2 * Sqx / n));
+    coef[c * 4 + 1] = (float)(k0 * m2);
+    coef[c * 4 + 2] = (float)(k0 * Sqx / n);
+    coef[c * 4 + 3] = (float)(k0 * (-m2 * qb - Sqx / n * m1));
+    dgamma_tan[c] = (float)(A * r);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kThreads) bn_dual_apply_kernel(const T* __restrict__ x, const T* __restrict__ xdot,
+                                                                 const T* __restrict__ dyt,
+                                                                 const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta,
+                                                                 const float* __restrict__ mean,
+                                                                 const float* __restrict__ rstd,
+                                                                 const float* __restrict__ coef, int act, long long P,
+                                                                 int C, Slab s, T* __restrict__ dx) {
+    const int t = threadIdx.x;
+    const int col = t % s.cc, roff = t / s.cc;
+    const long long p0 = (long long)blockIdx.x * s.slab;
+    const long long p1 = p0 + s.slab < P ? p0 + s.slab : P;
+    float sc[8], sh[8], mu[8], rs[8], k0[8], k1[8], k2[8], k3[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = col * 8 + j;
+        mu[j] = mean[c]; rs[j] = rstd[c];
+        sc[j] = gamma[c] * rs[j]; sh[j] = beta[c] - mu[j] * sc[j];
+        k0[j] = coef[c * 4]; k1[j] = coef[c * 4 + 1]; k2[j] = coef[c * 4 + 2]; k3[j] = coef[c * 4 + 3];
+    }
+    const size_t row_bytes = (size_t)C * sizeof(T), cofs = (size_t)col * 8 * sizeof(T);
+    for (long long p = p0 + roff; p < p1; p += s.rpi) {
+        float v[8], xd[8], g[8], o[8];
+        load8<T>(reinterpret_cast<const char*>(x) + cofs + p * row_bytes, v);
+        load8<T>(reinterpret_cast<const char*>(xdot) + cofs + p * row_bytes, xd);
+        load8<T>(reinterpret_cast<const char*>(dyt) + cofs + p * row_bytes, g);
+        load8<T>(reinterpret_cast<const char*>(dx) + cofs + p * row_bytes, o);          // accumulate into dx
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float q = g[j] * act_slope(v[j] * sc[j] + sh[j], act);
+            const float xh = (v[j] - mu[j]) * rs[j];
+            o[j] += k0[j] * xh + k1[j] * q + k2[j] * xd[j] + k3[j];
+        }
+        store8<T>(reinterpret_cast<char*>(dx) + cofs + p * row_bytes, o);
+    }
 }
 
 int make_slab(int C, long long P, Slab* s) {
@@ -566,16 +709,98 @@ int ppn_head_grad(int32_t dtype, const float* head, const float* grad_head, int3
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(channels_pad / 64, (hw + 63) / 64, batch);
     if (dtype == PPN_F32)
-        head_grad_kernel<float><<<grid, 256, 0, st>>>(head, grad_head, channels, channels_used, hw, channels_pad,
-                                                      (float*)dz);
+        head_grad_kernel<float, true><<<grid, 256, 0, st>>>(head, grad_head, channels, channels_used, hw, channels_pad,
+                                                            (float*)dz);
     else
-        head_grad_kernel<__bf16><<<grid, 256, 0, st>>>(head, grad_head, channels, channels_used, hw, channels_pad,
-                                                       (__bf16*)dz);
+        head_grad_kernel<__bf16, true><<<grid, 256, 0, st>>>(head, grad_head, channels, channels_used, hw, channels_pad,
+                                                             (__bf16*)dz);
     PPN_LAUNCH_CHECK();
     if (dbias) {
         head_bias_grad_kernel<<<(channels + 3) / 4, 256, 0, st>>>(head, grad_head, batch, channels, hw, dbias);
         PPN_LAUNCH_CHECK();
     }
+    return PPN_OK;
+}
+
+int ppn_nchw_to_nhwc(int32_t dtype, const float* src, int32_t batch, int32_t channels, int32_t hw, int32_t channels_used,
+                     int32_t channels_pad, void* dst, void* stream) {
+    if (!src || !dst) return ppn::fail(PPN_E_INVALID, "ppn_nchw_to_nhwc: NULL argument");
+    if (dtype != PPN_F32 && dtype != PPN_BF16) return ppn::fail(PPN_E_INVALID, "bad dtype %d", dtype);
+    if (batch < 1 || channels < 1 || hw < 1 || channels_used < 1 || channels_used > channels ||
+        channels_pad < channels_used || channels_pad % 64)
+        return ppn::fail(PPN_E_INVALID, "ppn_nchw_to_nhwc: bad channel counts");
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(channels_pad / 64, (hw + 63) / 64, batch);
+    if (dtype == PPN_F32)
+        head_grad_kernel<float, false><<<grid, 256, 0, st>>>(src, src, channels, channels_used, hw, channels_pad, (float*)dst);
+    else
+        head_grad_kernel<__bf16, false><<<grid, 256, 0, st>>>(src, src, channels, channels_used, hw, channels_pad, (__bf16*)dst);
+    PPN_LAUNCH_CHECK();
+    return PPN_OK;
+}
+
+int ppn_bn_act_mask(const ppn_bn_bwd_desc* d, void* stream) {
+    // uses x, dy (= the tensor to mask), gamma, beta, save_mean, save_rstd, act, dx (= output)
+    if (!d || !d->x || !d->dy || !d->gamma || !d->beta || !d->save_mean || !d->save_rstd || !d->dx)
+        return ppn::fail(PPN_E_INVALID, "ppn_bn_act_mask: NULL argument");
+    Slab s;
+    if (int rc = make_slab(d->channels, d->pixels, &s)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    if (d->dtype == PPN_F32)
+        bn_act_mask_kernel<float><<<s.nblocks, kThreads, 0, st>>>((const float*)d->x, (const float*)d->dy, d->gamma, d->beta,
+                                                                  d->save_mean, d->save_rstd, d->act, d->pixels,
+                                                                  d->channels, s, (float*)d->dx);
+    else if (d->dtype == PPN_BF16)
+        bn_act_mask_kernel<__bf16><<<s.nblocks, kThreads, 0, st>>>((const __bf16*)d->x, (const __bf16*)d->dy, d->gamma,
+                                                                   d->beta, d->save_mean, d->save_rstd, d->act,
+                                                                   d->pixels, d->channels, s, (__bf16*)d->dx);
+    else return ppn::fail(PPN_E_INVALID, "bad dtype %d", d->dtype);
+    PPN_LAUNCH_CHECK();
+    return PPN_OK;
+}
+
+size_t ppn_bn_dual_workspace_bytes(int32_t channels) {
+    if (channels <= 0) return 0;
+    return (size_t)kMaxBlocks * channels * 5 * sizeof(double) + (size_t)4 * channels * sizeof(float);
+}
+
+int ppn_bn_dual_bwd(const ppn_bn_bwd_desc* d, const void* xdot, float* dgamma_tan, void* stream) {
+    // d->dy = adjoint arriving at the (activated) tangent output, d->dx is ACCUMULATED into, d->workspace >=
+    // ppn_bn_dual_workspace_bytes(channels); d->dgamma / dbeta / dx_add are not used
+    if (!d || !d->x || !d->dy || !xdot || !d->gamma || !d->beta || !d->save_mean || !d->save_rstd || !d->dx ||
+        !d->workspace || !dgamma_tan)
+        return ppn::fail(PPN_E_INVALID, "ppn_bn_dual_bwd: NULL argument");
+    if (d->dtype != PPN_F32 && d->dtype != PPN_BF16) return ppn::fail(PPN_E_INVALID, "bad dtype %d", d->dtype);
+    Slab s;
+    if (int rc = make_slab(d->channels, d->pixels, &s)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const int C = d->channels;
+    double* partial = reinterpret_cast<double*>(d->workspace);
+    float* coef = reinterpret_cast<float*>(reinterpret_cast<char*>(d->workspace) + (size_t)kMaxBlocks * C * 5 * sizeof(double));
+    if (d->dtype == PPN_F32)
+        bn_dual_reduce_kernel<float><<<s.nblocks, kThreads, 0, st>>>((const float*)d->x, (const float*)xdot,
+                                                                     (const float*)d->dy, d->gamma, d->beta, d->save_mean,
+                                                                     d->save_rstd, d->act, d->pixels, C, s, partial);
+    else
+        bn_dual_reduce_kernel<__bf16><<<s.nblocks, kThreads, 0, st>>>((const __bf16*)d->x, (const __bf16*)xdot,
+                                                                      (const __bf16*)d->dy, d->gamma, d->beta,
+                                                                      d->save_mean, d->save_rstd, d->act, d->pixels, C, s,
+                                                                      partial);
+    PPN_LAUNCH_CHECK();
+    bn_dual_finalize_kernel<<<(C + 3) / 4, 256, 0, st>>>(partial, s.nblocks, C, d->pixels, d->gamma, d->save_rstd, coef,
+                                                         dgamma_tan);
+    PPN_LAUNCH_CHECK();
+    if (d->dtype == PPN_F32)
+        bn_dual_apply_kernel<float><<<s.nblocks, kThreads, 0, st>>>((const float*)d->x, (const float*)xdot,
+                                                                    (const float*)d->dy, d->gamma, d->beta, d->save_mean,
+                                                                    d->save_rstd, coef, d->act, d->pixels, C, s,
+                                                                    (float*)d->dx);
+    else
+        bn_dual_apply_kernel<__bf16><<<s.nblocks, kThreads, 0, st>>>((const __bf16*)d->x, (const __bf16*)xdot,
+                                                                     (const __bf16*)d->dy, d->gamma, d->beta,
+                                                                     d->save_mean, d->save_rstd, coef, d->act, d->pixels,
+                                                                     C, s, (__bf16*)d->dx);
+    PPN_LAUNCH_CHECK();
     return PPN_OK;
 }
 

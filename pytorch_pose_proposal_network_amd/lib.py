@@ -129,6 +129,13 @@ _SIGNATURES.update({
                            [C.POINTER(C.c_float), C.c_void_p, C.c_void_p, C.c_void_p]),
     "ppn_encode_targets": (C.c_int, [C.POINTER(LossCfg), C.POINTER(C.c_int32), C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_int32, C.c_int32] + [C.c_void_p] * 11),
+    "ppn_nchw_to_nhwc": (C.c_int, [C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                   C.c_void_p, C.c_void_p]),
+    "ppn_bn_act_mask": (C.c_int, [C.POINTER(BnBwdDesc), C.c_void_p]),
+    "ppn_bn_dual_workspace_bytes": (C.c_size_t, [C.c_int32]),
+    "ppn_bn_dual_bwd": (C.c_int, [C.POINTER(BnBwdDesc), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ppn_loss_dual": (C.c_int, [C.POINTER(LossCfg), C.c_void_p, C.c_void_p, C.c_int32] + [C.c_void_p] * 10 +
+                      [C.POINTER(C.c_float), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ppn_conv_wgrad_workspace_bytes": (C.c_size_t, [C.POINTER(WgradDesc)]),
     "ppn_conv_wgrad": (C.c_int, [C.POINTER(WgradDesc), C.c_void_p]),
 })

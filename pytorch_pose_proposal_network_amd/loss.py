@@ -102,6 +102,35 @@ class PPNLoss:
                 "ppn_loss_unary_bwd")
         return out
 
+    def dual(self, feature_map: torch.Tensor, tz: torch.Tensor, targets: Dict[str, torch.Tensor],
+             coeff: Sequence[float], unary_only: bool = False, out=None):
+        """Second-order seeds in head space (GradNorm's Lgrad.backward(), main.py:759): for the logit tangent `tz`
+        (head layout) returns (zbar, tzbar), the adjoints of the logits and of their tangents of
+        F = <d(sum c_i L_i)/ds, sig'(z)*tz>  (see ppn_loss_dual).  unary_only: only the first 6K channels."""
+        lib = self._lib = self._lib or L.load()
+        c = self._cfg
+        B = feature_map.shape[0]
+        C_ = 6 * c.K + c.E * c.sH * c.sW
+        feature_map = self._check("feature_map", feature_map, (B, C_, c.H, c.W))
+        tz = self._check("tz", tz, (B, C_, c.H, c.W))
+        t = {}
+        for k in TARGET_KEYS:
+            if unary_only and k in ("weight_ij", "te"):
+                continue
+            shape = (B, c.E, c.sH, c.sW, c.H, c.W) if k in ("weight_ij", "te") else (B, c.K, c.H, c.W)
+            t[k] = self._check(k, targets[k], shape)
+        zbar, tzbar = out if out is not None else (torch.empty_like(feature_map), torch.empty_like(feature_map))
+        cf = (C.c_float * 5)(*[float(v) for v in coeff])
+        if unary_only and float(coeff[4]) != 0.0:
+            raise ValueError("unary_only needs coeff[4] == 0")
+        L.check(lib.ppn_loss_dual(C.byref(c), feature_map.data_ptr(), tz.data_ptr(), B, t["delta"].data_ptr(),
+                                  t["weight"].data_ptr(), t["weight_ij"].data_ptr() if "weight_ij" in t else None,
+                                  t["tx_half"].data_ptr(), t["ty_half"].data_ptr(), t["tx"].data_ptr(),
+                                  t["ty"].data_ptr(), t["tw"].data_ptr(), t["th"].data_ptr(),
+                                  t["te"].data_ptr() if "te" in t else None, cf, 1 if unary_only else 0,
+                                  zbar.data_ptr(), tzbar.data_ptr(), L.current_stream_ptr()), "ppn_loss_dual")
+        return zbar, tzbar
+
     def forward(self, image, feature_map, delta, weight, weight_ij, tx_half, ty_half, tx, ty, tw, th, te):
         """Reference signature (main.py:180); `image` is only used for its batch size there and is ignored here."""
         targets = dict(delta=delta, weight=weight, weight_ij=weight_ij, tx_half=tx_half, ty_half=ty_half, tx=tx, ty=ty,

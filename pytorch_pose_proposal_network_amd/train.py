@@ -355,3 +355,58 @@ class BucketedAllReduce:
             h.wait()
         self.handles, self.next = [], 0
         return 1.0 / self.world
+
+
+# ---- second-order building blocks (GradNorm's Lgrad.backward(), main.py:759) --------------------------------------
+
+def _bwd_desc(x, dy, gamma, beta, saved, act, dx):
+    c = x.shape[-1]
+    d = L.BnBwdDesc()
+    d.dtype, d.channels, d.pixels, d.act = _dtype_code(x), c, x.numel() // c, ACT[act]
+    d.x, d.dy, d.dx = x.data_ptr(), dy.data_ptr(), dx.data_ptr()
+    d.gamma, d.beta = _f32(gamma, c, "gamma"), _f32(beta, c, "beta")
+    d.save_mean, d.save_rstd = saved.mean.data_ptr(), saved.rstd.data_ptr()
+    return d
+
+
+def bn_tangent(x, xdot, gamma, beta, saved: BnSaved, act: str) -> torch.Tensor:
+    """Forward-mode image of y = act(bn_train(x)) for an input tangent xdot: act'(z) * gamma*rstd*P(xdot)."""
+    lib = L.load()
+    jvp, _, _ = bn_train_backward(x, xdot, gamma, beta, saved, act="none")      # the BN tangent IS the backward formula
+    out = torch.empty_like(x)
+    d = _bwd_desc(x, jvp, gamma, beta, saved, act, out)
+    L.check(lib.ppn_bn_act_mask(C.byref(d), L.current_stream_ptr()), "ppn_bn_act_mask")
+    return out
+
+
+_dual_ws = {}
+
+
+def bn_dual_backward(x, xdot, dy, dyt, gamma, beta, saved: BnSaved, act: str):
+    """Adjoint of the pair (y, ydot) = (act(bn(x)), bn_tangent(x, xdot)) for adjoints (dy, dyt).
+    Returns (dx, dxdot, dgamma, dbeta): the ordinary backward of dy plus the tangent stream's contributions."""
+    lib = L.load()
+    c = x.shape[-1]
+    dx, dgamma, dbeta = bn_train_backward(x, dy, gamma, beta, saved, act=act)
+    dxdot, _, _ = bn_train_backward(x, dyt, gamma, beta, saved, act=act)        # (gamma*rstd) P(dyt * act')
+    key = (c, str(x.device), torch.cuda.current_stream(x.device).cuda_stream)
+    ws = _dual_ws.get(key)
+    if ws is None:
+        ws = _dual_ws[key] = torch.empty(lib.ppn_bn_dual_workspace_bytes(c), dtype=torch.uint8, device=x.device)
+    dg_tan = torch.empty(c, dtype=torch.float32, device=x.device)
+    d = _bwd_desc(x, dyt, gamma, beta, saved, act, dx)
+    d.workspace = ws.data_ptr()
+    L.check(lib.ppn_bn_dual_bwd(C.byref(d), xdot.data_ptr(), dg_tan.data_ptr(), L.current_stream_ptr()),
+            "ppn_bn_dual_bwd")
+    return dx, dxdot, dgamma + dg_tan, dbeta
+
+
+def nchw_to_nhwc(src: torch.Tensor, dtype: torch.dtype, channels_used=None) -> torch.Tensor:
+    """f32 [B,C,H,W] -> `dtype` [B,H,W,Cpad] (Cpad = channels_used rounded up to 64, padding zeroed)."""
+    B, Cn, H, W = src.shape
+    used = Cn if channels_used is None else channels_used
+    cpad = (used + 63) // 64 * 64
+    out = torch.empty(B, H, W, cpad, dtype=dtype, device=src.device)
+    L.check(L.load().ppn_nchw_to_nhwc(L.PPN_F32 if dtype == torch.float32 else L.PPN_BF16, src.data_ptr(), B, Cn,
+                                      H * W, used, cpad, out.data_ptr(), L.current_stream_ptr()), "ppn_nchw_to_nhwc")
+    return out
