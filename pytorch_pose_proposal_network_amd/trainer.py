@@ -41,7 +41,7 @@ _BUFFER_SUFFIXES = (".running_mean", ".running_var", ".num_batches_tracked")
 class PPNTrainer:
     def __init__(self, arch: str = "drn_d_22", state_dict: Optional[Dict] = None, compute_dtype: int = L.PPN_BF16,
                  lr: float = 7e-4, lr_weights: Optional[float] = None, alpha: float = 0.12, insize=(384, 384),
-                 device="cuda"):
+                 device="cuda", second_order: bool = False):
         L.load()                                               # fail loudly without libppn.so
         if A.DRN_D[arch][0] != "basic":
             raise NotImplementedError("training is implemented for the BasicBlock DRN-D variants (22/24/38/40)")
@@ -86,6 +86,12 @@ class PPNTrainer:
         self._probe_stream = torch.cuda.Stream(device=self.device) if self._side is not None else None
         self._probe_scratch = None
         self._conv1_local = None
+        # second_order: add d Lgrad / d theta (main.py:759, the double backward through the probe gradients) to the
+        # model gradients.  Everything then runs on one stream (the second-order pass accumulates into gradients the
+        # first-order pass has just written).
+        self.second_order = second_order
+        if second_order:
+            self._side = self._probe_stream = None
 
     # ---- state ------------------------------------------------------------------------------------------------
     def load_state_dict(self, sd):
@@ -296,7 +302,7 @@ class PPNTrainer:
         return cur
 
     # ---- backward ------------------------------------------------------------------------------------------------
-    def _head_backward(self, c, grad_head, probe_only: bool, channels_used: Optional[int] = None):
+    def _head_backward(self, c, grad_head, probe_only: bool, channels_used: Optional[int] = None, so=None):
         """Backward of the head unit.  probe_only: stop at conv1.weight and return its gradient (GradNorm);
         channels_used: only the first so many head channels carry a gradient (6K for the unary losses)."""
         lib = L.load()
@@ -336,10 +342,92 @@ class PPNTrainer:
             return T.conv_wgrad(c["h1"], da2, 3, 1, 1, 1)
         self._wgrad("conv1.weight", c["h1"], da2, 3, 1, 1, 1)
         dh1 = T.conv_dgrad(da2, self.P["conv1.weight"], (Ho, Wo), 1, 1, 1)
+        skip = da3
+        if so is not None:
+            # GradNorm's Lgrad.backward(): the second-order adjoints at h1 and at the skip tensor join the first-order
+            # ones here, so everything upstream is back-propagated once
+            h1_bar, r_bar = self._second_order_tail(c, so)
+            if h1_bar is not None:
+                dh1 = dh1 + h1_bar
+                skip = da3 + r_bar
         da1 = self._bn_bwd(c["a1"], dh1, "bn1", "lrelu", c["s1"])
         self._wgrad("conv1x1_1.weight", c["h0"], da1, 1)
         dh0 = T.conv_dgrad(da1, self.P["conv1x1_1.weight"], (Ho, Wo))
-        return self._bn_bwd(c["R"], dh0, "bn0_1", "lrelu", c["s0"], dx_add=da3)
+        return self._bn_bwd(c["R"], dh0, "bn0_1", "lrelu", c["s0"], dx_add=skip)
+
+    # ---- second order ------------------------------------------------------------------------------------------------
+    def _second_order_tail(self, c, so):
+        """d Lgrad / d theta restricted to what the probe weight W = conv1.weight can influence: the head's tail.
+        so = dict(head, targets, losses, coeff, unary=[dL_i/dW for i < 4]).  Accumulates into the tail parameters'
+        gradients and returns the adjoints (at h1, at the skip tensor R) to be added to the first-order seeds.
+        Derivation: DESIGN.md section 7 item 2; building blocks: train.bn_tangent / bn_dual_backward, PPNLoss.dual."""
+        head, targets, coeff = so["head"], so["targets"], so["coeff"]
+        B, Ch, Ho, Wo = head.shape
+        gw = list(so["unary"])
+        acc = sum(float(coeff[i]) * gw[i] for i in range(4))
+        gw.append((self.G["conv1.weight"] - acc) / float(coeff[4]))            # limb probe gradient by linearity
+        gn = torch.stack([T.sumsq(g.contiguous().view(-1)).sqrt().reshape(()) for g in gw])
+        so["gnorm"] = gn
+        w = self.task.w
+        G = w.abs() * gn                                                          # main.py:717-721
+        lhat = w * so["losses"] / self.base
+        Cc = G.mean() * (lhat / lhat.mean()) ** self.task.alpha                  # main.py:726-753 (constant)
+        kappa = (torch.sign(G - Cc) * torch.sign(w) * w.abs()).tolist()          # d Lgrad / d||g_i||, times w_i
+        gn_h = gn.tolist()
+        h1_bar = r_bar = None
+        k6 = 6 * cfg.K
+        P, Gd = self.P, self.G
+        for i in range(5):
+            if kappa[i] == 0.0 or gn_h[i] == 0.0:
+                continue
+            unary = i < 4
+            used = k6 if unary else Ch
+            v = (gw[i] / gn_h[i]).contiguous()                                    # unit direction on W
+            ci = [0.0] * 5
+            ci[i] = kappa[i]
+            # ---- forward-mode tangents through the tail ---------------------------------------------------------
+            u2 = T.conv2d_nhwc(c["h1"], v, 1, 1, 1)
+            t_h2 = T.bn_tangent(c["a2"], u2, P["bn0_2.weight"], P["bn0_2.bias"], c["s2"], "lrelu")
+            t_a3 = T.conv2d_nhwc(t_h2, P["conv1x1_2.weight"])
+            t_c2 = T.conv2d_nhwc(t_a3, P["conv2.weight"], 1, 1, 1)
+            t_h3 = T.bn_tangent(c["c2"], t_c2, P["bn2.weight"], P["bn2.bias"], c["s3"], "lrelu")
+            t_z = T.conv2d_nhwc(t_h3, P["conv3.weight"], nchw_f32=True)         # logit tangents, head layout
+            # ---- head space: gradient and Hessian-vector product of loss i, through the sigmoid --------------------
+            zbar, tzbar = self.criterion.dual(head, t_z, targets, ci, unary_only=unary)
+            zb = T.nchw_to_nhwc(zbar, self.tdt, used)
+            tzb = T.nchw_to_nhwc(tzbar, self.tdt, used)
+            cpad = zb.shape[-1]
+            w3p = torch.zeros(cpad, P["conv3.weight"].shape[1], 1, 1, dtype=torch.float32, device=self.device)
+            w3p[:used] = P["conv3.weight"][:used]
+            # ---- reverse pass over the dual tail (two streams: primal adjoints, tangent adjoints) -----------------
+            dw3 = T.conv_wgrad(c["h3"], zb, 1)
+            T.conv_wgrad(t_h3, tzb, 1, out=dw3, accumulate=True)
+            Gd["conv3.weight"][:used] += dw3[:used]
+            Gd["conv3.bias"][:used] += zbar[:, :used].sum((0, 2, 3))
+            h3_bar = T.conv_dgrad(zb, w3p, (Ho, Wo))
+            th3_bar = T.conv_dgrad(tzb, w3p, (Ho, Wo))
+            c2_bar, tc2_bar, dg, db = T.bn_dual_backward(c["c2"], t_c2, h3_bar, th3_bar, P["bn2.weight"],
+                                                         P["bn2.bias"], c["s3"], "lrelu")
+            Gd["bn2.weight"] += dg
+            Gd["bn2.bias"] += db
+            Gd["conv2.bias"] += c2_bar.float().sum((0, 1, 2))
+            T.conv_wgrad(c["a3"], c2_bar, 3, 1, 1, 1, out=Gd["conv2.weight"], accumulate=True)
+            T.conv_wgrad(t_a3, tc2_bar, 3, 1, 1, 1, out=Gd["conv2.weight"], accumulate=True)
+            a3_bar = T.conv_dgrad(c2_bar, P["conv2.weight"], (Ho, Wo), 1, 1, 1)
+            ta3_bar = T.conv_dgrad(tc2_bar, P["conv2.weight"], (Ho, Wo), 1, 1, 1)
+            T.conv_wgrad(c["h2"], a3_bar, 1, out=Gd["conv1x1_2.weight"], accumulate=True)
+            T.conv_wgrad(t_h2, ta3_bar, 1, out=Gd["conv1x1_2.weight"], accumulate=True)
+            h2_bar = T.conv_dgrad(a3_bar, P["conv1x1_2.weight"], (Ho, Wo))
+            th2_bar = T.conv_dgrad(ta3_bar, P["conv1x1_2.weight"], (Ho, Wo))
+            a2_bar, u2_bar, dg, db = T.bn_dual_backward(c["a2"], u2, h2_bar, th2_bar, P["bn0_2.weight"],
+                                                        P["bn0_2.bias"], c["s2"], "lrelu")
+            Gd["bn0_2.weight"] += dg
+            Gd["bn0_2.bias"] += db
+            T.conv_wgrad(c["h1"], a2_bar, 3, 1, 1, 1, out=Gd["conv1.weight"], accumulate=True)
+            hb = T.conv_dgrad(a2_bar, P["conv1.weight"], (Ho, Wo), 1, 1, 1) + T.conv_dgrad(u2_bar, v, (Ho, Wo), 1, 1, 1)
+            h1_bar = hb if h1_bar is None else h1_bar + hb
+            r_bar = a3_bar if r_bar is None else r_bar + a3_bar
+        return h1_bar, r_bar
 
     def _unit_offset(self, kind, u) -> int:
         """First element of the flat buffer that belongs to this unit (its parameters are contiguous)."""
@@ -349,7 +437,7 @@ class PPNTrainer:
             return self.offset[u.prefix + ".conv1.weight"]
         return self.offset[f"{u.prefix}.{u.conv_idx}.weight"]
 
-    def backward(self, grad_head: torch.Tensor, exchange: Optional["T.BucketedAllReduce"] = None):
+    def backward(self, grad_head: torch.Tensor, exchange: Optional["T.BucketedAllReduce"] = None, so=None):
         """d(sum_i coeff_i L_i)/d(theta) into self.grad, given d/d(head) from the loss kernel.  `exchange`: buckets
         of the flat buffer are all-reduced as soon as the units that own them are done (the buffer is in forward
         order, the backward completes it from its end)."""
@@ -367,7 +455,7 @@ class PPNTrainer:
                 nxt = self._next_offset[id(u)]
                 exchange.ready(nxt, before_issue=join_side)
             if kind == "head":
-                g = self._head_backward(c, g, probe_only=False)
+                g = self._head_backward(c, g, probe_only=False, so=so)
                 if exchange is not None and exchange.enabled:
                     # the GradNorm probes need THIS rank's d loss/d conv1.weight; keep it before its bucket is summed
                     join_side()
@@ -453,6 +541,24 @@ class PPNTrainer:
             self.base = losses.clone()                                   # get_baseloss stand-in: L_i(step 0)
         coeff = [v / 5.0 for v in w]
         unary = None
+        if self.second_order:
+            # the probe gradients themselves (not only their norms) steer the second-order pass inside backward()
+            if self._probe_scratch is None or self._probe_scratch.shape != head.shape:
+                self._probe_scratch = torch.empty_like(head)
+            grads = []
+            for i in range(4):
+                self.criterion.unary_backward(head, targets, [1.0 if j == i else 0.0 for j in range(4)],
+                                              out=self._probe_scratch)
+                grads.append(self.probe_grad(self._probe_scratch, channels_used=6 * cfg.K))
+            so = dict(head=head, targets=targets, losses=losses, coeff=coeff, unary=grads)
+            exchange = T.BucketedAllReduce(self.grad, group=group)
+            self.backward(ghead, exchange, so=so)
+            scale = exchange.finish()
+            self.task.step(losses, so["gnorm"], self.base, group=group)
+            self.opt.step(self.grad, grad_scale=scale)
+            self._tape = None
+            self._conv1_local = None
+            return losses, self.task.w
         if self._probe_stream is not None:
             # the four unary probe passes are small launches that depend only on the forward: they run on their own
             # stream underneath the backward pass

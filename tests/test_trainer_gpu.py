@@ -295,3 +295,50 @@ def test_training_converges_on_a_fixed_batch():
         assert abs(float(w.mean()) - 1.0) < 1e-5 and float(w.min()) > 0.5
         final[name] = losses.cpu().numpy()
     assert np.allclose(final["bf16"], final["f32"], rtol=0.35), final
+
+
+def test_second_order_gradients_match_oracle():
+    """second_order=True: the model gradients are d loss/d theta + d Lgrad/d theta, the exact semantics of main.py:755-759
+    (Lgrad.backward() through the create_graph probe gradients), against the CPU autograd restatement, which in f32 was
+    bit-identical to the imported reference when the fixture was made (fixture values g2*)."""
+    from pytorch_pose_proposal_network_amd import lib as L
+    from pytorch_pose_proposal_network_amd.trainer import PPNTrainer
+    from oracle import train_ref
+    g, sd, x, tg, size = _setup()
+    w0, base = g["w_before"], g["base"]
+    torch.set_num_threads(8)
+    r64 = train_ref.train_iteration_ref(sd, x, tg, w0, base, "drn_d_22", (size, size), float(g["alpha"]),
+                                        second_order=True)
+    r32 = train_ref.train_iteration_ref(sd, x, tg, w0, base, "drn_d_22", (size, size), float(g["alpha"]),
+                                        dtype=torch.float32, second_order=True)
+    first = train_ref.train_iteration_ref(sd, x, tg, w0, base, "drn_d_22", (size, size), float(g["alpha"]))
+    dev = torch.device("cuda")
+    tr = PPNTrainer("drn_d_22", sd, compute_dtype=L.PPN_F32, insize=(size, size), lr_weights=float(g["lr_w"]),
+                    alpha=float(g["alpha"]), second_order=True)
+    tr.task.w.copy_(torch.from_numpy(w0))
+    tr.base = torch.from_numpy(base).to(dev)
+    xd = torch.as_tensor(x).to(dev)
+    tgd = {k: torch.from_numpy(v).to(dev) for k, v in tg.items()}
+    head = tr.forward(xd)
+    coeff = [float(v) / 5 for v in w0]
+    losses, ghead = tr.criterion.forward_backward(head, tgd, coeff=coeff)
+    scratch = torch.empty_like(head)
+    grads = []
+    for i in range(4):
+        tr.criterion.unary_backward(head, tgd, [1.0 if j == i else 0.0 for j in range(4)], out=scratch)
+        grads.append(tr.probe_grad(scratch, channels_used=108))
+    so = dict(head=head, targets=tgd, losses=losses, coeff=coeff, unary=grads)
+    tr.backward(ghead, so=so)
+    torch.cuda.synchronize()
+    assert np.allclose(so["gnorm"].cpu().numpy(), r64["gnorm"], rtol=1e-2)
+    bad, moved = [], 0
+    for n in tr.param_names:
+        mine = tr.G[n].cpu().numpy().astype(np.float64)
+        noise = _rel(r32["grads"][n], r64["grads"][n])
+        err = _rel(mine, r64["grads"][n])
+        if err > max(3 * noise, 2e-2):
+            bad.append((n, err, noise))
+        if _rel(first["grads"][n], r64["grads"][n]) > 0.05:
+            moved += 1                      # the second-order term really changes this tensor
+    assert moved > 50, moved
+    assert not bad, bad[:8]
