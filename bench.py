@@ -125,7 +125,8 @@ def main_train(args):
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     B, S = args.batch, args.size
     tr = PPNTrainer(args.arch, synth.make_state_dict(args.arch, 0),
-                    compute_dtype=L.PPN_BF16 if args.dtype == "bf16" else L.PPN_F32, insize=(S, S), device=dev)
+                    compute_dtype=L.PPN_BF16 if args.dtype == "bf16" else L.PPN_F32, insize=(S, S), device=dev,
+                    second_order=not args.first_order)
     x = torch.from_numpy(synth.normalized_frames(prng.u8_frames(99 + rank, B, (S, S)))).to(dev)
     tg = targets.synthetic_targets(99 + 1000 * rank, B, (S, S), device=dev)      # encoded on the device
     for _ in range(args.warmup):
@@ -158,7 +159,9 @@ def main_train(args):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.arch} PPN training step {args.dtype}, batch {B}/GPU synthetic {S}x{S} frames, "
                                    "targets of 1-4 synthetic people per frame encoded on the device "
-                                   "(BASELINE configs[3] per-GPU shard; model gradient first-order, DESIGN.md section 7)",
+                                   "(BASELINE configs[3] per-GPU shard; GradNorm "
+                                   + ("without" if args.first_order else "with")
+                                   + " the second-order term of main.py:759)",
                        "frames_per_gpu": B, "parallelism": f"minibatch sharded over {world} GPU(s), one all-reduce of "
                                                            "the flat 128.5 MB gradient buffer + 20 B of task weights"},
             "roofline": {"bound": "mfma", "kernel": "whole step (3 x forward conv FLOPs / step time)",
@@ -190,6 +193,8 @@ def main():
     ap.add_argument("--lanes", type=int, default=int(os.environ.get("PPN_LANES", "2")),
                     help="stream lanes successive steps alternate between (rt.MultiLaneInference); 1 = one lane with "
                          "the same kernels (what the rocprofv3 per-kernel durations are compared with)")
+    ap.add_argument("--first-order", action="store_true",
+                    help="--workload train: model gradient = d loss/d theta only (skip d Lgrad/d theta of main.py:759)")
     ap.add_argument("--tile-policy", type=int, default=0, choices=[0, 1],
                     help="1 = conv tiles by efficiency alone (ppn_set_conv_tile_policy; +4 %% with two lanes)")
     ap.add_argument("--no-pipeline", action="store_true",

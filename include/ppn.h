@@ -441,7 +441,8 @@ int ppn_bn_dual_bwd(const ppn_bn_bwd_desc* d, const void* xdot, float* dgamma_ta
 /* Head-space seeds for one coefficient vector c (HOST, 5 floats): with s = head, sdot = s(1-s)*tz,
  *     tzbar = sdot_bar * sig'          sdot_bar = d(sum c_i L_i)/ds
  *     zbar  = s_bar*sig' + sdot_bar*sig''*tz,   s_bar = (d2(sum c_i L_i)/ds2) sdot   (dual-number evaluation)
- * all f32 in the head layout.  unary_only != 0: only the first 6K channels are touched (c[4] must be 0). */
+ * all f32.  tz, zbar, tzbar have the head layout [B][C][H*W]; with unary_only != 0 they are compact tensors
+ * [B][6K][H*W] holding only the unary channels (c[4] must be 0; weight_ij / te may be NULL). */
 int ppn_loss_dual(const ppn_loss_cfg* cfg, const float* head, const float* tz, int32_t batch, const float* delta,
                   const float* weight, const float* weight_ij, const float* tx_half, const float* ty_half,
                   const float* tx, const float* ty, const float* tw, const float* th, const float* te,

@@ -179,9 +179,10 @@ __device__ __forceinline__ void sigmoid_dual_adjoint(float s, float tz, float s_
 
 struct DualArgs {
     LossArgs a;
-    const float* tz;      // tangent of the logits, head layout
-    float* zbar;          // adjoint of the logits (primal stream), head layout
-    float* tzbar;         // adjoint of the logit tangents, head layout
+    const float* tz;      // tangent of the logits, [B][Cd][H*W]
+    float* zbar;          // adjoint of the logits (primal stream), [B][Cd][H*W]
+    float* tzbar;         // adjoint of the logit tangents, [B][Cd][H*W]
+    int Cd;               // channels of the three dual tensors: C (head layout) or 6K (compact, unary passes)
 };
 
 __global__ void __launch_bounds__(256) unary_dual_kernel(DualArgs p) {
@@ -194,13 +195,14 @@ __global__ void __launch_bounds__(256) unary_dual_kernel(DualArgs p) {
     const int k = (int)((i / HW) % a.K);
     const int b = (int)(i / ((long long)HW * a.K));
     const size_t hb = (size_t)b * a.C * HW + (size_t)k * HW + cell;
+    const size_t db = (size_t)b * p.Cd * HW + (size_t)k * HW + cell;
     const size_t KS = (size_t)a.K * HW;
     float s[6], tz[6];
     Dual in[6], g[6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
         s[j] = a.head[hb + j * KS];
-        tz[j] = p.tz[hb + j * KS];
+        tz[j] = p.tz[db + j * KS];
         in[j] = mk(s[j], s[j] * (1.f - s[j]) * tz[j]);                    // sdot = sig'(z) * tz
     }
     const size_t t = (size_t)i;
@@ -211,8 +213,8 @@ __global__ void __launch_bounds__(256) unary_dual_kernel(DualArgs p) {
                     (float)(a.inH / a.H), (float)a.inW, (float)a.inH, c, g);
 #pragma unroll
     for (int j = 0; j < 6; ++j)
-        sigmoid_dual_adjoint(s[j], tz[j], /*s_bar=*/g[j].d, /*sdot_bar=*/g[j].v, &p.zbar[hb + j * KS],
-                             &p.tzbar[hb + j * KS]);
+        sigmoid_dual_adjoint(s[j], tz[j], /*s_bar=*/g[j].d, /*sdot_bar=*/g[j].v, &p.zbar[db + j * KS],
+                             &p.tzbar[db + j * KS]);
 }
 
 // limb loss: g = 2 c4/B * w_ij * (e - te),  H sdot = 2 c4/B * w_ij * sdot
@@ -376,8 +378,8 @@ extern "C" int ppn_loss_unary_bwd(const ppn_loss_cfg* cfg, const float* head, in
 //   tz      f32 head layout: forward-mode tangent of the LOGITS (conv3 output before the sigmoid)
 //   zbar    f32 head layout (out): adjoint of the logits            = s_bar*sig' + sdot_bar*sig''*tz
 //   tzbar   f32 head layout (out): adjoint of the logit tangents    = sdot_bar*sig'
-// with sdot = sig'*tz, sdot_bar = d(sum c_i L_i)/ds, s_bar = (d2(sum c_i L_i)/ds2) sdot.  unary_only: only the first 6K
-// channels are read / written (coeff[4] must be 0).
+// with sdot = sig'*tz, sdot_bar = d(sum c_i L_i)/ds, s_bar = (d2(sum c_i L_i)/ds2) sdot.  unary_only: tz / zbar / tzbar are
+// COMPACT tensors [B][6K][H*W] holding only the unary channels (coeff[4] must be 0); otherwise they have the head layout.
 extern "C" int ppn_loss_dual(const ppn_loss_cfg* cfg, const float* head, const float* tz, int32_t batch,
                              const float* delta, const float* weight, const float* weight_ij, const float* tx_half,
                              const float* ty_half, const float* tx, const float* ty, const float* tw, const float* th,
@@ -393,6 +395,7 @@ extern "C" int ppn_loss_dual(const ppn_loss_cfg* cfg, const float* head, const f
     a.tx = tx; a.ty = ty; a.tw = tw; a.th = th; a.te = te; a.grad = nullptr; a.partial = nullptr; a.losses = nullptr;
     for (int i = 0; i < 5; ++i) a.coeff[i] = coeff[i];
     p.tz = tz; p.zbar = zbar; p.tzbar = tzbar;
+    p.Cd = unary_only ? 6 * a.K : a.C;
     hipStream_t st = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(unary_dual_kernel, dim3(a.nblk_unary), dim3(256), 0, st, p);
     PPN_LAUNCH_CHECK();

@@ -106,20 +106,22 @@ class PPNLoss:
              coeff: Sequence[float], unary_only: bool = False, out=None):
         """Second-order seeds in head space (GradNorm's Lgrad.backward(), main.py:759): for the logit tangent `tz`
         (head layout) returns (zbar, tzbar), the adjoints of the logits and of their tangents of
-        F = <d(sum c_i L_i)/ds, sig'(z)*tz>  (see ppn_loss_dual).  unary_only: only the first 6K channels."""
+        F = <d(sum c_i L_i)/ds, sig'(z)*tz>  (see ppn_loss_dual).  unary_only: tz and the results are compact
+        [B,6K,H,W] tensors (the four unary losses only touch those channels)."""
         lib = self._lib = self._lib or L.load()
         c = self._cfg
         B = feature_map.shape[0]
         C_ = 6 * c.K + c.E * c.sH * c.sW
         feature_map = self._check("feature_map", feature_map, (B, C_, c.H, c.W))
-        tz = self._check("tz", tz, (B, C_, c.H, c.W))
+        Cd = 6 * c.K if unary_only else C_                    # unary passes work on compact [B,6K,H,W] dual tensors
+        tz = self._check("tz", tz, (B, Cd, c.H, c.W))
         t = {}
         for k in TARGET_KEYS:
             if unary_only and k in ("weight_ij", "te"):
                 continue
             shape = (B, c.E, c.sH, c.sW, c.H, c.W) if k in ("weight_ij", "te") else (B, c.K, c.H, c.W)
             t[k] = self._check(k, targets[k], shape)
-        zbar, tzbar = out if out is not None else (torch.empty_like(feature_map), torch.empty_like(feature_map))
+        zbar, tzbar = out if out is not None else (torch.empty_like(tz), torch.empty_like(tz))
         cf = (C.c_float * 5)(*[float(v) for v in coeff])
         if unary_only and float(coeff[4]) != 0.0:
             raise ValueError("unary_only needs coeff[4] == 0")

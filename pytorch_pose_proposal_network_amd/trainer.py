@@ -17,10 +17,11 @@ One iteration (main.py:664-777):
     w                <- GradNorm weight step (Adam), all-reduce, clamp, renormalise
     grad             <- all-reduce(grad) / world;  theta <- Adam(theta, grad)
 
-Deviation from the reference, stated plainly: main.py:759 back-propagates Lgrad through the graph of the G_i
-(create_graph=True), which adds d Lgrad / d theta -- a second-order term -- to the model gradients.  This
-trainer applies the first-order gradient d loss / d theta only; the task-weight update (which needs no second
-order) is exact.  DESIGN.md lists the term as the next training item.
+main.py:759 back-propagates Lgrad through the graph of the G_i (create_graph=True), which adds d Lgrad / d theta -- a
+second-order term -- to the model gradients.  With second_order=True (default) the trainer adds exactly that term: the
+probe weight only influences the head's tail, so the term is a reverse pass over a forward-mode (dual) evaluation of
+that tail per loss, whose adjoints join the first-order ones before the backbone is back-propagated once
+(_second_order_tail).  second_order=False applies d loss / d theta only (35 % faster per step).
 """
 from __future__ import annotations
 
@@ -41,7 +42,7 @@ _BUFFER_SUFFIXES = (".running_mean", ".running_var", ".num_batches_tracked")
 class PPNTrainer:
     def __init__(self, arch: str = "drn_d_22", state_dict: Optional[Dict] = None, compute_dtype: int = L.PPN_BF16,
                  lr: float = 7e-4, lr_weights: Optional[float] = None, alpha: float = 0.12, insize=(384, 384),
-                 device="cuda", second_order: bool = False):
+                 device="cuda", second_order: bool = True):
         L.load()                                               # fail loudly without libppn.so
         if A.DRN_D[arch][0] != "basic":
             raise NotImplementedError("training is implemented for the BasicBlock DRN-D variants (22/24/38/40)")
@@ -90,8 +91,6 @@ class PPNTrainer:
         # model gradients.  Everything then runs on one stream (the second-order pass accumulates into gradients the
         # first-order pass has just written).
         self.second_order = second_order
-        if second_order:
-            self._side = self._probe_stream = None
 
     # ---- state ------------------------------------------------------------------------------------------------
     def load_state_dict(self, sd):
@@ -363,6 +362,11 @@ class PPNTrainer:
         Derivation: DESIGN.md section 7 item 2; building blocks: train.bn_tangent / bn_dual_backward, PPNLoss.dual."""
         head, targets, coeff = so["head"], so["targets"], so["coeff"]
         B, Ch, Ho, Wo = head.shape
+        main = torch.cuda.current_stream(self.device)
+        if self._side is not None:
+            main.wait_stream(self._side)                 # the first-order tail gradients this pass accumulates into
+        if so.get("stream") is not None:
+            main.wait_stream(so["stream"])                # the unary probe gradients
         gw = list(so["unary"])
         acc = sum(float(coeff[i]) * gw[i] for i in range(4))
         gw.append((self.G["conv1.weight"] - acc) / float(coeff[4]))            # limb probe gradient by linearity
@@ -391,11 +395,12 @@ class PPNTrainer:
             t_a3 = T.conv2d_nhwc(t_h2, P["conv1x1_2.weight"])
             t_c2 = T.conv2d_nhwc(t_a3, P["conv2.weight"], 1, 1, 1)
             t_h3 = T.bn_tangent(c["c2"], t_c2, P["bn2.weight"], P["bn2.bias"], c["s3"], "lrelu")
-            t_z = T.conv2d_nhwc(t_h3, P["conv3.weight"], nchw_f32=True)         # logit tangents, head layout
+            w3u = P["conv3.weight"] if not unary else P["conv3.weight"][:used].contiguous()
+            t_z = T.conv2d_nhwc(t_h3, w3u, nchw_f32=True)                       # logit tangents [B, used, H, W]
             # ---- head space: gradient and Hessian-vector product of loss i, through the sigmoid --------------------
             zbar, tzbar = self.criterion.dual(head, t_z, targets, ci, unary_only=unary)
-            zb = T.nchw_to_nhwc(zbar, self.tdt, used)
-            tzb = T.nchw_to_nhwc(tzbar, self.tdt, used)
+            zb = T.nchw_to_nhwc(zbar, self.tdt)
+            tzb = T.nchw_to_nhwc(tzbar, self.tdt)
             cpad = zb.shape[-1]
             w3p = torch.zeros(cpad, P["conv3.weight"].shape[1], 1, 1, dtype=torch.float32, device=self.device)
             w3p[:used] = P["conv3.weight"][:used]
@@ -403,7 +408,7 @@ class PPNTrainer:
             dw3 = T.conv_wgrad(c["h3"], zb, 1)
             T.conv_wgrad(t_h3, tzb, 1, out=dw3, accumulate=True)
             Gd["conv3.weight"][:used] += dw3[:used]
-            Gd["conv3.bias"][:used] += zbar[:, :used].sum((0, 2, 3))
+            Gd["conv3.bias"][:used] += zbar.sum((0, 2, 3))
             h3_bar = T.conv_dgrad(zb, w3p, (Ho, Wo))
             th3_bar = T.conv_dgrad(tzb, w3p, (Ho, Wo))
             c2_bar, tc2_bar, dg, db = T.bn_dual_backward(c["c2"], t_c2, h3_bar, th3_bar, P["bn2.weight"],
@@ -546,11 +551,20 @@ class PPNTrainer:
             if self._probe_scratch is None or self._probe_scratch.shape != head.shape:
                 self._probe_scratch = torch.empty_like(head)
             grads = []
-            for i in range(4):
-                self.criterion.unary_backward(head, targets, [1.0 if j == i else 0.0 for j in range(4)],
-                                              out=self._probe_scratch)
-                grads.append(self.probe_grad(self._probe_scratch, channels_used=6 * cfg.K))
-            so = dict(head=head, targets=targets, losses=losses, coeff=coeff, unary=grads)
+            main = torch.cuda.current_stream(self.device)
+            pst = self._probe_stream if self._probe_stream is not None else main
+            ev = torch.cuda.Event()
+            ev.record(main)
+            with torch.cuda.stream(pst):                  # the four cheap probe passes run beside the head backward
+                pst.wait_event(ev)
+                for i in range(4):
+                    self.criterion.unary_backward(head, targets, [1.0 if j == i else 0.0 for j in range(4)],
+                                                  out=self._probe_scratch)
+                    gi = self.probe_grad(self._probe_scratch, channels_used=6 * cfg.K)
+                    gi.record_stream(main)
+                    grads.append(gi)
+            so = dict(head=head, targets=targets, losses=losses, coeff=coeff, unary=grads,
+                      stream=pst if pst is not main else None)
             exchange = T.BucketedAllReduce(self.grad, group=group)
             self.backward(ghead, exchange, so=so)
             scale = exchange.finish()

@@ -28,6 +28,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--phases", action="store_true")
+    ap.add_argument("--first-order", action="store_true",
+                    help="skip d Lgrad/d theta (main.py:759): model gradient = d loss/d theta only")
     args = ap.parse_args()
     # one process per GPU under torchrun (RANK / LOCAL_RANK / WORLD_SIZE): gradients and task weights are
     # exchanged over RCCL inside train_step; each rank works on its own 32-frame shard (weak scaling)
@@ -39,7 +41,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
     sd = synth.make_state_dict("drn_d_22", 0)
     dt = L.PPN_BF16 if args.dtype == "bf16" else L.PPN_F32
-    tr = PPNTrainer("drn_d_22", sd, compute_dtype=dt, insize=(args.size, args.size))
+    tr = PPNTrainer("drn_d_22", sd, compute_dtype=dt, insize=(args.size, args.size), second_order=not args.first_order)
     frames = prng.u8_frames(99 + rank, args.batch, (args.size, args.size))
     x = torch.from_numpy(synth.normalized_frames(frames)).to(dev)
     # 1..4 synthetic people per frame, targets built by the on-device encoder (csrc/encode.hip)
