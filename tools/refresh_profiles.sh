@@ -14,9 +14,9 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -- pyt
 echo "[4/6] PMC pass WRITE_SIZE"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --lanes 1 > $O/write.json 2> $O/write.err
 echo "[5/6] training step (phases + JSON), bench.py --workload train"
-python3 $R/tools/bench_train.py --phases > $O/train_bench.txt 2>&1
+python3 $R/tools/bench_train.py --phases --first-order > $O/train_bench.txt 2>&1
 python3 $R/bench.py --workload train --steps 10 --warmup 2 > $O/bench_train.json 2> $O/bench_train.err
 echo "[6/6] rocprofv3 kernel stats of the training step"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/train_stats -o train -- python3 $R/tools/bench_train.py --steps 3 --warmup 1 > $O/train_profiled.txt 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/train_stats -o train -- python3 $R/tools/bench_train.py --steps 3 --warmup 1 --first-order > $O/train_profiled.txt 2>&1
 find $O -name "*.csv" -size +3M -delete
 echo done
