@@ -378,60 +378,90 @@ class PPNTrainer:
         Cc = G.mean() * (lhat / lhat.mean()) ** self.task.alpha                  # main.py:726-753 (constant)
         kappa = (torch.sign(G - Cc) * torch.sign(w) * w.abs()).tolist()          # d Lgrad / d||g_i||, times w_i
         gn_h = gn.tolist()
-        h1_bar = r_bar = None
         k6 = 6 * cfg.K
         P, Gd = self.P, self.G
-        for i in range(5):
-            if kappa[i] == 0.0 or gn_h[i] == 0.0:
+        act = [i for i in range(5) if kappa[i] != 0.0 and gn_h[i] != 0.0]
+        if not act:
+            return None, None
+        n = len(act)
+        vs = [(gw[i] / gn_h[i]).contiguous() for i in act]                       # unit directions on W
+
+        def chunks(t):                                                            # [n*B, ...] -> n views [B, ...]
+            return [t[j * B:(j + 1) * B] for j in range(n)]
+
+        def ssum(t):                                                              # sum over the stacked streams
+            return t.view(n, B, *t.shape[1:]).sum(0)
+
+        # ---- forward-mode tangents through the tail.  Every stream is linear in its tangent, so the streams are
+        # stacked along the batch dimension for the convolutions (one launch for all of them); the BN tangents need
+        # per-stream batch statistics and run stream by stream.
+        u2 = [T.conv2d_nhwc(c["h1"], v, 1, 1, 1) for v in vs]
+        TH2 = torch.cat([T.bn_tangent(c["a2"], u, P["bn0_2.weight"], P["bn0_2.bias"], c["s2"], "lrelu") for u in u2])
+        TA3 = T.conv2d_nhwc(TH2, P["conv1x1_2.weight"])
+        TC2 = T.conv2d_nhwc(TA3, P["conv2.weight"], 1, 1, 1)
+        TH3 = torch.cat([T.bn_tangent(c["c2"], t, P["bn2.weight"], P["bn2.bias"], c["s3"], "lrelu")
+                         for t in chunks(TC2)])
+        # ---- head space per stream: gradient and Hessian-vector product of loss i through the sigmoid.  The unary
+        # losses only touch the first 6K channels: their streams share 128-channel conv3 launches.
+        H3bar = torch.empty_like(TH3)
+        TH3bar = torch.empty_like(TH3)
+        groups = [([j for j, i in enumerate(act) if i < 4], k6), ([j for j, i in enumerate(act) if i == 4], Ch)]
+        for js, used in groups:
+            if not js:
                 continue
-            unary = i < 4
-            used = k6 if unary else Ch
-            v = (gw[i] / gn_h[i]).contiguous()                                    # unit direction on W
-            ci = [0.0] * 5
-            ci[i] = kappa[i]
-            # ---- forward-mode tangents through the tail ---------------------------------------------------------
-            u2 = T.conv2d_nhwc(c["h1"], v, 1, 1, 1)
-            t_h2 = T.bn_tangent(c["a2"], u2, P["bn0_2.weight"], P["bn0_2.bias"], c["s2"], "lrelu")
-            t_a3 = T.conv2d_nhwc(t_h2, P["conv1x1_2.weight"])
-            t_c2 = T.conv2d_nhwc(t_a3, P["conv2.weight"], 1, 1, 1)
-            t_h3 = T.bn_tangent(c["c2"], t_c2, P["bn2.weight"], P["bn2.bias"], c["s3"], "lrelu")
-            w3u = P["conv3.weight"] if not unary else P["conv3.weight"][:used].contiguous()
-            t_z = T.conv2d_nhwc(t_h3, w3u, nchw_f32=True)                       # logit tangents [B, used, H, W]
-            # ---- head space: gradient and Hessian-vector product of loss i, through the sigmoid --------------------
-            zbar, tzbar = self.criterion.dual(head, t_z, targets, ci, unary_only=unary)
-            zb = T.nchw_to_nhwc(zbar, self.tdt)
-            tzb = T.nchw_to_nhwc(tzbar, self.tdt)
+            m = len(js)
+            w3u = P["conv3.weight"] if used == Ch else P["conv3.weight"][:used].contiguous()
+            th3 = TH3[js[0] * B:(js[-1] + 1) * B]                                 # the group's streams are adjacent
+            t_z = T.conv2d_nhwc(th3, w3u, nchw_f32=True)                          # logit tangents [m*B, used, H, W]
+            zbar, tzbar = torch.empty_like(t_z), torch.empty_like(t_z)
+            for q, j in enumerate(js):
+                ci = [0.0] * 5
+                ci[act[j]] = kappa[act[j]]
+                sl = slice(q * B, (q + 1) * B)
+                self.criterion.dual(head, t_z[sl], targets, ci, unary_only=used != Ch, out=(zbar[sl], tzbar[sl]))
+            zb, tzb = T.nchw_to_nhwc(zbar, self.tdt), T.nchw_to_nhwc(tzbar, self.tdt)
             cpad = zb.shape[-1]
-            w3p = torch.zeros(cpad, P["conv3.weight"].shape[1], 1, 1, dtype=torch.float32, device=self.device)
-            w3p[:used] = P["conv3.weight"][:used]
-            # ---- reverse pass over the dual tail (two streams: primal adjoints, tangent adjoints) -----------------
-            dw3 = T.conv_wgrad(c["h3"], zb, 1)
-            T.conv_wgrad(t_h3, tzb, 1, out=dw3, accumulate=True)
+            w3p = torch.zeros(cpad, w3u.shape[1], 1, 1, dtype=torch.float32, device=self.device)
+            w3p[:used] = w3u
+            dw3 = T.conv_wgrad(c["h3"], zb.view(m, B, Ho, Wo, cpad).sum(0), 1)    # primal stream: same h3 for all
+            T.conv_wgrad(th3, tzb, 1, out=dw3, accumulate=True)                  # tangent stream: stacked batch
             Gd["conv3.weight"][:used] += dw3[:used]
             Gd["conv3.bias"][:used] += zbar.sum((0, 2, 3))
-            h3_bar = T.conv_dgrad(zb, w3p, (Ho, Wo))
-            th3_bar = T.conv_dgrad(tzb, w3p, (Ho, Wo))
-            c2_bar, tc2_bar, dg, db = T.bn_dual_backward(c["c2"], t_c2, h3_bar, th3_bar, P["bn2.weight"],
-                                                         P["bn2.bias"], c["s3"], "lrelu")
+            H3bar[js[0] * B:(js[-1] + 1) * B] = T.conv_dgrad(zb, w3p, (Ho, Wo))
+            TH3bar[js[0] * B:(js[-1] + 1) * B] = T.conv_dgrad(tzb, w3p, (Ho, Wo))
+        # ---- reverse pass over the dual tail --------------------------------------------------------------------------
+        c2b, tc2b = [], []
+        for t_c2, h3b, th3b in zip(chunks(TC2), chunks(H3bar), chunks(TH3bar)):
+            x_bar, xd_bar, dg, db = T.bn_dual_backward(c["c2"], t_c2, h3b, th3b, P["bn2.weight"], P["bn2.bias"],
+                                                       c["s3"], "lrelu")
             Gd["bn2.weight"] += dg
             Gd["bn2.bias"] += db
-            Gd["conv2.bias"] += c2_bar.float().sum((0, 1, 2))
-            T.conv_wgrad(c["a3"], c2_bar, 3, 1, 1, 1, out=Gd["conv2.weight"], accumulate=True)
-            T.conv_wgrad(t_a3, tc2_bar, 3, 1, 1, 1, out=Gd["conv2.weight"], accumulate=True)
-            a3_bar = T.conv_dgrad(c2_bar, P["conv2.weight"], (Ho, Wo), 1, 1, 1)
-            ta3_bar = T.conv_dgrad(tc2_bar, P["conv2.weight"], (Ho, Wo), 1, 1, 1)
-            T.conv_wgrad(c["h2"], a3_bar, 1, out=Gd["conv1x1_2.weight"], accumulate=True)
-            T.conv_wgrad(t_h2, ta3_bar, 1, out=Gd["conv1x1_2.weight"], accumulate=True)
-            h2_bar = T.conv_dgrad(a3_bar, P["conv1x1_2.weight"], (Ho, Wo))
-            th2_bar = T.conv_dgrad(ta3_bar, P["conv1x1_2.weight"], (Ho, Wo))
-            a2_bar, u2_bar, dg, db = T.bn_dual_backward(c["a2"], u2, h2_bar, th2_bar, P["bn0_2.weight"],
-                                                        P["bn0_2.bias"], c["s2"], "lrelu")
+            c2b.append(x_bar)
+            tc2b.append(xd_bar)
+        C2bar, TC2bar = torch.cat(c2b), torch.cat(tc2b)
+        c2sum = ssum(C2bar)
+        Gd["conv2.bias"] += c2sum.float().sum((0, 1, 2))
+        T.conv_wgrad(c["a3"], c2sum, 3, 1, 1, 1, out=Gd["conv2.weight"], accumulate=True)
+        T.conv_wgrad(TA3, TC2bar, 3, 1, 1, 1, out=Gd["conv2.weight"], accumulate=True)
+        both = T.conv_dgrad(torch.cat([C2bar, TC2bar]), P["conv2.weight"], (Ho, Wo), 1, 1, 1)
+        A3bar, TA3bar = both[:n * B], both[n * B:]
+        a3sum = ssum(A3bar)
+        T.conv_wgrad(c["h2"], a3sum, 1, out=Gd["conv1x1_2.weight"], accumulate=True)
+        T.conv_wgrad(TH2, TA3bar, 1, out=Gd["conv1x1_2.weight"], accumulate=True)
+        both = T.conv_dgrad(both, P["conv1x1_2.weight"], (Ho, Wo))
+        H2bar, TH2bar = both[:n * B], both[n * B:]
+        a2sum, h1_bar = None, None
+        for u, h2b, th2b, v in zip(u2, chunks(H2bar), chunks(TH2bar), vs):
+            x_bar, u_bar, dg, db = T.bn_dual_backward(c["a2"], u, h2b, th2b, P["bn0_2.weight"], P["bn0_2.bias"],
+                                                      c["s2"], "lrelu")
             Gd["bn0_2.weight"] += dg
             Gd["bn0_2.bias"] += db
-            T.conv_wgrad(c["h1"], a2_bar, 3, 1, 1, 1, out=Gd["conv1.weight"], accumulate=True)
-            hb = T.conv_dgrad(a2_bar, P["conv1.weight"], (Ho, Wo), 1, 1, 1) + T.conv_dgrad(u2_bar, v, (Ho, Wo), 1, 1, 1)
+            a2sum = x_bar if a2sum is None else a2sum + x_bar
+            hb = T.conv_dgrad(u_bar, v, (Ho, Wo), 1, 1, 1)                        # through u = conv(h1, v_i)
             h1_bar = hb if h1_bar is None else h1_bar + hb
-            r_bar = a3_bar if r_bar is None else r_bar + a3_bar
+        T.conv_wgrad(c["h1"], a2sum, 3, 1, 1, 1, out=Gd["conv1.weight"], accumulate=True)
+        h1_bar = h1_bar + T.conv_dgrad(a2sum, P["conv1.weight"], (Ho, Wo), 1, 1, 1)
+        r_bar = a3sum
         return h1_bar, r_bar
 
     def _unit_offset(self, kind, u) -> int:
