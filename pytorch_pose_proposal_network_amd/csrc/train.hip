@@ -474,31 +474,46 @@ __global__ void __launch_bounds__(kThreads) bn_dual_reduce_kernel(const T* __res
                                                                   const float* __restrict__ rstd, int act,
                                                                   long long P, int C, Slab s,
                                                                   double* __restrict__ partial) {
-    __shared__ double red[kThreads][5];
+    __shared__ double red[kThreads][9];
     const int t = threadIdx.x;
     const int col = t % s.cc, roff = t / s.cc;
     const long long p0 = (long long)blockIdx.x * s.slab;
     const long long p1 = p0 + s.slab < P ? p0 + s.slab : P;
     const size_t row_bytes = (size_t)C * sizeof(T), cofs = (size_t)col * 8 * sizeof(T);
-    for (int j = 0; j < 8; ++j) {                      // one channel of the chunk at a time keeps the accumulators few
+    float mu[8], rs[8], sc[8], sh[8];
+    double acc[5][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
         const int c = col * 8 + j;
-        const float mu = mean[c], rs = rstd[c], sc = gamma[c] * rs, sh = beta[c] - mu * sc;
-        double a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;
-        for (long long p = p0 + roff; p < p1; p += s.rpi) {
-            const float xv = (float)reinterpret_cast<const T*>(reinterpret_cast<const char*>(x) + cofs + p * row_bytes)[j];
-            const float xd = (float)reinterpret_cast<const T*>(reinterpret_cast<const char*>(xdot) + cofs + p * row_bytes)[j];
-            const float dv = (float)reinterpret_cast<const T*>(reinterpret_cast<const char*>(dyt) + cofs + p * row_bytes)[j];
-            const float q = dv * act_slope(xv * sc + sh, act);
-            const float xh = (xv - mu) * rs;
-            a0 += q; a1 += (double)q * xh; a2 += xd; a3 += (double)xd * xh; a4 += (double)q * xd;
+        mu[j] = mean[c]; rs[j] = rstd[c];
+        sc[j] = gamma[c] * rs[j]; sh[j] = beta[c] - mu[j] * sc[j];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) acc[k][j] = 0.0;
+    }
+    for (long long p = p0 + roff; p < p1; p += s.rpi) {
+        float xv[8], xd[8], dv[8];
+        load8<T>(reinterpret_cast<const char*>(x) + cofs + p * row_bytes, xv);
+        load8<T>(reinterpret_cast<const char*>(xdot) + cofs + p * row_bytes, xd);
+        load8<T>(reinterpret_cast<const char*>(dyt) + cofs + p * row_bytes, dv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float q = dv[j] * act_slope(xv[j] * sc[j] + sh[j], act);
+            const float xh = (xv[j] - mu[j]) * rs[j];
+            acc[0][j] += q; acc[1][j] += (double)q * xh; acc[2][j] += xd[j]; acc[3][j] += (double)xd[j] * xh;
+            acc[4][j] += (double)q * xd[j];
         }
-        red[t][0] = a0; red[t][1] = a1; red[t][2] = a2; red[t][3] = a3; red[t][4] = a4;
+    }
+    // fold the row-threads of every chunk column, one of the five sums at a time (18 KB of LDS)
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[t][j] = acc[k][j];
         __syncthreads();
-        for (int o = t; o < s.cc * 5; o += kThreads) {
-            const int c_ = o / 5, k = o % 5;
-            double acc = 0.0;
-            for (int r = 0; r < s.rpi; ++r) acc += red[r * s.cc + c_][k];
-            partial[((size_t)blockIdx.x * C + c_ * 8 + j) * 5 + k] = acc;
+        for (int o = t; o < s.cc * 8; o += kThreads) {
+            const int c_ = o / 8, j = o % 8;
+            double a_ = 0.0;
+            for (int r = 0; r < s.rpi; ++r) a_ += red[r * s.cc + c_][j];
+            partial[((size_t)blockIdx.x * C + c_ * 8 + j) * 5 + k] = a_;
         }
         __syncthreads();
     }
