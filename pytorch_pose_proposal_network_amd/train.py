@@ -369,11 +369,12 @@ def _bwd_desc(x, dy, gamma, beta, saved, act, dx):
     return d
 
 
-def bn_tangent(x, xdot, gamma, beta, saved: BnSaved, act: str) -> torch.Tensor:
+def bn_tangent(x, xdot, gamma, beta, saved: BnSaved, act: str, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Forward-mode image of y = act(bn_train(x)) for an input tangent xdot: act'(z) * gamma*rstd*P(xdot)."""
     lib = L.load()
     jvp, _, _ = bn_train_backward(x, xdot, gamma, beta, saved, act="none")      # the BN tangent IS the backward formula
-    out = torch.empty_like(x)
+    if out is None:
+        out = torch.empty_like(x)
     d = _bwd_desc(x, jvp, gamma, beta, saved, act, out)
     L.check(lib.ppn_bn_act_mask(C.byref(d), L.current_stream_ptr()), "ppn_bn_act_mask")
     return out
@@ -382,13 +383,13 @@ def bn_tangent(x, xdot, gamma, beta, saved: BnSaved, act: str) -> torch.Tensor:
 _dual_ws = {}
 
 
-def bn_dual_backward(x, xdot, dy, dyt, gamma, beta, saved: BnSaved, act: str):
+def bn_dual_backward(x, xdot, dy, dyt, gamma, beta, saved: BnSaved, act: str, out_dx=None, out_dxdot=None):
     """Adjoint of the pair (y, ydot) = (act(bn(x)), bn_tangent(x, xdot)) for adjoints (dy, dyt).
     Returns (dx, dxdot, dgamma, dbeta): the ordinary backward of dy plus the tangent stream's contributions."""
     lib = L.load()
     c = x.shape[-1]
-    dx, dgamma, dbeta = bn_train_backward(x, dy, gamma, beta, saved, act=act)
-    dxdot, _, _ = bn_train_backward(x, dyt, gamma, beta, saved, act=act)        # (gamma*rstd) P(dyt * act')
+    dx, dgamma, dbeta = bn_train_backward(x, dy, gamma, beta, saved, act=act, out=out_dx)
+    dxdot, _, _ = bn_train_backward(x, dyt, gamma, beta, saved, act=act, out=out_dxdot)   # (gamma*rstd) P(dyt * act')
     key = (c, str(x.device), torch.cuda.current_stream(x.device).cuda_stream)
     ws = _dual_ws.get(key)
     if ws is None:

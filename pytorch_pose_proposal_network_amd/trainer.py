@@ -396,11 +396,14 @@ class PPNTrainer:
         # stacked along the batch dimension for the convolutions (one launch for all of them); the BN tangents need
         # per-stream batch statistics and run stream by stream.
         u2 = [T.conv2d_nhwc(c["h1"], v, 1, 1, 1) for v in vs]
-        TH2 = torch.cat([T.bn_tangent(c["a2"], u, P["bn0_2.weight"], P["bn0_2.bias"], c["s2"], "lrelu") for u in u2])
+        TH2 = torch.empty(n * B, *c["a2"].shape[1:], dtype=self.tdt, device=self.device)
+        for u, dst in zip(u2, chunks(TH2)):
+            T.bn_tangent(c["a2"], u, P["bn0_2.weight"], P["bn0_2.bias"], c["s2"], "lrelu", out=dst)
         TA3 = T.conv2d_nhwc(TH2, P["conv1x1_2.weight"])
         TC2 = T.conv2d_nhwc(TA3, P["conv2.weight"], 1, 1, 1)
-        TH3 = torch.cat([T.bn_tangent(c["c2"], t, P["bn2.weight"], P["bn2.bias"], c["s3"], "lrelu")
-                         for t in chunks(TC2)])
+        TH3 = torch.empty_like(TC2)
+        for t, dst in zip(chunks(TC2), chunks(TH3)):
+            T.bn_tangent(c["c2"], t, P["bn2.weight"], P["bn2.bias"], c["s3"], "lrelu", out=dst)
         # ---- head space per stream: gradient and Hessian-vector product of loss i through the sigmoid.  The unary
         # losses only touch the first 6K channels: their streams share 128-channel conv3 launches.
         H3bar = torch.empty_like(TH3)
@@ -430,20 +433,18 @@ class PPNTrainer:
             H3bar[js[0] * B:(js[-1] + 1) * B] = T.conv_dgrad(zb, w3p, (Ho, Wo))
             TH3bar[js[0] * B:(js[-1] + 1) * B] = T.conv_dgrad(tzb, w3p, (Ho, Wo))
         # ---- reverse pass over the dual tail --------------------------------------------------------------------------
-        c2b, tc2b = [], []
-        for t_c2, h3b, th3b in zip(chunks(TC2), chunks(H3bar), chunks(TH3bar)):
-            x_bar, xd_bar, dg, db = T.bn_dual_backward(c["c2"], t_c2, h3b, th3b, P["bn2.weight"], P["bn2.bias"],
-                                                       c["s3"], "lrelu")
+        both = torch.empty(2 * n * B, *TC2.shape[1:], dtype=self.tdt, device=self.device)   # [primal adj | tangent adj]
+        C2bar, TC2bar = both[:n * B], both[n * B:]
+        for t_c2, h3b, th3b, ox, oxd in zip(chunks(TC2), chunks(H3bar), chunks(TH3bar), chunks(C2bar), chunks(TC2bar)):
+            _, _, dg, db = T.bn_dual_backward(c["c2"], t_c2, h3b, th3b, P["bn2.weight"], P["bn2.bias"], c["s3"], "lrelu",
+                                              out_dx=ox, out_dxdot=oxd)
             Gd["bn2.weight"] += dg
             Gd["bn2.bias"] += db
-            c2b.append(x_bar)
-            tc2b.append(xd_bar)
-        C2bar, TC2bar = torch.cat(c2b), torch.cat(tc2b)
         c2sum = ssum(C2bar)
         Gd["conv2.bias"] += c2sum.float().sum((0, 1, 2))
         T.conv_wgrad(c["a3"], c2sum, 3, 1, 1, 1, out=Gd["conv2.weight"], accumulate=True)
         T.conv_wgrad(TA3, TC2bar, 3, 1, 1, 1, out=Gd["conv2.weight"], accumulate=True)
-        both = T.conv_dgrad(torch.cat([C2bar, TC2bar]), P["conv2.weight"], (Ho, Wo), 1, 1, 1)
+        both = T.conv_dgrad(both, P["conv2.weight"], (Ho, Wo), 1, 1, 1)
         A3bar, TA3bar = both[:n * B], both[n * B:]
         a3sum = ssum(A3bar)
         T.conv_wgrad(c["h2"], a3sum, 1, out=Gd["conv1x1_2.weight"], accumulate=True)
