@@ -369,7 +369,11 @@ class PPNTrainer:
             main.wait_stream(so["stream"])                # the unary probe gradients
         gw = list(so["unary"])
         acc = sum(float(coeff[i]) * gw[i] for i in range(4))
-        gw.append((self.G["conv1.weight"] - acc) / float(coeff[4]))            # limb probe gradient by linearity
+        if coeff[4] > 1e-3 * max(coeff):
+            gw.append((self.G["conv1.weight"] - acc) / float(coeff[4]))        # limb probe gradient by linearity
+        else:                                                                     # too small to divide by: direct pass
+            _, g4 = self.criterion.forward_backward(head, targets, coeff=[0.0, 0.0, 0.0, 0.0, 1.0])
+            gw.append(self.probe_grad(g4))
         gn = torch.stack([T.sumsq(g.contiguous().view(-1)).sqrt().reshape(()) for g in gw])
         so["gnorm"] = gn
         w = self.task.w
