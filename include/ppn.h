@@ -357,6 +357,11 @@ int ppn_colsum(int32_t dtype, const void* x, int64_t pixels, int32_t channels, f
 int ppn_head_grad(int32_t dtype, const float* head, const float* grad_head, int32_t batch, int32_t channels,
                   int32_t hw, int32_t channels_used, int32_t channels_pad, void* dz, float* dbias, void* stream);
 
+/* Bottleneck tail (drn.py:92-95): out = relu(z + r), and its backward dz = dout * (out > 0) (+ add); n elements,
+ * a multiple of 8, any contiguous layout. */
+int ppn_add_relu(int32_t dtype, const void* z, const void* r, int64_t n, void* out, void* stream);
+int ppn_relu_mask(int32_t dtype, const void* out, const void* dout, const void* add, int64_t n, void* dz, void* stream);
+
 /*
  * A15: one torch.optim.Adam step (main.py:278-279: betas (0.9, 0.999), eps 1e-8, weight_decay 0, no amsgrad)
  * over a flat f32 buffer -- the whole model is one launch.  `step` is the 1-based step count.

@@ -584,6 +584,43 @@ __global__ void __launch_bounds__(kThreads) bn_dual_apply_kernel(const T* __rest
     }
 }
 
+
+// ---- Bottleneck tail: out = relu(z + r) (drn.py:92-95) and its backward mask -------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(kThreads) add_relu_kernel(const T* __restrict__ z, const T* __restrict__ r, long long n8,
+                                                            T* __restrict__ out) {
+    const long long stride = (long long)gridDim.x * kThreads;
+    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n8; i += stride) {
+        float a[8], b[8];
+        load8<T>(reinterpret_cast<const char*>(z) + i * 8 * sizeof(T), a);
+        load8<T>(reinterpret_cast<const char*>(r) + i * 8 * sizeof(T), b);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float v = a[j] + b[j]; a[j] = v > 0.f ? v : 0.f; }
+        store8<T>(reinterpret_cast<char*>(out) + i * 8 * sizeof(T), a);
+    }
+}
+// dz = dout * (out > 0)   [+ add]
+template <typename T>
+__global__ void __launch_bounds__(kThreads) relu_mask_kernel(const T* __restrict__ out, const T* __restrict__ dout,
+                                                             const T* __restrict__ add, long long n8,
+                                                             T* __restrict__ dz) {
+    const long long stride = (long long)gridDim.x * kThreads;
+    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n8; i += stride) {
+        float o[8], g[8];
+        load8<T>(reinterpret_cast<const char*>(out) + i * 8 * sizeof(T), o);
+        load8<T>(reinterpret_cast<const char*>(dout) + i * 8 * sizeof(T), g);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) g[j] = o[j] > 0.f ? g[j] : 0.f;
+        if (add) {
+            float r[8];
+            load8<T>(reinterpret_cast<const char*>(add) + i * 8 * sizeof(T), r);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) g[j] += r[j];
+        }
+        store8<T>(reinterpret_cast<char*>(dz) + i * 8 * sizeof(T), g);
+    }
+}
+
 int make_slab(int C, long long P, Slab* s) {
     if (C < 8 || C > 2048 || (C & (C - 1)) != 0)
         return ppn::fail(PPN_E_UNSUPPORTED, "BatchNorm channels must be a power of two in [8, 2048], got %d", C);
@@ -815,6 +852,34 @@ int ppn_bn_dual_bwd(const ppn_bn_bwd_desc* d, const void* xdot, float* dgamma_ta
                                                                      (const __bf16*)d->dy, d->gamma, d->beta,
                                                                      d->save_mean, d->save_rstd, coef, d->act, d->pixels,
                                                                      C, s, (__bf16*)d->dx);
+    PPN_LAUNCH_CHECK();
+    return PPN_OK;
+}
+
+int ppn_add_relu(int32_t dtype, const void* z, const void* r, int64_t n, void* out, void* stream) {
+    if (!z || !r || !out || n < 0 || n % 8) return ppn::fail(PPN_E_INVALID, "ppn_add_relu: NULL pointer or n %% 8 != 0");
+    long long blocks = (n / 8 + kThreads - 1) / kThreads;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks < 1) return PPN_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == PPN_F32) add_relu_kernel<float><<<(int)blocks, kThreads, 0, st>>>((const float*)z, (const float*)r, n / 8, (float*)out);
+    else if (dtype == PPN_BF16) add_relu_kernel<__bf16><<<(int)blocks, kThreads, 0, st>>>((const __bf16*)z, (const __bf16*)r, n / 8, (__bf16*)out);
+    else return ppn::fail(PPN_E_INVALID, "bad dtype %d", dtype);
+    PPN_LAUNCH_CHECK();
+    return PPN_OK;
+}
+
+int ppn_relu_mask(int32_t dtype, const void* out, const void* dout, const void* add, int64_t n, void* dz, void* stream) {
+    if (!out || !dout || !dz || n < 0 || n % 8) return ppn::fail(PPN_E_INVALID, "ppn_relu_mask: NULL pointer or n %% 8 != 0");
+    long long blocks = (n / 8 + kThreads - 1) / kThreads;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks < 1) return PPN_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == PPN_F32)
+        relu_mask_kernel<float><<<(int)blocks, kThreads, 0, st>>>((const float*)out, (const float*)dout, (const float*)add, n / 8, (float*)dz);
+    else if (dtype == PPN_BF16)
+        relu_mask_kernel<__bf16><<<(int)blocks, kThreads, 0, st>>>((const __bf16*)out, (const __bf16*)dout, (const __bf16*)add, n / 8, (__bf16*)dz);
+    else return ppn::fail(PPN_E_INVALID, "bad dtype %d", dtype);
     PPN_LAUNCH_CHECK();
     return PPN_OK;
 }

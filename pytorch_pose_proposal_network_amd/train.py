@@ -411,3 +411,20 @@ def nchw_to_nhwc(src: torch.Tensor, dtype: torch.dtype, channels_used=None) -> t
     L.check(L.load().ppn_nchw_to_nhwc(L.PPN_F32 if dtype == torch.float32 else L.PPN_BF16, src.data_ptr(), B, Cn,
                                       H * W, used, cpad, out.data_ptr(), L.current_stream_ptr()), "ppn_nchw_to_nhwc")
     return out
+
+
+def add_relu(z: torch.Tensor, r: torch.Tensor) -> torch.Tensor:
+    """relu(z + r): the tail of a Bottleneck (drn.py:92-95)."""
+    out = torch.empty_like(z)
+    L.check(L.load().ppn_add_relu(_dtype_code(z), z.data_ptr(), r.data_ptr(), z.numel(), out.data_ptr(),
+                                  L.current_stream_ptr()), "ppn_add_relu")
+    return out
+
+
+def relu_mask(out: torch.Tensor, dout: torch.Tensor, add: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dout * (out > 0) (+ add): backward of out = relu(.)."""
+    dz = torch.empty_like(out)
+    L.check(L.load().ppn_relu_mask(_dtype_code(out), out.data_ptr(), dout.data_ptr(),
+                                   add.data_ptr() if add is not None else None, out.numel(), dz.data_ptr(),
+                                   L.current_stream_ptr()), "ppn_relu_mask")
+    return dz

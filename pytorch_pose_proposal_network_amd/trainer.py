@@ -44,8 +44,6 @@ class PPNTrainer:
                  lr: float = 7e-4, lr_weights: Optional[float] = None, alpha: float = 0.12, insize=(384, 384),
                  device="cuda", second_order: bool = True):
         L.load()                                               # fail loudly without libppn.so
-        if A.DRN_D[arch][0] != "basic":
-            raise NotImplementedError("training is implemented for the BasicBlock DRN-D variants (22/24/38/40)")
         self.arch, self.compute_dtype, self.device = arch, compute_dtype, torch.device(device)
         self.tdt = torch.float32 if compute_dtype == L.PPN_F32 else torch.bfloat16
         self.units = A._units(arch)
@@ -275,6 +273,25 @@ class PPNTrainer:
                 out = T.conv2d_nhwc(b, self.P[p + ".conv2.weight"], 1, u.dil[1], u.dil[1], add=r)
                 tape.append(("basic", u, ctx))
                 cur = out
+            elif u.kind == "bottleneck":                              # drn.py:77-97 (post-activation)
+                p, pl = u.prefix, u.planes
+                y1 = T.conv2d_nhwc(cur, self.P[p + ".conv1.weight"])
+                h1, s1 = self._bn(y1, p + ".bn1", "relu")
+                y2 = T.conv2d_nhwc(h1, self.P[p + ".conv2.weight"], u.stride, u.dil[1], u.dil[1])
+                h2, s2 = self._bn(y2, p + ".bn2", "relu")
+                y3 = T.conv2d_nhwc(h2, self.P[p + ".conv3.weight"])
+                z3, s3 = self._bn(y3, p + ".bn3", "none")
+                ctx = dict(x=cur, y1=y1, h1=h1, s1=s1, y2=y2, h2=h2, s2=s2, y3=y3, s3=s3)
+                if u.downsample:
+                    yd = T.conv2d_nhwc(cur, self.P[p + ".downsample.0.weight"], u.stride, 1, 0)
+                    r, sd = self._bn(yd, p + ".downsample.1", "none")
+                    ctx.update(yd=yd, sd=sd)
+                else:
+                    r = cur
+                out = T.add_relu(z3, r)
+                ctx["out"] = out
+                tape.append(("bottleneck", u, ctx))
+                cur = out
             else:                                                     # PPN head, model.py:113-136
                 R = cur
                 h0, s0 = self._bn(R, "bn0_1", "lrelu")
@@ -473,7 +490,7 @@ class PPNTrainer:
         """First element of the flat buffer that belongs to this unit (its parameters are contiguous)."""
         if kind == "head":
             return self.offset["conv1x1_1.weight"]
-        if kind == "basic":
+        if kind in ("basic", "bottleneck"):
             return self.offset[u.prefix + ".conv1.weight"]
         return self.offset[f"{u.prefix}.{u.conv_idx}.weight"]
 
@@ -515,6 +532,25 @@ class PPNTrainer:
                 else:
                     dxr = g
                 g = self._bn_bwd(c["x"], da, p + ".bn1", "relu", c["s1"], dx_add=dxr)
+            elif kind == "bottleneck":
+                p = u.prefix
+                hw = c["x"].shape[1:3]
+                dsum = T.relu_mask(c["out"], g)                              # through relu(z3 + r)
+                dy3 = self._bn_bwd(c["y3"], dsum, p + ".bn3", "none", c["s3"])
+                self._wgrad(p + ".conv3.weight", c["h2"], dy3, 1)
+                dh2 = T.conv_dgrad(dy3, self.P[p + ".conv3.weight"], c["h2"].shape[1:3])
+                dy2 = self._bn_bwd(c["y2"], dh2, p + ".bn2", "relu", c["s2"])
+                self._wgrad(p + ".conv2.weight", c["h1"], dy2, 3, u.stride, u.dil[1], u.dil[1])
+                dh1 = T.conv_dgrad(dy2, self.P[p + ".conv2.weight"], c["h1"].shape[1:3], u.stride, u.dil[1], u.dil[1])
+                dy1 = self._bn_bwd(c["y1"], dh1, p + ".bn1", "relu", c["s1"])
+                self._wgrad(p + ".conv1.weight", c["x"], dy1, 1)
+                if u.downsample:
+                    dyd = self._bn_bwd(c["yd"], dsum, p + ".downsample.1", "none", c["sd"])
+                    self._wgrad(p + ".downsample.0.weight", c["x"], dyd, 1, u.stride, 1, 0)
+                    dxr = T.conv_dgrad(dyd, self.P[p + ".downsample.0.weight"], hw, u.stride, 1, 0)
+                else:
+                    dxr = dsum
+                g = T.conv_dgrad(dy1, self.P[p + ".conv1.weight"], hw, add=dxr)
             else:  # cbr
                 wn = f"{u.prefix}.{u.conv_idx}.weight"
                 bnp = f"{u.prefix}.{u.conv_idx + 1}"
