@@ -29,6 +29,13 @@ namespace {
 
 using namespace ppnconv;
 
+// Build-time diagnostics (tools/build_variant.py NAME conv_big.hip -DPPN_DIAG=n): TIMING ONLY, results are wrong.
+//   1 = no wait for the DMA, 2 = no DMA in the K loop, 3 = 32x32x16 MFMAs (half the MFMA issue slots) on the same reads,
+//   4 = 2 and 3 together, 5 = 2 without the per-step barrier, 6 = 2 without the LDS fragment reads,
+//   7 = no global stores in the NHWC epilogue
+#ifndef PPN_DIAG
+#define PPN_DIAG 0
+#endif
 constexpr unsigned kOOB = 0x80000000u;   // byte offset beyond any tensor this kernel accepts (< 2 GiB)
 
 template <typename F, int... I>
@@ -69,6 +76,13 @@ __device__ __forceinline__ void store4<__bf16>(char* p, const float* v) {
     *reinterpret_cast<bf16x4*>(p) = o;
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it waits until every
+// global store (and atomic) this wave has issued is acknowledged -- in the epilogue that put one full store round
+// trip on the critical path of every chunk.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 __device__ __forceinline__ void bufload_lds16(__amdgpu_buffer_rsrc_t rsrc, char* lds_wave_base, unsigned voff,
                                               unsigned soff) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (void __attribute__((address_space(3)))*)lds_wave_base, 16, voff,
@@ -94,6 +108,9 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
     static_assert(TP <= 8 && TC <= 8 && TC * TP % 4 == 0, "accumulators must fit the register file");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef PPN_CLOCK
+    const unsigned long long ck_entry = __builtin_amdgcn_s_memtime();
+#endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wc = wave / WP, wp = wave % WP;
@@ -131,12 +148,16 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
         const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
         const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
         xbase[j] = (((b * a.H + iy0) * a.W + ix0) * a.Cin + chunk * EPC) * ES;
-        unsigned mk = 0;
-        for (int t = 0; t < ntaps; ++t) {
-            const int dy = t / a.ks, dx = t - dy * a.ks;
-            const int iy = iy0 + dy * a.dil, ix = ix0 + dx * a.dil;
-            if (vm && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) mk |= (1u << t);
-        }
+        // tap t = dy * ks + dx is in bounds iff its row and its column are: ks column bits, replicated per valid row
+        // (no per-tap division: this runs once per workgroup but on the critical path of the first DMA)
+        unsigned mk = 0, cx = 0;
+#pragma unroll
+        for (int dx = 0; dx < 5; ++dx)                               // ksize <= 5 (checked by ppn_conv2d_fused)
+            cx |= (dx < a.ks && (unsigned)(ix0 + dx * a.dil) < (unsigned)a.W) ? (1u << dx) : 0u;
+#pragma unroll
+        for (int dy = 0; dy < 5; ++dy)
+            mk |= (dy < a.ks && (unsigned)(iy0 + dy * a.dil) < (unsigned)a.H) ? (cx << (dy * a.ks)) : 0u;
+        mk = vm ? mk : 0u;
         xmask[j] = mk | (vm ? 0x80000000u : 0u);
         if constexpr (SC)
             xbase2[j] = (((b * a.H2 + oy * a.stride2) * a.W2 + ox * a.stride2) * a.Cin2 + chunk * EPC) * ES;
@@ -224,6 +245,9 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
     constexpr int NRD = TC + TP;                                     // ds_read_b128 per fragment set
     auto read_one = [&](auto rc, f32x4 (&wf)[TC], f32x4 (&xf)[TP], int buf, int ks) {
         constexpr int r = decltype(rc)::value;
+#if PPN_DIAG == 6
+        if (buf >= 0 && ks >= 0 && nsteps > 0) { asm volatile("" : "+v"(xf[0]), "+v"(wf[0])); return; }
+#endif
         if constexpr (r < TP)
             xf[r] = *reinterpret_cast<const f32x4*>(smem + buf * STAGE + x_tile_off + foff[ks] + r * 16 * 128);
         else
@@ -231,8 +255,26 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
     };
     // MFMA group: 4 consecutive output tiles of the wave (flat index = i*TP + j)
     constexpr int NG = TC * TP / 4;
+#if PPN_DIAG == 3 || PPN_DIAG == 4
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    f32x16 acc32[TC * TP / 4];
+#pragma unroll
+    for (int i = 0; i < TC * TP / 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc32[i][j] = 0.f;
+#endif
     auto mma_group = [&](auto gc, const f32x4 (&wf)[TC], const f32x4 (&xf)[TP]) {
         constexpr int g = decltype(gc)::value;
+#if PPN_DIAG == 3 || PPN_DIAG == 4
+        if constexpr (std::is_same<T, __bf16>::value) {
+            constexpr int i0 = g * 4, i1 = g * 4 + 3;
+            acc32[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[i0 / TP]),
+                                                               __builtin_bit_cast(bf16x8, xf[i0 % TP]), acc32[g], 0, 0, 0);
+            acc32[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[i1 / TP]),
+                                                               __builtin_bit_cast(bf16x8, xf[i1 % TP]), acc32[g], 0, 0, 0);
+            return;
+        }
+#endif
         static_for<4>([&](auto tc) {
             constexpr int idx = g * 4 + decltype(tc)::value;
             mma_step(acc[idx / TP][idx % TP], wf[idx / TP], xf[idx % TP], (T*)nullptr);
@@ -242,14 +284,22 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
     constexpr int LPG = (NL + NG - 1) / NG;                          // DMA issues per MFMA group
 
     // ---- prologue: stage 0 -> LDS, both fragment sets of stage 0, stage 1 in flight --------------
+#ifdef PPN_CLOCK
+    const unsigned long long ck_state = __builtin_amdgcn_s_memtime();
+#endif
+    // Both stages are requested before the first wait, so their (cold) fill latencies overlap; LDS-DMA completes
+    // in issue order, so "all but the NL youngest" means stage 0 has landed.
     static_for<NL>([&](auto gc) { issue_one(gc, 0); });
     advance();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    static_for<NRD>([&](auto rc) { read_one(rc, wA, xA, 0, 0); });
-    static_for<NRD>([&](auto rc) { read_one(rc, wB, xB, 0, 1); });
     static_for<NL>([&](auto gc) { issue_one(gc, 1); });
     advance();
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");
+    __syncthreads();
+#ifdef PPN_CLOCK
+    const unsigned long long ck_bar = __builtin_amdgcn_s_memtime();
+#endif
+    static_for<NRD>([&](auto rc) { read_one(rc, wA, xA, 0, 0); });
+    static_for<NRD>([&](auto rc) { read_one(rc, wB, xB, 0, 1); });
     static_for<NG>([&](auto gc) { mma_group(gc, wA, xA); });
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
@@ -265,6 +315,10 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
 #else
 #define PPN_T(var) do { } while (0)
 #endif
+#ifdef PPN_CLOCK
+    // in-kernel clock: shader cycles (s_memtime) over the 100 MHz constant clock (s_memrealtime) around the K loop
+    const unsigned long long ck0 = __builtin_amdgcn_s_memtime(), rk0 = __builtin_amdgcn_s_memrealtime();
+#endif
     for (int s = 1; s < nsteps; ++s) {
         const int buf = s & 1;
 #ifdef PPN_STAMP
@@ -273,10 +327,12 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
         static_for<NG>([&](auto gc) {
             constexpr int g = decltype(gc)::value;
             mma_group(gc, wB, xB);
+#if PPN_DIAG != 2 && PPN_DIAG != 4 && PPN_DIAG != 5 && PPN_DIAG != 6
             static_for<LPG>([&](auto lc) {
                 constexpr int l = g * LPG + decltype(lc)::value;
                 if constexpr (l < NL) issue_one(std::integral_constant<int, l>{}, buf ^ 1);
             });
+#endif
             static_for<RPG>([&](auto rc) {
                 constexpr int r = g * RPG + decltype(rc)::value;
                 if constexpr (r < NRD) read_one(std::integral_constant<int, r>{}, wA, xA, buf, 0);
@@ -299,15 +355,30 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
 #ifdef PPN_STAMP
         PPN_T(tq0); st_b2 += tq0 - tq1;
 #endif
+#if PPN_DIAG == 1
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
 #ifdef PPN_STAMP
         PPN_T(tq1); st_wait += tq1 - tq0;
 #endif
+#if PPN_DIAG != 5
         __syncthreads();
+#endif
 #ifdef PPN_STAMP
         PPN_T(tq0); st_bar += tq0 - tq1;
 #endif
     }
+#ifdef PPN_CLOCK
+    {
+        const unsigned long long ck1 = __builtin_amdgcn_s_memtime(), rk1 = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0 && a.scale2 == nullptr && a.shift2 != nullptr) {   // diagnostic channel: shift2 = u64 buffer
+            unsigned long long* dbg = (unsigned long long*)a.shift2 + ((size_t)blockIdx.x * NW + wave) * 8;
+            dbg[0] = ck1 - ck0; dbg[1] = rk1 - rk0; dbg[2] = ck0 - ck_entry; dbg[3] = ck1; dbg[5] = ck_state - ck_entry; dbg[6] = ck_bar - ck_entry;
+        }
+    }
+#endif
 #ifdef PPN_STAMP
     unsigned long long t_epi0;
     PPN_T(t_epi0);
@@ -317,6 +388,12 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
     }
 #endif
     static_for<NG>([&](auto gc) { mma_group(gc, wB, xB); });
+#if PPN_DIAG == 3 || PPN_DIAG == 4
+#pragma unroll
+    for (int i = 0; i < TC * TP / 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[(i * 4 + j / 4) / TP][(i * 4 + j / 4) % TP][j % 4] += acc32[i][j];
+#endif
     __syncthreads();                                                 // LDS is reused by the epilogue
 
     // ---- epilogue through LDS chunks of 64 pixels (NHWC) / 64 channels (NCHW head) -------------------
@@ -330,20 +407,31 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
         static_assert((size_t)CPX * LD * 4 <= 2 * (size_t)STAGE, "epilogue chunk must fit the staging LDS");
         const int cg = tid % TPP, prow = tid / TPP;
         const int c = c0 + cg * 8;
-        // NHWC layers only use none / ReLU / LeakyReLU(0.1): all three are  t > 0 ? t : t * slope  (branch-free)
+        // NHWC layers only use none / ReLU / LeakyReLU(0.1): all three are  t > 0 ? t : t * slope  =  max(t, t * slope)
+        // for slope in [0, 1] (same values, signed zeros included; one v_max instead of compare + select)
         const float slope1 = a.act1 == PPN_ACT_RELU ? 0.f : (a.act1 == PPN_ACT_LRELU ? 0.1f : 1.f);
         const float slope2 = a.act2 == PPN_ACT_RELU ? 0.f : (a.act2 == PPN_ACT_LRELU ? 0.1f : 1.f);
         float s1[8], b1[8], s2[8], b2[8];
+        // 8 consecutive channels per thread: two 16-byte loads where the run is whole and aligned
+        auto affine8 = [&](const float* p, float dflt, float* o) {
+            if (p && c + 8 <= a.Cout && (reinterpret_cast<size_t>(p) & 15) == 0) {
+                const float4 lo = *reinterpret_cast<const float4*>(p + c), hi = *reinterpret_cast<const float4*>(p + c + 4);
+                o[0] = lo.x; o[1] = lo.y; o[2] = lo.z; o[3] = lo.w; o[4] = hi.x; o[5] = hi.y; o[6] = hi.z; o[7] = hi.w;
+            } else {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const bool cv = c + i < a.Cout;
-            s1[i] = (a.scale1 && cv) ? a.scale1[c + i] : 1.f;
-            b1[i] = (a.shift1 && cv) ? a.shift1[c + i] : 0.f;
-            s2[i] = (a.scale2 && cv) ? a.scale2[c + i] : 1.f;
-            b2[i] = (a.shift2 && cv) ? a.shift2[c + i] : 0.f;
-        }
+                for (int i = 0; i < 8; ++i) o[i] = (p && c + i < a.Cout) ? p[c + i] : dflt;
+            }
+        };
+        affine8(a.scale1, 1.f, s1); affine8(a.shift1, 0.f, b1);
+        affine8(a.scale2, 1.f, s2); affine8(a.shift2, 0.f, b2);
+#ifdef PPN_CLOCK
+        unsigned long long ep_w = 0, ep_s = 0;
+#endif
         auto chunk = [&](auto qc) {
             constexpr int q = decltype(qc)::value;
+#ifdef PPN_CLOCK
+            const unsigned long long e0 = __builtin_amdgcn_s_memtime();
+#endif
 #pragma unroll
             for (int jj = 0; jj < JC; ++jj)
 #pragma unroll
@@ -352,11 +440,16 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
                     const int ch = wc * (BC / 2) + i * 16 + 4 * fq;
                     *reinterpret_cast<f32x4*>(ct + px * LD + ch) = acc[i][q * JC + jj];
                 }
-            __syncthreads();
+            lds_barrier();
+#ifdef PPN_CLOCK
+            const unsigned long long e1 = __builtin_amdgcn_s_memtime();
+#endif
             if (c < a.Cout) {
                 constexpr int NPASS = CPX / PPP;
                 int mrow[NPASS];
+                size_t moff[NPASS];                                  // byte offset of (row, c) in the NHWC tensors
                 float res[NPASS][8];
+                const size_t row_bytes = (size_t)a.Cout * ES;
                 // residual rows of ALL passes are requested first: one memory latency per chunk, not per pass
 #pragma unroll
                 for (int pass = 0; pass < NPASS; ++pass) {
@@ -364,9 +457,16 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
                     const int pw = px / (JC * 16), pj = (px / 16) % JC, pr = px % 16;
                     const int m = m0 + pw * (BP / WP) + (q * JC + pj) * 16 + pr;
                     mrow[pass] = m < a.M ? m : -1;
+                    if constexpr (JC == 1 && PPP % 16 == 0) {
+                        // rows of successive passes are a fixed distance apart: one 64-bit multiply per chunk
+                        constexpr int DM = (PPP / 16) * (BP / WP);
+                        moff[pass] = pass == 0 ? (size_t)m * row_bytes + (size_t)c * ES : moff[0] + pass * (DM * row_bytes);
+                    } else {
+                        moff[pass] = (size_t)m * row_bytes + (size_t)c * ES;
+                    }
 #pragma unroll
                     for (int i = 0; i < 8; ++i) res[pass][i] = 0.f;
-                    if (a.residual && m < a.M) load8<T>(a.residual + ((size_t)m * a.Cout + c) * ES, res[pass]);
+                    if (a.residual && m < a.M) load8<T>(a.residual + moff[pass], res[pass]);
                 }
 #pragma unroll
                 for (int pass = 0; pass < NPASS; ++pass) {
@@ -377,28 +477,42 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
                         const f32x4 hi = *reinterpret_cast<const f32x4*>(ct + px * LD + cg * 8 + 4);
                         v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w;
                         v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
-                        const size_t off = ((size_t)mrow[pass] * a.Cout + c) * ES;
+                        const size_t off = moff[pass];
 #pragma unroll
                         for (int i = 0; i < 8; ++i) {
                             const float t1 = v[i] * s1[i] + b1[i];
-                            v[i] = (t1 > 0.f ? t1 : t1 * slope1) + res[pass][i];
+                            v[i] = fmaxf(t1, t1 * slope1) + res[pass][i];
                         }
+#if PPN_DIAG == 7
+                        if (a.out_raw && v[0] == 12345.678f) store8<T>(a.out_raw + off, v);
+#else
                         if (a.out_raw) store8<T>(a.out_raw + off, v);
+#endif
                         if (a.out_act) {
                             float u[8];
 #pragma unroll
                             for (int i = 0; i < 8; ++i) {
                                 const float t2 = v[i] * s2[i] + b2[i];
-                                u[i] = t2 > 0.f ? t2 : t2 * slope2;
+                                u[i] = fmaxf(t2, t2 * slope2);
                             }
                             store8<T>(a.out_act + off, u);
                         }
                     }
                 }
             }
-            __syncthreads();
+            lds_barrier();
+#ifdef PPN_CLOCK
+            const unsigned long long e2 = __builtin_amdgcn_s_memtime();
+            ep_w += e1 - e0; ep_s += e2 - e1;
+#endif
         };
         static_for<TP / JC>(chunk);
+#ifdef PPN_CLOCK
+        if (lane == 0 && a.scale2 == nullptr && a.shift2 != nullptr) {
+            unsigned long long* dbg = (unsigned long long*)a.shift2 + ((size_t)blockIdx.x * NW + wave) * 8;
+            dbg[7] = (ep_w << 32) | ep_s;
+        }
+#endif
     } else {
         // head: f32 NCHW [B, Cout, Ho*Wo] (model.py:136): 64 channels per chunk, pixel-contiguous rows
         constexpr int LD = BP + 4;                                   // [channel][pixel] f32
@@ -427,7 +541,7 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
                 ct_affine[tid] = (a.scale1 && c < a.Cout) ? a.scale1[c] : 1.f;
                 ct_affine[2 * IC * 16 + tid] = (a.shift1 && c < a.Cout) ? a.shift1[c] : 0.f;
             }
-            __syncthreads();
+            lds_barrier();
             if (a.amax_keys) {
                 // Fused decode front end: one thread per (pixel, 32-channel run).  Channels < unary_ch (resp, conf,
                 // x, y, w, h) go to the compact tensor; every limb channel competes in its (image, edge, cell)
@@ -503,10 +617,16 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
                     }
                 }
             }
-            __syncthreads();
+            lds_barrier();
         };
         static_for<TC / IC>(chunk);
     }
+#ifdef PPN_CLOCK
+    if (lane == 0 && a.scale2 == nullptr && a.shift2 != nullptr) {
+        unsigned long long* dbg = (unsigned long long*)a.shift2 + ((size_t)blockIdx.x * NW + wave) * 8;
+        dbg[4] = __builtin_amdgcn_s_memtime() - dbg[3];           // epilogue cycles
+    }
+#endif
 #ifdef PPN_STAMP
     {
         unsigned long long t_epi1;
