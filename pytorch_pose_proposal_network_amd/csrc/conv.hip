@@ -48,7 +48,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvKArgs a) {
         const int nb = gridDim.x, id = blockIdx.x;
         const int xcd = id & 7, loc = id >> 3, q = nb >> 3, r = nb & 7;
         const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-        ptile = logical / a.n_ctiles;
+        ptile = fast_div(logical, a.div_nct);
         ctile = logical - ptile * a.n_ctiles;
     }
     const int m0 = ptile * BP, c0 = ctile * BC;
@@ -66,17 +66,19 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvKArgs a) {
         const int m = m0 + row;
         const bool vm = m < a.M;
         const int mm = vm ? m : 0;
-        const int b = mm / a.HoWo, rem = mm - b * a.HoWo;
-        const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+        const int b = fast_div(mm, a.div_howo), rem = mm - b * a.HoWo;
+        const int oy = fast_div(rem, a.div_wo), ox = rem - oy * a.Wo;
         const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
         xbase[j] = ((b * a.H + iy0) * a.W + ix0) * a.Cin;
-        unsigned mk = 0;
-        for (int t = 0; t < ntaps; ++t) {
-            const int dy = t / a.ks, dx = t - dy * a.ks;
-            const int iy = iy0 + dy * a.dil, ix = ix0 + dx * a.dil;
-            if (vm && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) mk |= (1u << t);
-        }
-        xmask[j] = mk;
+        // tap t = dy * ks + dx is in bounds iff its row and its column are (no per-tap division; ksize <= 5)
+        unsigned mk = 0, cx = 0;
+#pragma unroll
+        for (int dx = 0; dx < 5; ++dx)
+            cx |= (dx < a.ks && (unsigned)(ix0 + dx * a.dil) < (unsigned)a.W) ? (1u << dx) : 0u;
+#pragma unroll
+        for (int dy = 0; dy < 5; ++dy)
+            mk |= (dy < a.ks && (unsigned)(iy0 + dy * a.dil) < (unsigned)a.H) ? (cx << (dy * a.ks)) : 0u;
+        xmask[j] = vm ? mk : 0u;
     }
     const char* wptr[NWI];
 #pragma unroll
@@ -250,7 +252,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvKArgs a) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = apply_act(v[i] * s1 + b1, a.act1);
             if (vec) {
-                const int b = m / a.HoWo, p = m - b * a.HoWo;
+                const int b = fast_div(m, a.div_howo), p = m - b * a.HoWo;
                 *reinterpret_cast<float4*>(out + ((size_t)b * a.Cout + c) * a.HoWo + p) =
                     make_float4(v[0], v[1], v[2], v[3]);
             } else {
@@ -258,7 +260,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvKArgs a) {
                 for (int i = 0; i < 4; ++i) {
                     const int mi = m + i;
                     if (mi < a.M) {
-                        const int b = mi / a.HoWo, p = mi - b * a.HoWo;
+                        const int b = fast_div(mi, a.div_howo), p = mi - b * a.HoWo;
                         out[((size_t)b * a.Cout + c) * a.HoWo + p] = v[i];
                     }
                 }
@@ -466,9 +468,11 @@ int ppn::conv_launch(const ppn_conv_desc* d, hipStream_t st, const char** kname)
     a.B = d->batch; a.H = d->in_h; a.W = d->in_w; a.Cin = d->cin; a.Ho = d->out_h; a.Wo = d->out_w; a.Cout = d->cout;
     a.ks = d->ksize; a.stride = d->stride; a.dil = d->dilation; a.pad = d->pad;
     a.Ktot = d->k_total; a.M = (int)m; a.HoWo = d->out_h * d->out_w;
+    a.div_howo = make_fastdiv((unsigned)a.HoWo); a.div_wo = make_fastdiv((unsigned)d->out_w);
     a.act1 = d->act1; a.act2 = d->act2; a.nchw = d->out_nchw_f32;
     a.log2Cin = log2c < 0 ? 0 : log2c;
     a.n_ctiles = d->cout_pad / bc;
+    a.div_nct = make_fastdiv((unsigned)a.n_ctiles);
     a.n_ptiles = (int)((m + bp - 1) / bp);
     a.src2 = static_cast<const char*>(d->src2);
     a.H2 = d->src2 ? d->in2_h : 1; a.W2 = d->src2 ? d->in2_w : 1; a.Cin2 = d->src2 ? d->cin2 : 0;

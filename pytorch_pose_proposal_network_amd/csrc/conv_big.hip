@@ -120,7 +120,7 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
         const int nb = gridDim.x, id = blockIdx.x;
         const int xcd = id & 7, loc = id >> 3, q = nb >> 3, r = nb & 7;
         const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-        ptile = logical / a.n_ctiles;
+        ptile = fast_div(logical, a.div_nct);
         ctile = logical - ptile * a.n_ctiles;
     }
     const int m0 = ptile * BP, c0 = ctile * BC;
@@ -144,8 +144,8 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
         const int m = m0 + row;
         const bool vm = m < a.M;
         const int mm = vm ? m : 0;
-        const int b = mm / a.HoWo, rem = mm - b * a.HoWo;
-        const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+        const int b = fast_div(mm, a.div_howo), rem = mm - b * a.HoWo;
+        const int oy = fast_div(rem, a.div_wo), ox = rem - oy * a.Wo;
         const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
         xbase[j] = (((b * a.H + iy0) * a.W + ix0) * a.Cin + chunk * EPC) * ES;
         // tap t = dy * ks + dx is in bounds iff its row and its column are: ks column bits, replicated per valid row
@@ -555,7 +555,7 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
                     const int cw = item / BP, px = item - cw * BP;
                     const int m = m0 + px;
                     if (m >= a.M) continue;
-                    const int nb = m / a.HoWo, np = m - nb * a.HoWo;
+                    const int nb = fast_div(m, a.div_howo), np = m - nb * a.HoWo;
                     const int cb = c0 + cw * (BC / 2) + q * RUN;     // first channel of this run
                     const float* row = ct + (cw * RUN) * LD + px;
                     const float* aff = ct_affine + cw * RUN;
@@ -602,7 +602,7 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) v[i] = apply_act(v[i] * s1 + b1, a.act1);
                     if (vec) {
-                        const int nb = m / a.HoWo, np = m - nb * a.HoWo;
+                        const int nb = fast_div(m, a.div_howo), np = m - nb * a.HoWo;
                         *reinterpret_cast<float4*>(out + ((size_t)nb * a.Cout + c) * a.HoWo + np) =
                             make_float4(v[0], v[1], v[2], v[3]);
                     } else {
@@ -610,7 +610,7 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
                         for (int i = 0; i < 4; ++i) {
                             const int mi = m + i;
                             if (mi < a.M) {
-                                const int bi = mi / a.HoWo, pi = mi - bi * a.HoWo;
+                                const int bi = fast_div(mi, a.div_howo), pi = mi - bi * a.HoWo;
                                 out[((size_t)bi * a.Cout + c) * a.HoWo + pi] = v[i];
                             }
                         }

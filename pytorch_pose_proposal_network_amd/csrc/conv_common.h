@@ -10,6 +10,23 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 
+// Division by a launch-invariant divisor (Granlund-Montgomery, round-up variant): exact for every 32-bit unsigned
+// dividend, 4 VALU instructions instead of the ~35 of an emulated integer division.  The index arithmetic at the
+// head of a workgroup sits on the critical path of its first loads.
+struct FastDiv {
+    unsigned mul, sh1, sh2;
+};
+inline FastDiv make_fastdiv(unsigned d) {
+    unsigned l = 0;
+    while ((1ull << l) < d) ++l;                                     // ceil(log2 d)
+    const unsigned long long m = ((1ull << 32) * ((1ull << l) - d)) / d + 1;
+    return FastDiv{(unsigned)m, l < 1 ? l : 1u, l > 0 ? l - 1 : 0u};
+}
+__device__ __forceinline__ int fast_div(int n, const FastDiv& f) {   // n >= 0
+    const unsigned t = __umulhi(f.mul, (unsigned)n);
+    return (int)((t + (((unsigned)n - t) >> f.sh1)) >> f.sh2);
+}
+
 struct ConvKArgs {
     const char* src;
     const char* wgt;
@@ -25,6 +42,7 @@ struct ConvKArgs {
     int Ktot;      // padded GEMM depth (multiple of BK)
     int M;         // B*Ho*Wo
     int HoWo;
+    FastDiv div_howo, div_wo, div_nct;   // dividers by HoWo, Wo, n_ctiles
     int act1, act2, nchw;
     int log2Cin;
     int n_ctiles, n_ptiles;
