@@ -232,10 +232,11 @@ def build_program(arch: str = "drn_d_22", head_channels: Optional[int] = None, f
             p = u.prefix
             assert act is not None, "pre-activation tensor missing for BasicBlock"
             res = raw
-            # measured on MI355X (batch 32): fusing wins 10-12 us for the 128/256-wide blocks, whose separate 1x1
-            # launch under-fills the GPU, and loses 6-30 us for the 512-wide ones (the two-source loader slows
-            # every K step of a launch that is already efficient) -> fuse only up to 256 output channels
-            fuse_ds = u.downsample and fuse_shortcut and u.cin % 64 == 0 and 64 <= u.cout <= 256
+            # measured on MI355X (batch 32): fusing wins ~15 us for the 128->256 block (90 vs 21 + 90 us), loses
+            # ~50 us for the 64->128 block (97 vs 12 + 36 us: its stride-2 gather of 128-byte rows dominates the
+            # short K loop) and 6-30 us for the 512-wide ones (the two-source loader slows every K step of a
+            # launch that is already efficient) -> fuse only 128-wide inputs up to 256 output channels
+            fuse_ds = u.downsample and fuse_shortcut and u.cin % 64 == 0 and u.cin >= 128 and u.cout <= 256
             if u.downsample and not fuse_ds:
                 res = t(p.replace(".", "_") + "_ds")
                 ops.append(ConvOp(f"{p}.downsample", raw, f"{p}.downsample.0.weight", u.cin, u.cout, 1,

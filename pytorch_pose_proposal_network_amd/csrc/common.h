@@ -40,3 +40,10 @@ inline int fail(int code, const char* fmt, ...) {
     } while (0)
 
 }  // namespace ppn
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it waits until every
+// global store (and atomic) this wave has issued is acknowledged -- in a conv epilogue or at the top of a persistent
+// tile loop that puts one full store round trip on the critical path of every chunk / tile.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}

@@ -76,13 +76,6 @@ __device__ __forceinline__ void store4<__bf16>(char* p, const float* v) {
     *reinterpret_cast<bf16x4*>(p) = o;
 }
 
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it waits until every
-// global store (and atomic) this wave has issued is acknowledged -- in the epilogue that put one full store round
-// trip on the critical path of every chunk.
-__device__ __forceinline__ void lds_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
 __device__ __forceinline__ void bufload_lds16(__amdgpu_buffer_rsrc_t rsrc, char* lds_wave_base, unsigned voff,
                                               unsigned soff) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (void __attribute__((address_space(3)))*)lds_wave_base, 16, voff,

@@ -84,7 +84,7 @@ __global__ void __launch_bounds__(256) stem7x7_kernel(StemArgs a) {
     const int ty = bid % a.tiles_y;
     const int b = bid / a.tiles_y;
     const int y0 = ty * TH, x0 = tx * TW;
-    __syncthreads();                                     // previous tile's readers are done with the patch
+    lds_barrier();   // previous tile's readers are done with the patch (LDS only: its stores keep draining)
     // ---- stage the normalised patch ---------------------------------------------------------
     // (all global loads are issued before the first LDS store so that their latencies overlap)
     constexpr int NPIX = PH * PW, NIT = (NPIX + 255) / 256;

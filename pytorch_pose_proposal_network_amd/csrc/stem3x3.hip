@@ -97,7 +97,7 @@ __global__ void __launch_bounds__(256) stem3x3_kernel(Stem3Args a) {
     const int b = bid / a.tiles_y;
     const int oy0 = ty * TH, ox0 = tx * TW;
     const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;     // pad 1
-    __syncthreads();                                     // previous tile's readers are done with the patch
+    lds_barrier();   // previous tile's readers are done with the patch (LDS only: its stores keep draining)
     // ---- stage the input patch (zero padded) ------------------------------------------------------
     const char* src = static_cast<const char*>(a.src);
     // (all loads are issued before the first LDS store so that their latencies overlap)
