@@ -286,6 +286,7 @@ def main():
         # per-launch durations with one launch in flight (what rocprofv3 shows for `--lanes 1`)
         agg, table = {}, []
         reps = 5
+        net.profile_layers(frames, src_is_u8=True, repeats=1, fused_decode=fused)   # untimed: first direct launches
         for r in range(reps):
             for name, kern, ms, fl in net.profile_layers(frames, src_is_u8=True, repeats=4, fused_decode=fused):
                 a = agg.setdefault(kern, [0.0, 0.0, 0])

@@ -40,7 +40,6 @@ DRN_D = {
 }
 CHANNELS = (16, 32, 64, 128, 256, 512, 512, 512)  # drn.py:105
 
-
 @dataclass
 class ConvOp:
     """One fused launch.  Tensor names refer to NHWC activation buffers."""
@@ -70,7 +69,6 @@ class ConvOp:
     ds_cin: int = 0
     ds_stride: int = 1
 
-
 @dataclass
 class Unit:
     kind: str                         # 'cbr' | 'basic' | 'bottleneck' | 'head'
@@ -83,7 +81,6 @@ class Unit:
     k: int = 3
     conv_idx: int = 0                 # for 'cbr': index of conv inside its nn.Sequential
     planes: int = 0                   # bottleneck inner width
-
 
 def _units(arch: str) -> List[Unit]:
     block, layers = DRN_D[arch]
@@ -120,12 +117,10 @@ def _units(arch: str) -> List[Unit]:
     units.append(Unit("head", "", 512, cfg.lastsize()))
     return units
 
-
 def _bn(prefix: str, c: int):
     return [(f"{prefix}.weight", (c,)), (f"{prefix}.bias", (c,)),
             (f"{prefix}.running_mean", (c,)), (f"{prefix}.running_var", (c,)),
             (f"{prefix}.num_batches_tracked", ())]
-
 
 def param_spec(arch: str = "drn_d_22", head_channels: Optional[int] = None) -> List[Tuple[str, tuple]]:
     """(name, shape) of every state_dict entry of the reference PoseProposalNet(arch)."""
@@ -166,7 +161,6 @@ def param_spec(arch: str = "drn_d_22", head_channels: Optional[int] = None) -> L
             spec += _bn("bn0_1", 512) + _bn("bn0_2", 128) + _bn("bn1", 128) + _bn("bn2", 512)
     return spec
 
-
 def _needs(u: Optional[Unit]):
     """What unit `u` wants from its producer: (needs_raw, (bn_prefix, act) or None)."""
     if u is None:
@@ -176,7 +170,6 @@ def _needs(u: Optional[Unit]):
     if u.kind == "head":
         return True, ("bn0_1", ACT_LRELU)                # R is re-added at model.py:127
     return True, None                                    # cbr / bottleneck read raw x
-
 
 def build_program(arch: str = "drn_d_22", head_channels: Optional[int] = None, fuse_stem: bool = False,
                   fuse_shortcut: bool = True) -> List[ConvOp]:
@@ -232,11 +225,11 @@ def build_program(arch: str = "drn_d_22", head_channels: Optional[int] = None, f
             p = u.prefix
             assert act is not None, "pre-activation tensor missing for BasicBlock"
             res = raw
-            # measured on MI355X (batch 32): fusing wins ~15 us for the 128->256 block (90 vs 21 + 90 us), loses
-            # ~50 us for the 64->128 block (97 vs 12 + 36 us: its stride-2 gather of 128-byte rows dominates the
-            # short K loop) and 6-30 us for the 512-wide ones (the two-source loader slows every K step of a
-            # launch that is already efficient) -> fuse only 128-wide inputs up to 256 output channels
-            fuse_ds = u.downsample and fuse_shortcut and u.cin % 64 == 0 and u.cin >= 128 and u.cout <= 256
+            # measured on MI355X (batch 32, whole step, same box): fusing the 64->128 and 128->256 projections is
+            # worth 0-3 % of the step (their separate 1x1 launches under-fill the GPU); for the 512-wide blocks it
+            # loses 6-30 us each (the two-source loader slows every K step of a launch that is already efficient)
+            # -> fuse only up to 256 output channels
+            fuse_ds = u.downsample and fuse_shortcut and u.cin % 64 == 0 and 64 <= u.cout <= 256
             if u.downsample and not fuse_ds:
                 res = t(p.replace(".", "_") + "_ds")
                 ops.append(ConvOp(f"{p}.downsample", raw, f"{p}.downsample.0.weight", u.cin, u.cout, 1,
@@ -288,11 +281,9 @@ def build_program(arch: str = "drn_d_22", head_channels: Optional[int] = None, f
                               act1=ACT_SIGMOID, out_raw="head", nchw_f32_out=True))
     return ops
 
-
 def out_hw(op: ConvOp, h: int, w: int) -> Tuple[int, int]:
     eff = op.dilation * (op.k - 1) + 1
     return (h + 2 * op.pad - eff) // op.stride + 1, (w + 2 * op.pad - eff) // op.stride + 1
-
 
 def tensor_shapes(ops: List[ConvOp], h: int, w: int) -> Dict[str, Tuple[int, int, int]]:
     """(H, W, C) of every activation tensor for an input of h x w."""
@@ -309,7 +300,6 @@ def tensor_shapes(ops: List[ConvOp], h: int, w: int) -> Dict[str, Tuple[int, int
             assert shapes[op.residual] == (oh, ow, op.cout), (op.name, shapes[op.residual], (oh, ow, op.cout))
     return shapes
 
-
 def conv_flops(ops: List[ConvOp], h: int, w: int) -> int:
     """2*MACs of all convolutions for one image (the 95.304 GFLOP figure of BASELINE.md)."""
     shapes = tensor_shapes(ops, h, w)
@@ -317,7 +307,6 @@ def conv_flops(ops: List[ConvOp], h: int, w: int) -> int:
     for op in ops:
         total += op_flops(op, shapes)
     return total
-
 
 def op_flops(op: ConvOp, shapes) -> int:
     """2*MACs of one launch for one image (a fused layer0+layer1 launch counts both convolutions)."""

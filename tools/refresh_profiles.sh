@@ -18,5 +18,9 @@ python3 $R/tools/bench_train.py --phases --first-order > $O/train_bench.txt 2>&1
 python3 $R/bench.py --workload train --steps 10 --warmup 2 > $O/bench_train.json 2> $O/bench_train.err
 echo "[6/6] rocprofv3 kernel stats of the training step"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/train_stats -o train -- python3 $R/tools/bench_train.py --steps 3 --warmup 1 --first-order > $O/train_profiled.txt 2>&1
+echo "[7] in-kernel clock and phase stamps of the dominant conv kernel (diagnostic build: python tools/build_variant.py clock conv_big.hip -DPPN_CLOCK)"
+if [ -f $R/tools/bin/libppn_clock.so ]; then
+  (cd $R && python3 tools/clock_conv.py && python3 tools/clock_conv.py --head) 2>&1 | grep -v amdgpu.ids > $O/conv_clock.txt
+fi
 find $O -name "*.csv" -size +3M -delete
 echo done
