@@ -188,6 +188,11 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvKArgs a) {
         constexpr int PPP = 256 / TPP;                               // pixels per pass
         const int cg = tid % TPP, prow = tid / TPP;
         const int c = c0 + cg * 8;
+        // none / ReLU / LeakyReLU(0.1) are all  max(t, t * slope)  with slope 1 / 0 / 0.1 (same values as the
+        // compare + select form, signed zeros included); sigmoid keeps the general path
+        const bool simple = a.act1 != PPN_ACT_SIGMOID && a.act2 != PPN_ACT_SIGMOID;
+        const float slope1 = a.act1 == PPN_ACT_RELU ? 0.f : (a.act1 == PPN_ACT_LRELU ? 0.1f : 1.f);
+        const float slope2 = a.act2 == PPN_ACT_RELU ? 0.f : (a.act2 == PPN_ACT_LRELU ? 0.1f : 1.f);
         if (c < a.Cout) {
             float s1[8], b1[8], s2[8], b2[8];
 #pragma unroll
@@ -206,8 +211,16 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvKArgs a) {
                 const f32x4 hi = *reinterpret_cast<const f32x4*>(ct + px * LD + cg * 8 + 4);
                 v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
                 const size_t off = ((size_t)m * a.Cout + c) * ES;
+                if (simple) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] = apply_act(v[i] * s1[i] + b1[i], a.act1);
+                    for (int i = 0; i < 8; ++i) {
+                        const float t1 = v[i] * s1[i] + b1[i];
+                        v[i] = fmaxf(t1, t1 * slope1);
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = apply_act(v[i] * s1[i] + b1[i], a.act1);
+                }
                 if (a.residual) {
                     float r[8];
                     load8<T>(a.residual + off, r);
@@ -217,8 +230,16 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvKArgs a) {
                 if (a.out_raw) store8<T>(a.out_raw + off, v);
                 if (a.out_act) {
                     float u[8];
+                    if (simple) {
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) u[i] = apply_act(v[i] * s2[i] + b2[i], a.act2);
+                        for (int i = 0; i < 8; ++i) {
+                            const float t2 = v[i] * s2[i] + b2[i];
+                            u[i] = fmaxf(t2, t2 * slope2);
+                        }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) u[i] = apply_act(v[i] * s2[i] + b2[i], a.act2);
+                    }
                     store8<T>(a.out_act + off, u);
                 }
             }
