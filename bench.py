@@ -177,6 +177,173 @@ def main_train(args):
         dist.destroy_process_group()
 
 
+def _people_equal(a, b):
+    if a["n"] != b["n"]:
+        return False
+    return all(np.array_equal(a[k], b[k]) for k in ("kp_cell", "limb_arg", "bbox", "score"))
+
+
+def verify_against_slices(net, frames, out):
+    """Outside the timed region: the last step's people lists (batch B, the tile instantiations the timed steps ran)
+    must equal, bit for bit, what B/2 independent batch-2 passes return (frames are independent units; the batch-2
+    path is the one the golden-vector tests pin to the reference).  Returns the `verified` object of the JSON line."""
+    from pytorch_pose_proposal_network_amd import rt
+    if getattr(out, "ready", None) is not None:
+        out.ready.synchronize()
+    full = out.to_host()
+    bad = []
+    B = frames.shape[0]
+    for i in range(0, B - 1, 2):
+        part = rt.inference_batch(frames[i:i + 2].contiguous(), net).to_host()
+        for j in range(2):
+            if not _people_equal(full[i + j], part[j]):
+                bad.append(i + j)
+    return {"check": f"last timed step's decode result == {B // 2} independent batch-2 passes (every index, box, score)",
+            "frames": B, "people": int(sum(r["n"] for r in full)), "mismatching_frames": bad, "ok": not bad}
+
+
+def _time_steps(fn, dev, steps, warmup=2):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize(dev)
+    return (time.perf_counter() - t0) / steps
+
+
+def extra_sections(args, dev, net, frames, dec):
+    """Driver-visible numbers for the other BASELINE configs and modes (rank 0, N=1, outside the headline's timed
+    loop; each a few steps, < 60 s in total).  A section that fails reports its error instead of failing the run."""
+    from pytorch_pose_proposal_network_amd import arch as A, decode, drn, lib as L, model, rt, targets
+    B, S = args.batch, args.size
+    out = {}
+
+    def section(name, fn):
+        t0 = time.perf_counter()
+        try:
+            out[name] = fn()
+        except Exception as e:                                    # noqa: BLE001 -- reported, never hidden
+            out[name] = {"error": f"{type(e).__name__}: {e}"}
+        out[name]["wall_s"] = round(time.perf_counter() - t0, 2)
+        torch.cuda.empty_cache()
+
+    flops = A.conv_flops(A.build_program(args.arch), S, S) * B
+
+    def materialized():
+        # the model.forward() + get_humans_by_feature path: the f32 head [B,7605,24,24] is written and re-read
+        def step():
+            dec(net.forward_u8(frames))
+        dt = _time_steps(step, dev, 10)
+        return {"what": "forward writing the f32 NCHW head (17.5 MB/image) + stand-alone arg-max/NMS/parse decode",
+                "images_per_sec": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 3)}
+
+    def f32_mode():
+        n32 = model.PoseProposalNet(getattr(drn, args.arch)(), insize=(S, S), outsize=(S // 16, S // 16),
+                                    compute_dtype="float32").cuda(dev)
+        n32.load_state_dict(net.state_dict())
+        d32 = decode.Decoder(B, (S // 16, S // 16), (S, S), device=dev)
+
+        def step():
+            u, k = n32.forward_u8(frames, fused_decode=True)
+            d32.decode_fused(u, k)
+        dt = _time_steps(step, dev, 3, warmup=3)
+        return {"what": "the 1e-4 parity mode: exact-f32 MFMA (v_mfma_f32_16x16x4_f32), same fused path, batch %d" % B,
+                "images_per_sec": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 3),
+                "tflops": round(flops / dt / 1e12, 2), "frac_of_f32_mfma_peak": round(flops / dt / 1e12 / F32_MFMA_PEAK_TFLOPS, 4)}
+
+    def decode_stress():
+        # BASELINE configs[4]: 32 planted 16-person crowds (+4 decoys), stand-alone decode of the dense f32 heads
+        heads = np.stack([synth.planted_crowd_head(7 + i) for i in range(B)])
+        hs = [torch.from_numpy(heads).to(dev) for _ in range(4)]   # 4 copies: 2.2 GB, far beyond the 256 MB MALL
+        d = decode.Decoder(B, device=dev)
+        res = {}
+        for name, fn in (("limb_argmax", d.limb_argmax), ("decode", d)):
+            for h in hs:
+                fn(h)
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
+            for i, (a, b) in enumerate(ev):
+                a.record(); fn(hs[i % 4]); b.record()
+            torch.cuda.synchronize(dev)
+            ms = sorted(a.elapsed_time(b) for a, b in ev)
+            med = ms[len(ms) // 2]
+            res[name] = {"us": round(med * 1e3, 1), "gbps": round(heads.nbytes / med / 1e6, 1),
+                         "frac_of_hbm_peak": round(heads.nbytes / med / 1e6 / 8000.0, 4)}
+        people = int(d(hs[0]).count.sum().item())
+        del hs
+        return {"what": f"{B} planted-crowd heads f32 [7605,24,24] (seeds 7..{6 + B}): limb arg-max + NMS + limb parse, "
+                        "median of 20 over 4 rotating copies", "algorithmic_bytes": int(heads.nbytes),
+                "people": people, **res}
+
+    def d54():
+        g = load_bn_stats("drn_d_54")
+        n54 = model.PoseProposalNet(drn.drn_d_54(), insize=(S, S), outsize=(S // 16, S // 16),
+                                    compute_dtype="bfloat16").cuda(dev)
+        n54.load_state_dict(synth.make_state_dict("drn_d_54", 0, bn_stats=g))
+        d54_ = decode.Decoder(B, (S // 16, S // 16), (S, S), device=dev)
+
+        def step():
+            u, k = n54.forward_u8(frames, fused_decode=True)
+            d54_.decode_fused(u, k)
+        dt = _time_steps(step, dev, 5, warmup=3)
+        fl = A.conv_flops(A.build_program("drn_d_54"), S, S) * B
+        return {"what": f"DRN-D-54 (Bottleneck trunk) end to end, bf16, batch {B}, fused decode, one lane",
+                "images_per_sec": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 3),
+                "tflops": round(fl / dt / 1e12, 1), "frac_of_mfma_peak": round(fl / dt / 1e12 / BF16_DENSE_PEAK_TFLOPS, 4)}
+
+    def train_shard():
+        from pytorch_pose_proposal_network_amd.trainer import PPNTrainer
+        tr = PPNTrainer(args.arch, synth.make_state_dict(args.arch, 0), compute_dtype=L.PPN_BF16, insize=(S, S),
+                        device=dev)
+        x = torch.from_numpy(synth.normalized_frames(prng.u8_frames(99, B, (S, S)))).to(dev)
+        tg = targets.synthetic_targets(99, B, (S, S), device=dev)
+        dt = _time_steps(lambda: tr.train_step(x, tg), dev, 4, warmup=2)
+        return {"what": f"BASELINE configs[3] per-GPU shard: one PPNTrainer.train_step (train-mode fwd, PPNLoss, bwd, "
+                        f"GradNorm incl. second-order term, Adam), bf16, batch {B}",
+                "images_per_sec": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 3),
+                "frac_of_mfma_peak_3x_fwd_flops": round(3 * flops / dt / 1e12 / BF16_DENSE_PEAK_TFLOPS, 4)}
+
+    section("materialized_head", materialized)
+    section("decode_stress", decode_stress)
+    section("f32_parity_mode", f32_mode)
+    section("d54_end_to_end", d54)
+    section("train_shard", train_shard)
+    return out
+
+
+def self_launch(argv, gpus):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU under
+    torch.distributed.run, rendezvous on 127.0.0.1) as a CHILD process, relay its output, exit with its code.
+    Runs before anything touches the GPU in this process; never exec."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    print("bench.py: launching " + " ".join(cmd), file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = []
+    for line in proc.stdout:                     # rank 0's JSON line (other ranks print nothing on stdout)
+        lines.append(line)
+    rc = proc.wait()
+    json_lines = [l for l in lines if l.lstrip().startswith("{")]
+    for l in lines:
+        if l not in json_lines:
+            sys.stderr.write(l)
+    if rc != 0 or not json_lines:
+        sys.stderr.write(f"bench.py: the {gpus}-rank run failed (exit code {rc})\n")
+        raise SystemExit(rc or 1)
+    sys.stdout.write(json_lines[-1])
+    sys.stdout.flush()
+    raise SystemExit(0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="inference", choices=["inference", "train"],
@@ -189,6 +356,9 @@ def main():
     ap.add_argument("--arch", default="drn_d_22")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the extra sections (materialized_head, decode_stress, f32_parity_mode, d54_end_to_end, "
+                         "train_shard) reported beside the headline at N=1")
     ap.add_argument("--layers", action="store_true", help="print the per-layer table to stderr")
     ap.add_argument("--lanes", type=int, default=int(os.environ.get("PPN_LANES", "2")),
                     help="stream lanes successive steps alternate between (rt.MultiLaneInference); 1 = one lane with "
@@ -203,6 +373,8 @@ def main():
                     help="write the f32 head tensor [B,7605,24,24] and decode it with the stand-alone arg-max kernel "
                          "(model.forward + get_humans_by_feature path) instead of the fused inference path")
     args = ap.parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        self_launch(sys.argv[1:], args.gpus)
     if args.workload == "train":
         return main_train(args)
 
@@ -325,8 +497,14 @@ def main():
                                    + ("" if fused else ", head tensor materialised")
                                    + (", batches alternate between two stream lanes (rt.MultiLaneInference)"
                                       if pipe is not None else ""),
-                       "frames_per_gpu": B, "input": f"{S}x{S}x3 u8", "head": f"{cfg.lastsize()}x{S//16}x{S//16} f32",
+                       "frames_per_gpu": B, "input": f"{S}x{S}x3 u8 resident in HBM",
+                       "head": (f"{cfg.lastsize()}x{S//16}x{S//16} f32 per image, NOT materialised: the head conv's "
+                                "epilogue keeps the 108 unary channels and one arg-max key per (edge, cell)"
+                                if fused else f"{cfg.lastsize()}x{S//16}x{S//16} f32 written to HBM"),
+                       "excluded_from_value": "H2D of the u8 frames and D2H of the compact people lists "
+                                              "(`pcie_inclusive` is the rate with both)",
                        "parallelism": f"frames sharded over {world} GPU(s), no data-path collective"},
+            "rccl_ranks": world if (dist is not None and backend == "nccl") else (1 if world == 1 else 0),
             "roofline": {"bound": "mfma", "kernel": dk, "launches_per_step": dn // reps,
                          "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4),
@@ -379,6 +557,12 @@ def main():
                                         "ms_per_step": round(dt1 / n * 1e3, 4), "h2d_bytes_per_step": host.numel(),
                                         "note": "per step: H2D of the pinned u8 frames, the step, D2H + unpacking of the "
                                                 "compact result of the previous step (read while this one runs)"}
+        if fused and B % 2 == 0:
+            result["verified"] = verify_against_slices(net, frames, out)
+        if world == 1 and not args.no_extras:
+            if pipe is not None:
+                pipe.close()
+            result.update(extra_sections(args, dev, net, frames, dec))
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args.arch, 4, S)
     if dist is not None:
@@ -386,6 +570,8 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(result), flush=True)
+        if result.get("verified") is not None and not result["verified"]["ok"]:
+            raise SystemExit("bench.py: the timed path's output differs from the batch-2 reference path")
 
 
 if __name__ == "__main__":

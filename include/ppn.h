@@ -217,6 +217,17 @@ int ppn_conv2d_fused(const ppn_conv_desc* d, void* stream);
  * the most efficient tile shape is taken regardless of the round count (measured +4..5 % with two lanes). */
 int ppn_set_conv_tile_policy(int32_t policy);
 
+/* Force the (pixels x channels) tile of the large-tile convolution kernel for every later launch / plan entry whose
+ * Cout class admits it: bp in {128,192,256}, bc in {64,128,256} (not 192x64); (0,0) restores the automatic choice.
+ * Test and tuning hook: the automatic choice depends on B*Ho*Wo, so small parity problems would otherwise never
+ * reach the instantiations a batch-32 384x384 forward runs (tests/test_conv_tiles_gpu.py).  Process-wide, like the
+ * PPN_CONV_TILE="bp,bc" environment knob that supplies its initial value. */
+int ppn_set_conv_tile_override(int32_t bp, int32_t bc);
+
+/* Name of the kernel instantiation the calling thread's last successful ppn_conv2d_fused launched
+ * (e.g. "conv_igemm_big_kernel<__bf16, 192, 256, 8, false>"); "" before the first call. */
+const char* ppn_last_conv_kernel(void);
+
 /*
  * First layer (drn.py:123-128 layer0: 7x7 conv 3->16, BN, ReLU) with the input normalisation of
  * rt_test.py:97-101 / aug.py:149-153 fused into the load.
@@ -263,6 +274,11 @@ int ppn_plan_run(ppn_plan* p, void* stream);
  * divided by `repeats`, which amortises the event/launch gap (launches are idempotent: no output aliases an
  * input).  Synchronises on the last event. */
 int ppn_plan_run_timed(ppn_plan* p, void* stream, float* ms, int32_t n_ms, int32_t repeats);
+/* Number of times the plan's launch sequence has been captured into a hipGraph (0 while it still launches directly).
+ * A plan re-captures when its input pointer or its stream changes -- the old executable graph is retired only after
+ * its stream has drained -- so callers that serve fresh frames keep ONE plan-owned input buffer per plan and copy
+ * into it (PoseProposalNet._plan_for does); this counter lets tests assert that. */
+int ppn_plan_graph_captures(const ppn_plan* p);
 int ppn_plan_size(const ppn_plan* p);
 /* Name of the kernel launch i dispatches (as it appears in rocprofv3 --kernel-trace). */
 const char* ppn_plan_kernel_name(const ppn_plan* p, int32_t i);

@@ -513,9 +513,16 @@ int ppn::conv_launch(const ppn_conv_desc* d, hipStream_t st, const char** kname)
     return launch_dtype<__bf16>(a, smallc, tc, st, kname);
 }
 
+static thread_local const char* g_last_conv_kernel = "";
+
 extern "C" int ppn_conv2d_fused(const ppn_conv_desc* d, void* stream) {
-    return ppn::conv_launch(d, static_cast<hipStream_t>(stream), nullptr);
+    const char* kn = nullptr;
+    const int rc = ppn::conv_launch(d, static_cast<hipStream_t>(stream), &kn);
+    if (rc == PPN_OK && kn) g_last_conv_kernel = kn;
+    return rc;
 }
+
+extern "C" const char* ppn_last_conv_kernel(void) { return g_last_conv_kernel; }
 
 static int pack_weight_impl(int32_t dtype, const float* w, int32_t cout, int32_t cin, int32_t ksize,
                             int32_t cout_pad, int32_t k_total, int32_t k_order, int32_t k_step, void* out,

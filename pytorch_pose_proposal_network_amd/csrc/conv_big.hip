@@ -759,17 +759,26 @@ namespace ppnconv {
 // (256 CUs; one workgroup per CU, two for the 64-channel tile whose LDS footprint is 80 KB).
 // PPN_CONV_TILE="bp,bc" overrides the choice for every eligible layer (tuning knob).
 static int g_tile_policy = getenv("PPN_CONV_CONT") ? 1 : 0;
+// forced tile (ppn_set_conv_tile_override; initial value from PPN_CONV_TILE="bp,bc"): 0,0 = automatic choice
+static int g_ov_bp = -1, g_ov_bc = 0;
+
+static bool tile_shape_ok(int bp, int bc) {
+    return (bp == 128 || bp == 192 || bp == 256) && (bc == 64 || bc == 128 || bc == 256) && !(bc == 64 && bp == 192);
+}
 
 bool big_tile_for(int cout, long long m, BigTile* out) {
     if (cout < 64) return false;
-    static const char* ov = getenv("PPN_CONV_TILE");
-    if (ov) {
+    if (g_ov_bp < 0) {                                   // first call: the environment knob
+        g_ov_bp = g_ov_bc = 0;
         int bp = 0, bc = 0;
-        if (sscanf(ov, "%d,%d", &bp, &bc) == 2 && (bp == 128 || bp == 192 || bp == 256) &&
-            (bc == 64 || bc == 128 || bc == 256) && !(bc == 64 && bp == 192) && bc <= ((cout + 63) / 64) * 64) {
-            out->bp = bp; out->bc = bc;
-            return true;
-        }
+        const char* ov = getenv("PPN_CONV_TILE");
+        if (ov && sscanf(ov, "%d,%d", &bp, &bc) == 2 && tile_shape_ok(bp, bc)) { g_ov_bp = bp; g_ov_bc = bc; }
+    }
+    // a forced tile applies to every layer whose padded Cout it divides (the packed weights are padded to the
+    // LARGEST channel tile of the layer's Cout class, ppn_conv_tiling, so any smaller power-of-two tile fits)
+    if (g_ov_bp > 0 && g_ov_bc <= ((cout + 63) / 64) * 64 && g_ov_bc <= (cout >= 256 ? 256 : (cout >= 128 ? 128 : 64))) {
+        out->bp = g_ov_bp; out->bc = g_ov_bc;
+        return true;
     }
     if (cout >= 4096) {
         // the head conv (512 -> 7605, K = 512) writes 17.5 MB/image and is store-bound: a 192x128 tile keeps
@@ -809,6 +818,14 @@ int launch_big(const ConvKArgs& a, int dtype, BigTile t, hipStream_t st, const c
 }
 
 }  // namespace ppnconv
+
+extern "C" int ppn_set_conv_tile_override(int32_t bp, int32_t bc) {
+    if (bp == 0 && bc == 0) { ppnconv::g_ov_bp = ppnconv::g_ov_bc = 0; return PPN_OK; }
+    if (!ppnconv::tile_shape_ok(bp, bc))
+        return ppn::fail(PPN_E_INVALID, "ppn_set_conv_tile_override: bp in {128,192,256}, bc in {64,128,256}, not 192x64");
+    ppnconv::g_ov_bp = bp; ppnconv::g_ov_bc = bc;
+    return PPN_OK;
+}
 
 extern "C" int ppn_set_conv_tile_policy(int32_t policy) {
     if (policy != 0 && policy != 1) return ppn::fail(PPN_E_INVALID, "ppn_set_conv_tile_policy: 0 or 1");

@@ -38,6 +38,7 @@ struct ppn_plan {
     const void* graph_src = nullptr;
     hipStream_t graph_stream = nullptr;
     int direct_runs = 0;
+    int captures = 0;          // how many times the launch sequence was captured + instantiated
     bool graph_off = false;
 };
 
@@ -137,7 +138,13 @@ extern "C" int ppn_plan_run(ppn_plan* p, void* stream) {
     if (graphs && !p->graph_off && p->direct_runs >= 2) {
         const void* src = plan_src(p);
         if (!p->graph_exec || p->graph_src != src || p->graph_stream != st) {
-            if (p->graph_exec) { (void)hipGraphExecDestroy(p->graph_exec); p->graph_exec = nullptr; }
+            if (p->graph_exec) {
+                // the old executable graph may still have a launch queued on its stream: retire it only once that
+                // stream has drained (rare path: the callers above keep one input buffer and one stream per plan)
+                (void)hipStreamSynchronize(p->graph_stream);
+                (void)hipGraphExecDestroy(p->graph_exec);
+                p->graph_exec = nullptr;
+            }
             hipGraph_t g = nullptr;
             bool ok = hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed) == hipSuccess;
             if (ok) {
@@ -155,6 +162,7 @@ extern "C" int ppn_plan_run(ppn_plan* p, void* stream) {
             } else {
                 p->graph_src = src;
                 p->graph_stream = st;
+                ++p->captures;
             }
         }
         if (p->graph_exec) {
@@ -193,6 +201,8 @@ extern "C" int ppn_plan_run_timed(ppn_plan* p, void* stream, float* ms, int32_t 
     return PPN_OK;
 }
 
+extern "C" int ppn_plan_graph_captures(const ppn_plan* p) { return p ? p->captures : 0; }
+
 extern "C" int ppn_plan_size(const ppn_plan* p) { return p ? (int)p->ops.size() : 0; }
 
 extern "C" const char* ppn_plan_kernel_name(const ppn_plan* p, int32_t i) {
@@ -203,7 +213,10 @@ extern "C" const char* ppn_plan_kernel_name(const ppn_plan* p, int32_t i) {
 extern "C" int ppn_plan_destroy(ppn_plan* p) {
     if (!p) return PPN_OK;
     for (auto e : p->events) (void)hipEventDestroy(e);
-    if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
+    if (p->graph_exec) {
+        (void)hipStreamSynchronize(p->graph_stream);
+        (void)hipGraphExecDestroy(p->graph_exec);
+    }
     delete p;
     return PPN_OK;
 }

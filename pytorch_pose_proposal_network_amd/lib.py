@@ -102,6 +102,7 @@ _SIGNATURES = {
     "ppn_plan_run": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ppn_plan_run_timed": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.c_int32, C.c_int32]),
     "ppn_plan_size": (C.c_int, [C.c_void_p]),
+    "ppn_plan_graph_captures": (C.c_int, [C.c_void_p]),
     "ppn_plan_kernel_name": (C.c_char_p, [C.c_void_p, C.c_int32]),
     "ppn_plan_destroy": (C.c_int, [C.c_void_p]),
     "ppn_pack_weight": (C.c_int, [C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
@@ -122,6 +123,8 @@ _SIGNATURES.update({
                                            C.c_void_p, C.c_void_p]),
     "ppn_gradnorm_renorm": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "ppn_set_conv_tile_policy": (C.c_int, [C.c_int32]),
+    "ppn_set_conv_tile_override": (C.c_int, [C.c_int32, C.c_int32]),
+    "ppn_last_conv_kernel": (C.c_char_p, []),
     "ppn_add_relu": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "ppn_relu_mask": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "ppn_colsum": (C.c_int, [C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),

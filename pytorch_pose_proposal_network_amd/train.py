@@ -182,23 +182,33 @@ class GradNormWeights:
         self.step_count = 0
         self.log = torch.zeros(20, dtype=torch.float32, device=device)
 
-    def step(self, losses: torch.Tensor, gnorm: torch.Tensor, base: torch.Tensor, group=None):
-        """losses, gnorm, base: f32[5] device tensors.  Returns the log tensor (G, C, dw, [Lgrad, G_avg,...])."""
-        import torch.distributed as dist
+    def local_step(self, losses: torch.Tensor, gnorm: torch.Tensor, base: torch.Tensor):
+        """This rank's optimizerR.step() (main.py:717-768): G_i, C_i, Lgrad, dLgrad/dw, Adam on w -- before the
+        all-reduce and the renormalisation.  losses, gnorm, base: f32[5] device tensors."""
         lib = L.load()
         self.step_count += 1
-        st = L.current_stream_ptr()
         L.check(lib.ppn_gradnorm_weight_step(self.w.data_ptr(), _f32(losses, 5, "losses"), _f32(gnorm, 5, "gnorm"),
                                              _f32(base, 5, "base"), self.alpha, self.exp_avg.data_ptr(),
                                              self.exp_avg_sq.data_ptr(), self.lr, self.betas[0], self.betas[1],
-                                             self.eps, self.step_count, self.log.data_ptr(), st),
+                                             self.eps, self.step_count, self.log.data_ptr(), L.current_stream_ptr()),
                 "ppn_gradnorm_weight_step")
+        return self.log
+
+    def renorm(self, world: int = 1):
+        """main.py:769-777 after the SUM all-reduce: w / world, clamp, renormalise to sum 5."""
+        L.check(L.load().ppn_gradnorm_renorm(self.w.data_ptr(), world, L.current_stream_ptr()), "ppn_gradnorm_renorm")
+
+    def step(self, losses: torch.Tensor, gnorm: torch.Tensor, base: torch.Tensor, group=None):
+        """local_step, SUM all-reduce of the five weights over `group` (main.py:769-771), renorm.
+        Returns the log tensor (G, C, dw, [Lgrad, G_avg,...])."""
+        import torch.distributed as dist
+        self.local_step(losses, gnorm, base)
         world = 1
         if dist.is_available() and dist.is_initialized():
             world = dist.get_world_size(group)
             if world > 1:
                 dist.all_reduce(self.w, op=dist.ReduceOp.SUM, group=group)      # main.py:769-771
-        L.check(lib.ppn_gradnorm_renorm(self.w.data_ptr(), world, st), "ppn_gradnorm_renorm")
+        self.renorm(world)
         return self.log
 
 

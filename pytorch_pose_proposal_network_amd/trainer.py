@@ -386,11 +386,7 @@ class PPNTrainer:
             main.wait_stream(so["stream"])                # the unary probe gradients
         gw = list(so["unary"])
         acc = sum(float(coeff[i]) * gw[i] for i in range(4))
-        if coeff[4] > 1e-3 * max(coeff):
-            gw.append((self.G["conv1.weight"] - acc) / float(coeff[4]))        # limb probe gradient by linearity
-        else:                                                                     # too small to divide by: direct pass
-            _, g4 = self.criterion.forward_backward(head, targets, coeff=[0.0, 0.0, 0.0, 0.0, 1.0])
-            gw.append(self.probe_grad(g4))
+        gw.append(self._limb_probe(self.G["conv1.weight"], acc, coeff, head, targets))
         gn = torch.stack([T.sumsq(g.contiguous().view(-1)).sqrt().reshape(()) for g in gw])
         so["gnorm"] = gn
         w = self.task.w
@@ -587,6 +583,22 @@ class PPNTrainer:
             acc.add_(gw, alpha=float(coeff[i]))
         return gn, acc
 
+    def _limb_probe(self, total, acc, coeff, head, targets) -> torch.Tensor:
+        """dL_4/dW (limb loss) = (sum_i coeff_i dL_i/dW - sum_{i<4} coeff_i dL_i/dW) / coeff_4 by linearity of the
+        backward pass, or the direct fifth pass when that remainder cannot be trusted: coeff_4 too small to divide by,
+        or -- bf16 mode, where `total` and `acc` come from differently rounded passes (relative noise ~2^-8 each) -- a
+        remainder that is not clearly above the rounding noise of the total."""
+        if coeff[4] > 1e-3 * max(coeff):
+            rest = total - acc
+            trusted = True
+            if self.compute_dtype != L.PPN_F32:
+                n_rest, n_tot = float(T.sumsq(rest.contiguous().view(-1))), float(T.sumsq(total.contiguous().view(-1)))
+                trusted = n_rest > (16.0 * 2.0 ** -8) ** 2 * n_tot
+            if trusted:
+                return rest / float(coeff[4])
+        _, g4 = self.criterion.forward_backward(head, targets, coeff=[0.0, 0.0, 0.0, 0.0, 1.0])
+        return self.probe_grad(g4)
+
     def probe_norms(self, head, targets, coeff, ghead, unary=None) -> torch.Tensor:
         """gnorm_i = ||dL_i/dW||_2, i = 0..4, AFTER backward() ran with `coeff` (so self.G['conv1.weight'] holds
         sum_i coeff_i dL_i/dW).  The four unary losses touch only the first 6K head channels, so their probe passes
@@ -598,23 +610,36 @@ class PPNTrainer:
         gn4, acc = unary if unary is not None else self._unary_probes(head, targets, coeff, ghead)
         gn = torch.empty(5, dtype=torch.float32, device=self.device)
         gn[:4] = gn4
-        if coeff[4] > 1e-3 * max(coeff):
-            local = self._conv1_local if self._conv1_local is not None else self.G["conv1.weight"]
-            rest = (local - acc) / float(coeff[4])
-        else:
-            _, g4 = self.criterion.forward_backward(head, targets, coeff=[0.0, 0.0, 0.0, 0.0, 1.0])
-            rest = self.probe_grad(g4)
+        local = self._conv1_local if self._conv1_local is not None else self.G["conv1.weight"]
+        rest = self._limb_probe(local, acc, coeff, head, targets)
         gn[4:5] = T.sumsq(rest.contiguous().view(-1)).sqrt()
         return gn
 
     # ---- one iteration ------------------------------------------------------------------------------------------
-    def train_step(self, x: torch.Tensor, targets: Dict[str, torch.Tensor], group=None):
-        """main.py:664-777 for one minibatch shard.  Returns (losses f32[5], task weights f32[5]) device tensors."""
+    def _init_base(self, losses: torch.Tensor, group=None):
+        """No get_baseloss() / explicit base before the first step: fall back to this minibatch's train-mode losses
+        (the reference uses eval-mode losses averaged over the loader, main.py:578-621, which changes the GradNorm
+        targets C_i) -- loudly, and identical on every rank."""
+        import warnings
+        import torch.distributed as dist
+        warnings.warn("PPNTrainer: GradNorm base losses not set (call get_baseloss() or assign trainer.base as "
+                      "main.py:403 does); using the first minibatch's train-mode losses", RuntimeWarning, stacklevel=3)
+        base = losses.clone()
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(base, op=dist.ReduceOp.SUM, group=group)
+            base /= dist.get_world_size(group)
+        self.base = base
+
+    def local_pass(self, x: torch.Tensor, targets: Dict[str, torch.Tensor], group=None):
+        """Everything of main.py:664-759 that happens on this rank's shard: train-mode forward, PPNLoss fwd+bwd, the
+        backward pass (with the second-order term when enabled) into self.grad -- its 32 MB buckets all-reduced
+        (SUM) over `group` while the backward runs -- and the five probe-gradient norms.
+        Returns (losses f32[5], gnorm f32[5], scale = 1/world for the optimiser)."""
         head = self.forward(x)
         w = self.task.w.tolist()                                         # 5 floats D2H (coefficients of the loss kernel)
         losses, ghead = self.criterion.forward_backward(head, targets, coeff=[v / 5.0 for v in w])
         if self.base is None:
-            self.base = losses.clone()                                   # get_baseloss stand-in: L_i(step 0)
+            self._init_base(losses, group)
         coeff = [v / 5.0 for v in w]
         unary = None
         if self.second_order:
@@ -639,33 +664,35 @@ class PPNTrainer:
             exchange = T.BucketedAllReduce(self.grad, group=group)
             self.backward(ghead, exchange, so=so)
             scale = exchange.finish()
-            self.task.step(losses, so["gnorm"], self.base, group=group)
-            self.opt.step(self.grad, grad_scale=scale)
-            self._tape = None
-            self._conv1_local = None
-            return losses, self.task.w
-        if self._probe_stream is not None:
-            # the four unary probe passes are small launches that depend only on the forward: they run on their own
-            # stream underneath the backward pass
-            main = torch.cuda.current_stream(self.device)
-            if self._probe_scratch is None or self._probe_scratch.shape != head.shape:
-                self._probe_scratch = torch.empty_like(head)
-            ev = torch.cuda.Event()
-            ev.record(main)
-            with torch.cuda.stream(self._probe_stream):
-                self._probe_stream.wait_event(ev)
-                unary = self._unary_probes(head, targets, coeff, self._probe_scratch)
-        # gradient exchange: 32 MB buckets of the flat buffer go out over RCCL as the backward completes them
-        exchange = T.BucketedAllReduce(self.grad, group=group)
-        self.backward(ghead, exchange)
-        scale = exchange.finish()
-        if unary is not None:
-            torch.cuda.current_stream(self.device).wait_stream(self._probe_stream)
-            for t in unary:
-                t.record_stream(torch.cuda.current_stream(self.device))
-        gn = self.probe_norms(head, targets, coeff, ghead, unary=unary)
-        self.task.step(losses, gn, self.base, group=group)               # optimizerR.step + all-reduce + renormalise
-        self.opt.step(self.grad, grad_scale=scale)                       # optimizerM.step
+            gn = so["gnorm"]
+        else:
+            if self._probe_stream is not None:
+                # the four unary probe passes are small launches that depend only on the forward: they run on their
+                # own stream underneath the backward pass
+                main = torch.cuda.current_stream(self.device)
+                if self._probe_scratch is None or self._probe_scratch.shape != head.shape:
+                    self._probe_scratch = torch.empty_like(head)
+                ev = torch.cuda.Event()
+                ev.record(main)
+                with torch.cuda.stream(self._probe_stream):
+                    self._probe_stream.wait_event(ev)
+                    unary = self._unary_probes(head, targets, coeff, self._probe_scratch)
+            # gradient exchange: 32 MB buckets of the flat buffer go out over RCCL as the backward completes them
+            exchange = T.BucketedAllReduce(self.grad, group=group)
+            self.backward(ghead, exchange)
+            scale = exchange.finish()
+            if unary is not None:
+                torch.cuda.current_stream(self.device).wait_stream(self._probe_stream)
+                for t in unary:
+                    t.record_stream(torch.cuda.current_stream(self.device))
+            gn = self.probe_norms(head, targets, coeff, ghead, unary=unary)
         self._tape = None
         self._conv1_local = None
+        return losses, gn, scale
+
+    def train_step(self, x: torch.Tensor, targets: Dict[str, torch.Tensor], group=None):
+        """main.py:664-777 for one minibatch shard.  Returns (losses f32[5], task weights f32[5]) device tensors."""
+        losses, gn, scale = self.local_pass(x, targets, group)
+        self.task.step(losses, gn, self.base, group=group)               # optimizerR.step + all-reduce + renormalise
+        self.opt.step(self.grad, grad_scale=scale)                       # optimizerM.step
         return losses, self.task.w

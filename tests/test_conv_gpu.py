@@ -19,8 +19,12 @@ def _act(v, a):
 
 
 def run_conv(x, w, dtype, stride=1, dil=1, pad=0, s1=None, b1=None, act1=0, residual=None, s2=None, b2=None, act2=0,
-             want_raw=True, want_act=False, nchw=False, shortcut=None):
-    """x [B,Cin,H,W], w [Cout,Cin,k,k] CPU f32 -> (raw, act) as NCHW CPU f32 tensors via libppn."""
+             want_raw=True, want_act=False, nchw=False, shortcut=None, argmax=None, info=None):
+    """x [B,Cin,H,W], w [Cout,Cin,k,k] CPU f32 -> (raw, act) as NCHW CPU f32 tensors via libppn.
+
+    argmax=(unary_channels, window): NCHW head mode with the decode's limb arg-max fused into the epilogue; the
+    compact unary tensor and the u64 keys are returned through ``info`` (a dict, which also receives the name of
+    the kernel instantiation that ran)."""
     from pytorch_pose_proposal_network_amd import lib as L
     lib = L.load()
     dev = torch.device("cuda")
@@ -77,8 +81,18 @@ def run_conv(x, w, dtype, stride=1, dil=1, pad=0, s1=None, b1=None, act1=0, resi
     if want_act:
         act = torch.full((B, Ho, Wo, Cout), float("nan"), device=dev).to(tdt)
         d.out_act = act.data_ptr()
+    if argmax is not None:
+        uch, win = argmax
+        unary = torch.full((B, uch, Ho, Wo), float("nan"), device=dev)
+        keys = torch.zeros(B, (Cout - uch) // win, Ho, Wo, dtype=torch.int64, device=dev)
+        keep += [unary, keys]
+        d.unary_out, d.argmax_keys, d.unary_channels, d.limb_window = unary.data_ptr(), keys.data_ptr(), uch, win
     L.check(lib.ppn_conv2d_fused(C.byref(d), st), "ppn_conv2d_fused")
     torch.cuda.synchronize()
+    if info is not None:
+        info["kernel"] = lib.ppn_last_conv_kernel().decode()
+        if argmax is not None:
+            info["unary"], info["keys"] = unary.cpu(), keys.cpu()
     out = []
     for t in (raw, act):
         if t is None:

@@ -1,0 +1,306 @@
+"""GPU parity of EVERY tile instantiation of the large-tile convolution kernel (csrc/conv_big.hip).
+
+The tile of a launch is picked from M = B*Ho*Wo (big_tile_for): the small problems of test_conv_gpu.py only ever
+reach 128x128 / 128x64, while a batch-32 384x384 forward (bench.py, BASELINE configs[1]) runs 192x256, 192x128
+(plain and with the fused projection shortcut), 256x128 and 128x64.  Here
+
+* every (bp, bc) is FORCED through ppn_set_conv_tile_override on problems with a ragged last pixel tile and a
+  partial last channel tile, in f32 and bf16, for each epilogue: single output (bf16: the single-pass epilogue where
+  it fits, else the chunked one), residual + second (pre-activation) output, fused projection shortcut, and the
+  NCHW sigmoid head with the decode's arg-max keys;
+* the layer shapes of the batch-32 forward run at FULL size with the automatic choice and are compared with an
+  fp64 reference on sampled output rows (first / last tile, tile seams, the ragged tail).
+
+Every test asserts and prints the kernel instantiation it hit (ppn_last_conv_kernel).
+Reference: plain PyTorch CPU fp64 conv of the same layer (/root/reference/drn.py:42-57, model.py:104-136)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from test_conv_gpu import BF16_TOL, F32_TOL, q, ref_conv, rnd, run_conv
+
+pytestmark = pytest.mark.gpu
+
+TILES = [(256, 256), (192, 256), (128, 256), (256, 128), (192, 128), (128, 128), (256, 64), (128, 64)]
+
+
+@pytest.fixture
+def force_tile():
+    from pytorch_pose_proposal_network_amd import lib as L
+    lib = L.load()
+
+    def force(bp, bc):
+        L.check(lib.ppn_set_conv_tile_override(bp, bc), "ppn_set_conv_tile_override")
+
+    yield force
+    L.check(lib.ppn_set_conv_tile_override(0, 0), "ppn_set_conv_tile_override")
+
+
+def _dt(name):
+    from pytorch_pose_proposal_network_amd import lib as L
+    return L.PPN_F32 if name == "f32" else L.PPN_BF16
+
+
+def _kname(dtype_name, bp, bc, sc=False):
+    return "conv_igemm_big_kernel<%s, %d, %d, 8, %s>" % ("float" if dtype_name == "f32" else "__bf16", bp, bc,
+                                                         "true" if sc else "false")
+
+
+def _cout_for(bc):
+    # two channel tiles, the second one partial (cout_pad is a multiple of the class's largest tile)
+    return {256: 320, 128: 200, 64: 200}[bc]
+
+
+@pytest.mark.parametrize("dtype_name", ["f32", "bf16"])
+@pytest.mark.parametrize("tile", TILES, ids=["%dx%d" % t for t in TILES])
+def test_forced_tile_single_output(force_tile, tile, dtype_name):
+    """conv + BN + ReLU, one output: bf16 takes the single-pass epilogue where the tile fits it."""
+    bp, bc = tile
+    dtype = _dt(dtype_name)
+    force_tile(bp, bc)
+    B, Cin, H, W, Cout = 2, 128, 20, 23, _cout_for(bc)          # M = 920: ragged for 128 / 192 / 256
+    x = q(rnd(B, Cin, H, W, seed=31), dtype)
+    w = q(rnd(Cout, Cin, 3, 3, seed=32, scale=(2.0 / (Cin * 9)) ** 0.5), dtype)
+    s1 = 0.5 + torch.rand(Cout, generator=torch.Generator().manual_seed(33))
+    b1 = rnd(Cout, seed=34, scale=0.3)
+    info = {}
+    raw, _ = run_conv(x, w, dtype, 1, 2, 2, s1, b1, act1=1, info=info)
+    ref, _ = ref_conv(x, w, 1, 2, 2, s1, b1, act1=1)
+    print(info["kernel"])
+    assert info["kernel"] == _kname(dtype_name, bp, bc)
+    tol = (F32_TOL if dtype_name == "f32" else BF16_TOL) * max(1.0, float(ref.abs().max()))
+    assert not torch.isnan(raw).any()
+    assert float((raw - ref).abs().max()) <= tol
+
+
+@pytest.mark.parametrize("dtype_name", ["f32", "bf16"])
+@pytest.mark.parametrize("tile", TILES, ids=["%dx%d" % t for t in TILES])
+def test_forced_tile_residual_dual_output(force_tile, tile, dtype_name):
+    """conv2 of a BasicBlock: raw = acc + residual, act = relu(bn_next(raw)) -- the chunked f32 epilogue."""
+    bp, bc = tile
+    dtype = _dt(dtype_name)
+    force_tile(bp, bc)
+    B, Cc, H, W = 3, _cout_for(bc), 17, 19                        # M = 969
+    Cin = 64
+    x, res = q(rnd(B, Cin, H, W, seed=41), dtype), q(rnd(B, Cc, H, W, seed=42), dtype)
+    w = q(rnd(Cc, Cin, 3, 3, seed=43, scale=0.04), dtype)
+    s2, b2 = 0.5 + torch.rand(Cc, generator=torch.Generator().manual_seed(44)), rnd(Cc, seed=45, scale=0.2)
+    info = {}
+    raw, act = run_conv(x, w, dtype, 1, 1, 1, residual=res, s2=s2, b2=b2, act2=1, want_act=True, info=info)
+    rr, ra = ref_conv(x, w, 1, 1, 1, residual=res, s2=s2, b2=b2, act2=1)
+    print(info["kernel"])
+    assert info["kernel"] == _kname(dtype_name, bp, bc)
+    tol = F32_TOL * 10 if dtype_name == "f32" else BF16_TOL * 2
+    assert not torch.isnan(raw).any() and not torch.isnan(act).any()
+    assert float((raw - rr).abs().max()) <= tol * max(1.0, float(rr.abs().max()))
+    assert float((act - ra).abs().max()) <= tol * max(1.0, float(ra.abs().max()))
+    # second output only (Bottleneck tail, relu(bn3(conv) + residual)): no raw store
+    _, act2 = run_conv(x, w, dtype, 1, 1, 1, s1=s2, b1=b2, residual=res, act2=1, want_raw=False, want_act=True)
+    y = F.relu(F.conv2d(x.double(), w.double(), None, 1, 1, 1) * s2.double().view(1, -1, 1, 1) +
+               b2.double().view(1, -1, 1, 1) + res.double()).float()
+    assert float((act2 - y).abs().max()) <= tol * max(1.0, float(y.abs().max()))
+
+
+SC_TILES = [t for t in TILES if t[1] >= 128]
+
+
+@pytest.mark.parametrize("dtype_name", ["f32", "bf16"])
+@pytest.mark.parametrize("tile", SC_TILES, ids=["%dx%d" % t for t in SC_TILES])
+def test_forced_tile_fused_shortcut(force_tile, tile, dtype_name):
+    """conv2 + BasicBlock.downsample as one GEMM (the SC=true instantiations), with the pre-activation output."""
+    bp, bc = tile
+    dtype = _dt(dtype_name)
+    force_tile(bp, bc)
+    B, Cm, C2, Ho, s2 = 2, (256 if bc == 256 else 128), 64, 21, 2    # M = 882, source 41x41 (odd)
+    H2 = Ho * s2 - 1
+    x = q(rnd(B, Cm, Ho, Ho, seed=51), dtype)
+    w = q(rnd(Cm, Cm, 3, 3, seed=52, scale=(Cm * 9) ** -0.5), dtype)
+    x2 = q(rnd(B, C2, H2, H2, seed=53), dtype)
+    w2 = q(rnd(Cm, C2, 1, 1, seed=54, scale=C2 ** -0.5), dtype)
+    b1, sc2, sh2 = rnd(Cm, seed=55), rnd(Cm, seed=56) + 1.5, rnd(Cm, seed=57)
+    info = {}
+    raw, act = run_conv(x, w, dtype, 1, 1, 1, b1=b1, s2=sc2, b2=sh2, act2=1, want_act=True, shortcut=(x2, w2, s2),
+                        info=info)
+    print(info["kernel"])
+    assert info["kernel"] == _kname(dtype_name, bp, bc, sc=True)
+    y = F.conv2d(x.double(), w.double(), None, 1, 1, 1) + F.conv2d(x2.double(), w2.double(), None, s2)
+    y = y + b1.double().view(1, -1, 1, 1)
+    u = torch.relu(y * sc2.double().view(1, -1, 1, 1) + sh2.double().view(1, -1, 1, 1))
+    tol = 2e-5 if dtype_name == "f32" else 2e-2
+    assert (raw.double() - y).abs().max() <= tol * max(1.0, y.abs().max().item())
+    assert (act.double() - u).abs().max() <= tol * max(1.0, u.abs().max().item())
+
+
+def _check_keys(info, head, uch, win):
+    """keys[b,e,cell] = (value bits << 32) | ~s must be the FIRST maximum of head[b, uch+e*win : uch+(e+1)*win, cell]
+    (np.argmax semantics, /root/reference/datatest.py:113), and the compact unary tensor the first uch channels."""
+    keys = info["keys"].numpy().astype(np.int64)
+    B, E = keys.shape[:2]
+    hv = head.numpy()
+    val = ((keys >> 32) & 0xFFFFFFFF).astype(np.uint32).view(np.float32)
+    idx = (0xFFFFFFFF - (keys & 0xFFFFFFFF)).astype(np.int64)
+    limbs = hv[:, uch:uch + E * win].reshape(B, E, win, *hv.shape[2:])
+    assert np.array_equal(idx, limbs.argmax(axis=2))
+    assert np.array_equal(val, limbs.max(axis=2))
+    assert np.array_equal(info["unary"].numpy(), hv[:, :uch])
+
+
+HEAD_TILES = [t for t in TILES if t[1] >= 128]
+
+
+@pytest.mark.parametrize("dtype_name", ["f32", "bf16"])
+@pytest.mark.parametrize("tile", HEAD_TILES, ids=["%dx%d" % t for t in HEAD_TILES])
+def test_forced_tile_head_nchw_argmax(force_tile, tile, dtype_name):
+    """conv3-shaped launch (1x1 + bias + sigmoid, f32 NCHW) with the fused arg-max keys, head materialised too."""
+    bp, bc = tile
+    dtype = _dt(dtype_name)
+    force_tile(bp, bc)
+    uch, win, E = 108, 441, 3
+    Cout = uch + E * win                                            # 1431: partial last channel tile
+    B, H, W = 3, 15, 13                                             # M = 585
+    x = q(rnd(B, 512, H, W, seed=61), dtype)
+    w = q(rnd(Cout, 512, 1, 1, seed=62, scale=0.06), dtype)
+    bias = rnd(Cout, seed=63, scale=0.1)
+    info = {}
+    raw, _ = run_conv(x, w, dtype, b1=bias, act1=3, nchw=True, argmax=(uch, win), info=info)
+    print(info["kernel"])
+    assert info["kernel"] == _kname(dtype_name, bp, bc)
+    ref, _ = ref_conv(x, w, b1=bias, act1=3)
+    assert float((raw - ref).abs().max()) <= (2e-6 if dtype_name == "f32" else 5e-3)
+    _check_keys(info, raw, uch, win)
+    # keys only (the benchmarked path: the head tensor is not written)
+    info2 = {}
+    run_conv(x, w, dtype, b1=bias, act1=3, nchw=True, argmax=(uch, win), want_raw=False, info=info2)
+    assert torch.equal(info2["keys"], info["keys"]) and torch.equal(info2["unary"], info["unary"])
+
+
+# ---- the batch-32 384x384 layer shapes at full size, automatic tile choice ----------------------------------------
+
+def _sampled_rows(M, tiles=(128, 192, 256), n_random=96, seed=0):
+    """output pixel indices at tile seams of every tile height, the first / last rows and a random sample."""
+    rows = {0, 1, M - 1, M - 2}
+    for t in tiles:
+        last = (M - 1) // t * t
+        for base in (t, 2 * t, last, (M // t // 2) * t):
+            for d in (-1, 0, 1, t - 1):
+                r = base + d
+                if 0 <= r < M:
+                    rows.add(r)
+    g = np.random.default_rng(seed)
+    rows.update(int(v) for v in g.integers(0, M, n_random))
+    return np.array(sorted(rows))
+
+
+def _ref_rows(x, w, rows, Ho, Wo, stride, dil, pad):
+    """fp64 conv outputs [len(rows), Cout] at flat output pixels `rows` (b*Ho*Wo + oy*Wo + ox); x NCHW, w OIHW."""
+    B, Cin, H, W = x.shape
+    k = w.shape[2]
+    xp = F.pad(x.double(), (pad, pad, pad, pad))
+    wm = w.double().reshape(w.shape[0], -1)                         # [Cout, Cin*k*k]
+    out = torch.empty(len(rows), w.shape[0], dtype=torch.float64)
+    for i, r in enumerate(rows):
+        b, rem = divmod(int(r), Ho * Wo)
+        oy, ox = divmod(rem, Wo)
+        patch = xp[b, :, oy * stride: oy * stride + dil * (k - 1) + 1: dil, ox * stride: ox * stride + dil * (k - 1) + 1: dil]
+        out[i] = wm @ patch.reshape(-1)
+    return out
+
+
+FULL = [
+    # name,                    B,  Cin, Cout, H,  W,  k, s, d, p, expected kernel tile
+    ("L7_512_d2_48x48",        32, 512, 512, 48, 48, 3, 1, 2, 2, (192, 256)),
+    ("L6_c1_256_512_d4",       32, 256, 512, 48, 48, 3, 1, 4, 4, (192, 256)),
+    ("L5_c2_256_d2",           32, 256, 256, 48, 48, 3, 1, 2, 2, (192, 128)),
+    ("L4_c1_64_128_s2",        32, 64, 128, 96, 96, 3, 2, 1, 1, (192, 128)),
+    ("L3_c2_64_96x96",         32, 64, 64, 96, 96, 3, 1, 1, 1, None),
+    ("B1_c1_512_s2_24x24",     32, 512, 512, 48, 48, 3, 2, 1, 1, None),
+    ("ragged_M_31",            31, 512, 512, 47, 45, 3, 1, 2, 2, None),
+]
+
+
+@pytest.mark.parametrize("dtype_name", ["f32", "bf16"])
+@pytest.mark.parametrize("case", FULL, ids=[c[0] for c in FULL])
+def test_full_size_layer_sampled(case, dtype_name):
+    """Batch-32 layer shapes of DRN-D-22 at 384x384 with the AUTOMATIC tile (the instantiations bench.py runs):
+    single-output conv+BN+ReLU, then the same conv with residual + second output; sampled rows vs fp64."""
+    name, B, Cin, Cout, H, W, k, s, dl, p, want = case
+    dtype = _dt(dtype_name)
+    eff = dl * (k - 1) + 1
+    Ho, Wo = (H + 2 * p - eff) // s + 1, (W + 2 * p - eff) // s + 1
+    M = B * Ho * Wo
+    x = q(rnd(B, Cin, H, W, seed=71), dtype)
+    w = q(rnd(Cout, Cin, k, k, seed=72, scale=(2.0 / (Cin * k * k)) ** 0.5), dtype)
+    s1 = 0.5 + torch.rand(Cout, generator=torch.Generator().manual_seed(73))
+    b1 = rnd(Cout, seed=74, scale=0.3)
+    rows = _sampled_rows(M)
+    acc = _ref_rows(x, w, rows, Ho, Wo, s, dl, p)
+    info = {}
+    raw, _ = run_conv(x, w, dtype, s, dl, p, s1, b1, act1=1, info=info)
+    print(name, dtype_name, "M =", M, info["kernel"])
+    if want is not None:
+        assert info["kernel"] == _kname(dtype_name, *want)
+    got = raw.permute(0, 2, 3, 1).reshape(M, Cout)[rows].double()
+    ref = torch.relu(acc * s1.double() + b1.double())
+    tol = (F32_TOL if dtype_name == "f32" else BF16_TOL) * max(1.0, float(ref.abs().max()))
+    assert not torch.isnan(raw).any()
+    assert float((got - ref).abs().max()) <= tol
+    # residual + second output on the same shape (chunked epilogue of the same instantiation)
+    res = q(rnd(B, Cout, Ho, Wo, seed=75), dtype)
+    s2, b2 = 0.5 + torch.rand(Cout, generator=torch.Generator().manual_seed(76)), rnd(Cout, seed=77, scale=0.2)
+    raw2, act2 = run_conv(x, w, dtype, s, dl, p, residual=res, s2=s2, b2=b2, act2=1, want_act=True)
+    rr = acc + res.permute(0, 2, 3, 1).reshape(M, Cout)[rows].double()
+    ra = torch.relu(rr * s2.double() + b2.double())
+    tol2 = (F32_TOL * 10 if dtype_name == "f32" else BF16_TOL * 2)
+    assert not torch.isnan(raw2).any() and not torch.isnan(act2).any()
+    assert float((raw2.permute(0, 2, 3, 1).reshape(M, Cout)[rows].double() - rr).abs().max()) <= tol2 * max(1.0, float(rr.abs().max()))
+    assert float((act2.permute(0, 2, 3, 1).reshape(M, Cout)[rows].double() - ra).abs().max()) <= tol2 * max(1.0, float(ra.abs().max()))
+
+
+@pytest.mark.parametrize("dtype_name", ["f32", "bf16"])
+def test_full_size_fused_shortcut_sampled(dtype_name):
+    """layer4.0 conv2 + projection shortcut at batch 32 (M = 73 728): the 192x128 SC=true instantiation."""
+    dtype = _dt(dtype_name)
+    B, Cm, C2, Ho, s2 = 32, 128, 64, 48, 2
+    H2 = Ho * s2
+    M = B * Ho * Ho
+    x = q(rnd(B, Cm, Ho, Ho, seed=81), dtype)
+    w = q(rnd(Cm, Cm, 3, 3, seed=82, scale=(Cm * 9) ** -0.5), dtype)
+    x2 = q(rnd(B, C2, H2, H2, seed=83), dtype)
+    w2 = q(rnd(Cm, C2, 1, 1, seed=84, scale=C2 ** -0.5), dtype)
+    b1, sc2, sh2 = rnd(Cm, seed=85), rnd(Cm, seed=86) + 1.5, rnd(Cm, seed=87)
+    info = {}
+    raw, act = run_conv(x, w, dtype, 1, 1, 1, b1=b1, s2=sc2, b2=sh2, act2=1, want_act=True, shortcut=(x2, w2, s2),
+                        info=info)
+    print(info["kernel"])
+    assert info["kernel"] == _kname(dtype_name, 192, 128, sc=True)
+    rows = _sampled_rows(M)
+    y = _ref_rows(x, w, rows, Ho, Ho, 1, 1, 1) + _ref_rows(x2, w2, rows, Ho, Ho, s2, 1, 0) + b1.double()
+    u = torch.relu(y * sc2.double() + sh2.double())
+    tol = 2e-5 if dtype_name == "f32" else 2e-2
+    assert (raw.permute(0, 2, 3, 1).reshape(M, Cm)[rows].double() - y).abs().max() <= tol * max(1.0, y.abs().max().item())
+    assert (act.permute(0, 2, 3, 1).reshape(M, Cm)[rows].double() - u).abs().max() <= tol * max(1.0, u.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype_name", ["f32", "bf16"])
+def test_full_size_head_conv3_argmax(dtype_name):
+    """conv3 at batch 32 (512 -> 7605 on 24x24, the 192x128 head tile): materialised head on sampled pixels vs fp64,
+    arg-max keys vs the materialised head everywhere, and keys-only == keys of the materialising launch."""
+    dtype = _dt(dtype_name)
+    B, H, W, Cout, uch, win = 32, 24, 24, 7605, 108, 441
+    M = B * H * W
+    x = q(rnd(B, 512, H, W, seed=91), dtype)
+    w = q(rnd(Cout, 512, 1, 1, seed=92, scale=0.06), dtype)
+    bias = rnd(Cout, seed=93, scale=0.1)
+    info = {}
+    raw, _ = run_conv(x, w, dtype, b1=bias, act1=3, nchw=True, argmax=(uch, win), info=info)
+    print(info["kernel"])
+    assert info["kernel"] == _kname(dtype_name, 192, 128)
+    rows = _sampled_rows(M, n_random=32)
+    ref = torch.sigmoid(_ref_rows(x, w, rows, H, W, 1, 1, 0) + bias.double())
+    got = raw.permute(0, 2, 3, 1).reshape(M, Cout)[rows].double()
+    assert float((got - ref).abs().max()) <= (2e-6 if dtype_name == "f32" else 5e-3)
+    _check_keys(info, raw, uch, win)
+    info2 = {}
+    run_conv(x, w, dtype, b1=bias, act1=3, nchw=True, argmax=(uch, win), want_raw=False, info=info2)
+    assert torch.equal(info2["keys"], info["keys"]) and torch.equal(info2["unary"], info["unary"])
