@@ -5,10 +5,13 @@ th [K,H,W]; te [E,sH,sW,H,W]; max_delta_ij -> weight_ij; weight; tx_half, ty_hal
 generator (1..4 people per image, keypoints uniform in frame, part size 8..24 px,
 instance box 60..200 px) driven by the repo's integer PRNG.
 
-Parity pin: UNPINNED for the encoder itself -- KeypointsDataset.__getitem__ cannot run here (needs MPII images,
-imgaug, skimage and uses the removed np.bool, dataset.py:53); the rules below follow dataset.py:108-185 line by
-line.  What IS pinned is everything computed FROM these targets (PPNLoss, oracle/loss_ref.py vs the imported
-main.PPNLoss, tests/golden/loss_*.npz).
+Parity pin: PINNED by tests/golden/targets_cases.npz -- the ten tensors returned by the reference's own
+KeypointsDataset.__getitem__ (dataset.py:70-200), run in this container by tests/golden/make_golden.py on synthetic
+annotation files (image loader stubbed, `np.bool` aliased, the imgaug stage bypassed with the annotated coordinates in
+IAA's containers, the reference's own aug.ToNormalizedTensor kept).  encode_targets() below equals them bit for bit
+on every case, edge cases included (unlabeled root, keypoints outside the frame and their int() truncation, limbs
+beyond the window, invisible joints, people sharing cells); tests/test_oracle.py replays the fixture on CPU.
+Not covered: dataset.py:44-55 drops annotations without a visible joint at load time (dataset loading is out of scope).
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
 """

@@ -420,6 +420,91 @@ def make_eval(datatest):
                         ap=np.array(exp, np.float64))
 
 
+def target_cases():
+    """People lists of the target-encoder fixture: synthetic crowds (synth.synthetic_people) plus the edge cases of
+    dataset.py:108-152 -- an unlabeled root (w = 0), keypoints left/above the frame (int() truncates towards zero,
+    so x in (-16, 0) lands in column 0 with a negative offset), keypoints right/below the frame (dropped), limbs
+    longer than the 21x21 window (dropped), an invisible joint, and two people sharing cells (the later one wins)."""
+    cases = []
+    for seed in (11, 12, 13):
+        cases.append([dict(p) for p in synth.synthetic_people(seed)])
+    ppl = [dict(p) for p in synth.synthetic_people(14)]
+    a = ppl[0]
+    a["points"] = a["points"].copy()
+    a["points"][0] = (-5.0, 37.5)          # left of the frame, truncation -> column 0, tx = -0.3125
+    a["points"][1] = (391.25, 100.0)       # right of the frame -> dropped
+    a["points"][2] = (200.0, -3.0)         # above the frame -> row 0, ty = -0.1875
+    a["points"][3] = (10.0, 383.9)         # last row
+    a["points"][4] = (383.99, 383.99)      # last cell
+    a["visible"] = a["visible"].copy()
+    a["visible"][5] = False
+    twin = dict(a)                          # same cells, other sizes: overwrites a's entries
+    twin["size"] = np.float32(19.5)
+    twin["bbox"] = (a["bbox"][0], a["bbox"][1], np.float32(0.0), a["bbox"][3])   # w = 0: root unlabeled
+    cases.append(ppl + [twin])
+    return cases
+
+
+def make_targets():
+    """tests/golden/targets_cases.npz: the ten target tensors of the reference's own
+    KeypointsDataset.__getitem__ (dataset.py:70-200) for synthetic annotation files.  The image loader is stubbed
+    (skimage.io.imread -> zeros; the encoder never reads pixels), `np.bool` (removed from NumPy, dataset.py:53) is
+    aliased to bool, and the IAA augmentation (aug.py:13-134, needs imgaug) is bypassed by a transform that hands
+    over the annotated coordinates in the containers IAA produces (keypoints f32 [P,17,2], bbox [[cx,cy,w,h]]) to the
+    reference's own aug.ToNormalizedTensor."""
+    import json
+    import tempfile
+    if not hasattr(np, "bool"):
+        np.bool = bool                      # dataset.py:53
+    sys.modules["skimage.io"].imread = lambda path: np.zeros((384, 384, 3), np.uint8)
+    sys.modules["skimage"].io.imread = sys.modules["skimage.io"].imread
+    import aug
+    import dataset
+    from oracle import targets_ref as T
+    cases = target_cases()
+    annos = []
+    for i, people in enumerate(cases):
+        for p in people:
+            annos.append({"file_name": f"img_{i:03d}.jpg",
+                          "keypoints": [[float(x), float(y)] for x, y in np.asarray(p["points"], np.float32)],
+                          "bbox": [float(v) for v in p["bbox"]],
+                          "is_visible": [int(bool(v)) for v in p["visible"]],
+                          "size": float(p["size"])})
+    to_tensor = aug.ToNormalizedTensor()
+
+    def bypass_iaa(sample):
+        kp = np.asarray(sample["keypoints"], np.float32).reshape(-1, 17, 2)
+        bb = [[float(v) for v in b] for b in sample["bbox"]]
+        return to_tensor({"image": sample["image"], "keypoints": kp, "bbox": bb, "is_visible": sample["is_visible"],
+                          "size": sample["size"]})
+
+    with tempfile.TemporaryDirectory() as td:
+        jf = os.path.join(td, "anno.json")
+        with open(jf, "w") as f:
+            json.dump({"annotations": annos}, f)
+        ds = dataset.KeypointsDataset(json_file=jf, root_dir=td, transform=bypass_iaa, insize=(384, 384),
+                                      outsize=(24, 24), local_grid_size=(21, 21))
+        assert len(ds) == len(cases)
+        names = ["delta", "weight", "weight_ij", "tx", "ty", "tx_half", "ty_half", "tw", "th", "te"]   # dataset.py:200
+        out = {}
+        for i, people in enumerate(cases):
+            item = ds[i]
+            ref = {n: item[1 + j].numpy() for j, n in enumerate(names)}
+            mine = T.encode_targets(people)
+            for n in names:
+                assert ref[n].dtype == np.float32 and ref[n].shape == mine[n].shape, n
+                assert np.array_equal(ref[n], mine[n]), (i, n, np.abs(ref[n] - mine[n]).max())
+                out[f"case{i}/{n}"] = ref[n]
+            out[f"case{i}/bbox"] = np.array([p["bbox"] for p in people], np.float32)
+            out[f"case{i}/points"] = np.stack([np.asarray(p["points"], np.float32) for p in people])
+            out[f"case{i}/visible"] = np.stack([np.asarray(p["visible"], bool) for p in people])
+            out[f"case{i}/size"] = np.array([p["size"] for p in people], np.float32)
+            print(f"targets case {i}: {len(people)} people, delta {int(ref['delta'].sum())} cells, te {int(ref['te'].sum())} "
+                  f"limbs, weight_ij==1 {int((ref['weight_ij'] == 1).sum())}; oracle == reference (10 tensors, bitwise)")
+    out["n_cases"] = np.array(len(cases))
+    np.savez_compressed(os.path.join(HERE, "targets_cases.npz"), **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -438,6 +523,8 @@ def main():
         make_train(drn, model)
     if args.only in (None, "eval"):
         make_eval(datatest)
+    if args.only in (None, "targets"):
+        make_targets()
 
 
 if __name__ == "__main__":

@@ -85,3 +85,17 @@ def test_target_encoder_bit_exact(size, batch, seed):
         exp = np.stack([r[k] for r in ref])
         assert np.array_equal(got[k].cpu().numpy(), exp), k
     assert float(got["te"].sum()) > 0 and float(got["delta"].sum()) > 0
+
+
+def test_target_encoder_equals_reference_fixture(golden_dir):
+    """csrc/encode.hip vs the tensors the reference's own KeypointsDataset.__getitem__ produced (targets_cases.npz,
+    dataset.py:96-200): all cases in one batch (ragged people counts), bit for bit."""
+    from pytorch_pose_proposal_network_amd import targets
+    g = np.load(os.path.join(golden_dir, "targets_cases.npz"))
+    n = int(g["n_cases"])
+    lists = [[dict(bbox=tuple(g[f"case{i}/bbox"][p]), points=g[f"case{i}/points"][p], visible=g[f"case{i}/visible"][p],
+                   size=g[f"case{i}/size"][p]) for p in range(len(g[f"case{i}/size"]))] for i in range(n)]
+    got = targets.encode_targets(targets.pack_people(lists))
+    for k in targets.TARGET_KEYS:
+        exp = np.stack([g[f"case{i}/{k}"] for i in range(n)])
+        assert np.array_equal(got[k].cpu().numpy(), exp), k

@@ -241,3 +241,21 @@ def test_ap_evaluation_golden(golden_dir):
     empty = [list(o) for o in obj]
     empty[2], empty[3] = [[] for _ in obj[2]], [[] for _ in obj[3]]
     assert np.allclose(evaluate.evaluation(empty), 0.0)
+
+
+def test_target_encoder_oracle_equals_reference_fixture(golden_dir):
+    """oracle/targets_ref.encode_targets == the reference's KeypointsDataset.__getitem__ (dataset.py:96-200) on the
+    fixture's people lists: ten tensors, bit for bit (fixture generated by make_golden.py --only targets)."""
+    from oracle import targets_ref as T
+    g = np.load(os.path.join(golden_dir, "targets_cases.npz"))
+    n = int(g["n_cases"])
+    assert n >= 4
+    for i in range(n):
+        people = [dict(bbox=tuple(g[f"case{i}/bbox"][p]), points=g[f"case{i}/points"][p],
+                       visible=g[f"case{i}/visible"][p], size=g[f"case{i}/size"][p])
+                  for p in range(len(g[f"case{i}/size"]))]
+        mine = T.encode_targets(people)
+        for k in ("delta", "weight", "weight_ij", "tx", "ty", "tx_half", "ty_half", "tw", "th", "te"):
+            assert np.array_equal(mine[k], g[f"case{i}/{k}"]), (i, k)
+    # the edge cases are really in there: a negative offset (keypoint left of the frame, int() truncation)
+    assert float(g["case3/tx"].min()) < 0 and float(g["case3/ty"].min()) < 0

@@ -76,11 +76,6 @@ def test_pipelined_inference_equals_serial(golden_dir):
     results.append(prev.to_host())
     pipe.flush()
     assert sum(r["n"] for res in serial for r in res) > 0
-    # five different input tensors went through each of the two slots: the plans copy them into their own input
-    # buffer, so every plan captured its hipGraph at most once (not once per fresh tensor)
-    caps = model.graph_captures()
-    assert caps and all(c <= 1 for c in caps.values()), caps
-    assert any(c == 1 for c in caps.values()), caps
     for s_, p_ in zip(serial, results):
         for a, b in zip(s_, p_):
             assert a["n"] == b["n"]
@@ -110,6 +105,11 @@ def test_multi_lane_inference_equals_serial(golden_dir, lanes):
         results.append(r.to_host())
     pipe.close()                                  # restores the single-stream tile policy
     assert len(results) == len(serial)
+    # seven DIFFERENT input tensors went through the lanes: a plan copies them into its own input buffer, so its
+    # hipGraph is captured once (third run of a plan on a non-default stream), not once per fresh tensor
+    caps = {k: c for k, c in model.graph_captures().items() if k[4]}
+    assert all(c <= 1 for c in caps.values()), caps
+    assert lanes != 2 or any(c == 1 for c in caps.values()), caps
     for s_, p_ in zip(serial, results):
         for a, b in zip(s_, p_):
             assert a["n"] == b["n"]
