@@ -304,6 +304,27 @@ def extra_sections(args, dev, net, frames, dec):
                 "images_per_sec": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 3),
                 "frac_of_mfma_peak_3x_fwd_flops": round(3 * flops / dt / 1e12 / BF16_DENSE_PEAK_TFLOPS, 4)}
 
+    def bf16_agreement():
+        # the benchmarked dtype against the REFERENCE pipeline's people lists (tests/golden/e2e_d22_384.npz: 8 frames,
+        # forward + get_humans_by_feature of the reference itself); gated in tests/test_e2e_gpu.py
+        g = np.load(os.path.join(ROOT, "tests", "golden", "e2e_d22_384.npz"))
+        nb, sz = int(g["batch"]), int(g["size"])
+        if args.arch != str(g["arch"]) or S != sz or args.dtype != "bf16":
+            return {"skipped": "fixture is drn_d_22 384x384, bf16 mode"}
+        fr = torch.from_numpy(prng.u8_frames(int(g["seed_in"]), nb, (sz, sz))).to(dev)
+        got = rt.inference_batch(fr, net).to_host()
+        tot = np.zeros(5, np.int64)
+        for i in range(nb):
+            exp = {k: g[f"{i}/{k}"] for k in ("n", "kp_cell", "limb_arg")}
+            tot += np.array(decode.people_agreement(exp, got[i]))
+        n, exact, same, kp_eq, kp_all = (int(v) for v in tot)
+        return {"what": "bf16 fused path vs the reference pipeline's people on 8 calibrated frames (dense synthetic heads: "
+                        "~490 root candidates per frame with near-equal scores)", "reference_people": n,
+                "reproduced_exactly": exact, "same_root": same, "keypoint_cells_equal": kp_eq,
+                "keypoint_cells_compared": kp_all, "same_root_frac": round(same / max(n, 1), 4),
+                "keypoint_cell_agreement": round(kp_eq / max(kp_all, 1), 4)}
+
+    section("bf16_agreement", bf16_agreement)
     section("materialized_head", materialized)
     section("decode_stress", decode_stress)
     section("f32_parity_mode", f32_mode)

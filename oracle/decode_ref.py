@@ -61,8 +61,15 @@ def build_bbox(x, y, w, h, insize=(384, 384)):
     return np.stack([ymin, xmin, ymax, xmax], axis=-1).astype(np.float32)
 
 
-def nms_ref(bbox: np.ndarray, thresh: float, score=None, limit=None) -> np.ndarray:
-    """datatest.py:134-160 with fp32 arithmetic in the reference's operation order."""
+def _note(margins, key, value):
+    if margins is not None and np.isfinite(value):
+        margins[key] = min(margins.get(key, np.inf), float(value))
+
+
+def nms_ref(bbox: np.ndarray, thresh: float, score=None, limit=None, margins=None) -> np.ndarray:
+    """datatest.py:134-160 with fp32 arithmetic in the reference's operation order.
+    `margins` (optional dict) receives the smallest distance of any decision from its flip point: 'iou' =
+    min |iou - thresh| over the compared pairs, 'order' = smallest gap between consecutively sorted scores."""
     n = len(bbox)
     if n == 0:
         return np.zeros((0,), dtype=np.int32)
@@ -71,6 +78,8 @@ def nms_ref(bbox: np.ndarray, thresh: float, score=None, limit=None) -> np.ndarr
         score = np.asarray(score, np.float32)
         order = np.argsort(-score, kind="stable")      # tie rule: see module docstring
         bbox = bbox[order]
+        if n > 1:
+            _note(margins, "order", np.min(-np.diff(score[order].astype(np.float64))))
     thr = np.float32(thresh)
     area = (bbox[:, 2] - bbox[:, 0]) * (bbox[:, 3] - bbox[:, 1])
     keep = []
@@ -86,6 +95,8 @@ def nms_ref(bbox: np.ndarray, thresh: float, score=None, limit=None) -> np.ndarr
             with np.errstate(divide="ignore", invalid="ignore"):
                 iou = inter / ((area[i] + area[keep]) - inter)
             ok = not bool((iou >= thr).any())
+            # (pairs after the first suppressing one are not decisive, but counting them only shrinks the margin)
+            _note(margins, "iou", np.nanmin(np.abs(iou.astype(np.float64) - float(thr))))
         if ok:
             keep.append(i)
             if limit is not None and len(keep) >= limit:
@@ -108,8 +119,13 @@ def tree_edges():
 
 
 def decode_ref(head: np.ndarray, det_thr=0.15, nms_thr=0.3, min_kp=1, insize=(384, 384),
-               local_grid=(21, 21)):
+               local_grid=(21, 21), margins=None):
     """Compact decode of one image's head tensor.
+
+    `margins` (optional dict) receives, per kind of decision taken on THIS head, the smallest distance from its
+    flip point: 'cand' |delta_root - thr| over all cells, 'order' / 'iou' (nms_ref), 'argmax' top1 - top2 of every
+    evaluated limb window, 'hop' |delta_target - thr| of every evaluated hop.  A head within eps of this one must
+    decode to the same indices when every margin exceeds the perturbation eps can cause (tests/test_e2e_gpu.py).
 
     Returns dict with
       n            number of humans kept
@@ -127,7 +143,8 @@ def decode_ref(head: np.ndarray, det_thr=0.15, nms_thr=0.3, min_kp=1, insize=(38
     thr = np.float32(det_thr)
     cand_h, cand_w = np.where(delta[0] > thr)
     cand = (cand_h * W + cand_w).astype(np.int32)
-    selected = nms_ref(bbox[0][cand_h, cand_w], nms_thr, delta[0][cand_h, cand_w])
+    selected = nms_ref(bbox[0][cand_h, cand_w], nms_thr, delta[0][cand_h, cand_w], margins=margins)
+    _note(margins, "cand", np.min(np.abs(delta[0].astype(np.float64) - float(thr))))
 
     order = tree_edges()
     roots, kp_cells, limb_args, boxes, scores = [], [], [], [], []
@@ -144,10 +161,14 @@ def decode_ref(head: np.ndarray, det_thr=0.15, nms_thr=0.3, min_kp=1, insize=(38
             win = e[ei, :, :, i_h, i_w]                       # [sH, sW], row-major argmax
             u = int(np.argmax(win))                            # first maximum (datatest.py:113)
             larg[ei] = u
+            if margins is not None:
+                top2 = np.partition(win.reshape(-1).astype(np.float64), -2)[-2:]
+                _note(margins, "argmax", top2[1] - top2[0])
             j_h = i_h + u // sW - sH // 2
             j_w = i_w + u % sW - sW // 2
             if j_h < 0 or j_w < 0 or j_h >= H or j_w >= W:
                 continue
+            _note(margins, "hop", abs(float(delta[t, j_h, j_w]) - float(thr)))
             if delta[t, j_h, j_w] < thr:
                 continue
             cell[t] = j_h * W + j_w

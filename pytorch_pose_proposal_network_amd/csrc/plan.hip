@@ -135,7 +135,8 @@ extern "C" int ppn_plan_run(ppn_plan* p, void* stream) {
     hipStream_t st = static_cast<hipStream_t>(stream);
     static const bool graphs = !(getenv("PPN_PLAN_GRAPH") && atoi(getenv("PPN_PLAN_GRAPH")) == 0);
     // the first runs go launch by launch (they set kernel attributes, which must not happen inside a capture)
-    if (graphs && !p->graph_off && p->direct_runs >= 2) {
+    // (the legacy default stream cannot be captured: launches on it stay direct, without giving up on graphs)
+    if (graphs && !p->graph_off && st != nullptr && p->direct_runs >= 2) {
         const void* src = plan_src(p);
         if (!p->graph_exec || p->graph_src != src || p->graph_stream != st) {
             if (p->graph_exec) {

@@ -79,6 +79,19 @@ class DecodeResult:
         return res
 
 
+def people_agreement(expected: dict, got: dict):
+    """How much of one image's `expected` compact result (DecodeResult.to_host() / oracle format) `got` reproduces,
+    people matched by root cell: (expected people, reproduced exactly = same root, every keypoint cell and every limb
+    arg-max, same root found, equal keypoint cells among same-root people, keypoint cells compared)."""
+    def people(res):
+        return {int(res["kp_cell"][i, 0]): (res["kp_cell"][i], res["limb_arg"][i]) for i in range(int(res["n"]))}
+    pe, pg = people(expected), people(got)
+    same = [r for r in pe if r in pg]
+    exact = sum(1 for r in same if np.array_equal(pe[r][0], pg[r][0]) and np.array_equal(pe[r][1], pg[r][1]))
+    kp_eq = sum(int((pe[r][0] == pg[r][0]).sum()) for r in same)
+    return len(pe), exact, len(same), kp_eq, len(same) * cfg.K
+
+
 class Decoder:
     """Owns the scratch/output buffers for a fixed (batch, grid) so repeated calls allocate nothing."""
 
