@@ -211,6 +211,15 @@ int ppn_conv_tiling(int32_t dtype, int32_t cin, int32_t cout, int32_t ksize, int
 
 int ppn_conv2d_fused(const ppn_conv_desc* d, void* stream);
 
+/*
+ * Frame ingest (rt_test.py:150-157 grab_frame): cv2.resize(frame, (dst_w, dst_h)) [INTER_LINEAR, 8-bit fixed point],
+ * cv2.flip(.,0) + cv2.flip(.,1) when `flip`, cv2.COLOR_BGR2RGB when `swap_rb`, on the device.
+ *   src_bgr  u8 [batch, src_h, src_w, 3]   camera frames as cv2.VideoCapture.read() delivers them
+ *   dst_rgb  u8 [batch, dst_h, dst_w, 3]   e.g. the conv plan's own input buffer (PoseProposalNet.input_buffer)
+ * The arithmetic is OpenCV's (oracle/ingest_ref.py restates it; parity unpinned: cv2 is not in this image). */
+int ppn_ingest_frames(const void* src_bgr, int32_t batch, int32_t src_h, int32_t src_w, void* dst_rgb, int32_t dst_h,
+                      int32_t dst_w, int32_t flip, int32_t swap_rb, void* stream);
+
 /* Process-wide tile choice of the large-tile convolution kernel.  0 (default): one launch at a time -- tiles are
  * sized so that the workgroup count fills whole rounds of the 256 CUs.  1: several launches are in flight on
  * different streams (rt.MultiLaneInference) -- a partial last round is filled by the other stream's workgroups, so

@@ -30,6 +30,7 @@ SOURCES = [
     ("encode.hip", ["-ffp-contract=off"]),
     ("wgrad.hip", []),
     ("stem_wgrad.hip", []),
+    ("ingest.hip", ["-ffp-contract=off"]),
 ]
 
 

@@ -86,6 +86,8 @@ class PoseProposalNet:
         self._dev: Dict[str, torch.Tensor] = {}      # packed weights / folded BN on the device
         self._plans: Dict[tuple, _Plan] = {}
         self._lib = None
+        self._trainer = None                          # trainer.PPNTrainer behind train(): same object, both modes
+        self._trainer_dirty = False
         self._mean = (C.c_float * 3)(*cfg.MEAN)
         self._std = (C.c_float * 3)(*cfg.STD)
 
@@ -95,20 +97,41 @@ class PoseProposalNet:
         return self
 
     def eval(self):
-        self.training = False
-        return self
+        return self.train(False)
 
     def train(self, mode: bool = True):
-        if mode:
-            raise NotImplementedError("this class runs the folded-BN inference plan; training (train-mode BN, "
-                                      "backward, GradNorm, Adam) lives in trainer.PPNTrainer")
-        self.training = False
+        """nn.Module.train(): the SAME object serves both modes, as in main.py:643 / rt_test.py:94.
+
+        mode=True: forward() runs the train-mode network (batch statistics, running statistics updated with momentum
+        0.1, activations taped) of ``self.trainer`` -- a trainer.PPNTrainer created on first use from this model's
+        state_dict; the training loop then calls ``model.trainer.train_step(x, targets)``.
+        mode=False: back to the folded-BN inference plan; parameters and running statistics the trainer changed are
+        folded again first."""
+        if mode and not self.training:
+            if not self._sd:
+                raise RuntimeError("PoseProposalNet.train(): call load_state_dict() first")
+            if self._trainer is None:
+                from .trainer import PPNTrainer
+                self._trainer = PPNTrainer(self.arch, self._sd, compute_dtype=self.compute_dtype, insize=self.insize,
+                                           device=self.device)
+            self._trainer_dirty = True                # train_step / train-mode forwards change parameters and statistics
+        if not mode and self.training and self._trainer is not None and self._trainer_dirty:
+            self._trainer_dirty = False
+            self.load_state_dict(self._trainer.state_dict(), _from_trainer=True)
+        self.training = bool(mode)
         return self
 
+    @property
+    def trainer(self):
+        """The PPNTrainer behind train mode (None before the first train())."""
+        return self._trainer
+
     def state_dict(self):
+        if self._trainer is not None and self._trainer_dirty:        # train mode: the trainer holds the live values
+            return {k: v.detach().cpu() for k, v in self._trainer.state_dict().items()}
         return dict(self._sd)
 
-    def load_state_dict(self, state_dict, strict: bool = True):
+    def load_state_dict(self, state_dict, strict: bool = True, _from_trainer: bool = False):
         """Accepts the reference checkpoint's ``state_dict`` (rt_test.py:74-75); ``module.``-prefixed DDP
         checkpoints are stripped as main.py:311-318 does."""
         sd = {}
@@ -127,6 +150,8 @@ class PoseProposalNet:
                 raise RuntimeError(f"load_state_dict: {k} has shape {tuple(sd[k].shape)}, expected {tuple(shape)}")
         self._sd = sd
         self._prepare()
+        if self._trainer is not None and not _from_trainer:
+            self._trainer.load_state_dict(sd)
         return self
 
     # ---- weight preparation -------------------------------------------------------------------
@@ -312,6 +337,8 @@ class PoseProposalNet:
         next forward of the same shape (clone it to keep it)."""
         if not (input.is_cuda and input.dtype == torch.float32 and input.dim() == 4 and input.shape[1] == 3):
             raise ValueError("forward expects a float32 CUDA tensor [B,3,H,W]")
+        if self.training:                                  # model.train(): batch statistics, running stats advance
+            return self._trainer.forward(input)
         x = input.contiguous()
         plan = self._plan_for(x, False)
         L.check(self._lib.ppn_plan_run(plan.handle, L.current_stream_ptr()), "ppn_plan_run")
@@ -329,6 +356,8 @@ class PoseProposalNet:
         outputs while slot 1's forward runs (rt.InferencePipeline)."""
         if not (frames.is_cuda and frames.dtype == torch.uint8 and frames.dim() == 4 and frames.shape[3] == 3):
             raise ValueError("forward_u8 expects a uint8 CUDA tensor [B,H,W,3]")
+        if self.training:
+            raise RuntimeError("forward_u8 is the inference entry point (folded BN): call model.eval() first")
         x = frames.contiguous()
         plan = self._plan_for(x, True, fused_decode, slot)
         L.check(self._lib.ppn_plan_run(plan.handle, L.current_stream_ptr()), "ppn_plan_run")

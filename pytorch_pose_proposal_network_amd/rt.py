@@ -41,6 +41,39 @@ def network(resume: Optional[str] = None, image_size: int = 384, arch: str = "dr
     return model, outsize, local_grid_size
 
 
+def ingest_frames(frames_bgr: torch.Tensor, size: int = 384, out: Optional[torch.Tensor] = None,
+                  flip: bool = True, swap_rb: bool = True) -> torch.Tensor:
+    """The cv2 calls of rt_test.py:150-157 on the device: u8 BGR camera frames [B,Hs,Ws,3] (CUDA) ->
+    cv2.resize(dsize=(size,size)) -> flip both axes -> BGR2RGB -> u8 RGB [B,size,size,3].  `out` may be the model's
+    own input buffer (``model.input_buffer(B, size, size, fused_decode=..., slot=...)``): forward_u8(out) then runs
+    without any further copy."""
+    from . import lib as L
+    if not (frames_bgr.is_cuda and frames_bgr.dtype == torch.uint8 and frames_bgr.dim() == 4 and frames_bgr.shape[3] == 3):
+        raise ValueError("ingest_frames expects a uint8 CUDA tensor [B,Hs,Ws,3]")
+    x = frames_bgr.contiguous()
+    b, hs, ws, _ = x.shape
+    if out is None:
+        out = torch.empty(b, size, size, 3, dtype=torch.uint8, device=x.device)
+    if tuple(out.shape) != (b, size, size, 3) or out.dtype != torch.uint8 or not out.is_contiguous():
+        raise ValueError(f"out must be a contiguous uint8 tensor {(b, size, size, 3)}")
+    L.check(L.load().ppn_ingest_frames(x.data_ptr(), b, hs, ws, out.data_ptr(), size, size, int(flip), int(swap_rb),
+                                       L.current_stream_ptr()), "ppn_ingest_frames")
+    return out
+
+
+def grab_frame(cap, size: int = 384, out: Optional[torch.Tensor] = None):
+    """rt_test.py:150-157 with the resize / flips / colour conversion on the GPU: `cap` is anything with
+    cv2.VideoCapture's ``read() -> (ret, frame_bgr_u8_hwc)``.  Returns ``(ret, frame)`` where frame is a u8 RGB
+    [1,size,size,3] CUDA tensor (pass it to ``inference`` / ``model.forward_u8``)."""
+    ret, frame = cap.read()
+    if not ret or frame is None:
+        return ret, None
+    f = np.ascontiguousarray(np.asarray(frame))
+    if f.dtype != np.uint8 or f.ndim != 3 or f.shape[2] != 3:
+        raise ValueError("cap.read() must deliver a uint8 HxWx3 BGR frame")
+    return ret, ingest_frames(torch.from_numpy(f).unsqueeze(0).cuda(non_blocking=True), size, out)
+
+
 def inference(image, model: PoseProposalNet, outsize, local_grid_size, detection_thresh: float = 0.15,
               draw: Optional[Callable] = None):
     """rt_test.py:87-147 for one RGB frame (u8 [S,S,3] array / PIL image / tensor).
@@ -48,13 +81,20 @@ def inference(image, model: PoseProposalNet, outsize, local_grid_size, detection
     Returns ``(humans, scores)`` exactly as datatest.get_humans_by_feature does (lists of dicts
     keypoint -> [ymin,xmin,ymax,xmax] / keypoint -> delta), or ``draw(image, humans, scores)`` if given."""
     model.eval()
-    img = np.asarray(image)
-    if img.dtype != np.uint8 or img.ndim != 3 or img.shape[2] != 3:
-        raise ValueError("inference expects a uint8 HxWx3 RGB frame")
-    frames = torch.from_numpy(np.ascontiguousarray(img)).unsqueeze(0).cuda(non_blocking=True)
+    if isinstance(image, torch.Tensor) and image.is_cuda:             # what grab_frame() returns: already on the device
+        frames = image if image.dim() == 4 else image.unsqueeze(0)
+        if frames.dtype != torch.uint8 or frames.shape[0] != 1 or frames.shape[3] != 3:
+            raise ValueError("inference expects a uint8 [1,H,W,3] / [H,W,3] RGB frame")
+        hw = (frames.shape[1], frames.shape[2])
+    else:
+        img = np.asarray(image)
+        if img.dtype != np.uint8 or img.ndim != 3 or img.shape[2] != 3:
+            raise ValueError("inference expects a uint8 HxWx3 RGB frame")
+        frames = torch.from_numpy(np.ascontiguousarray(img)).unsqueeze(0).cuda(non_blocking=True)
+        hw = (img.shape[0], img.shape[1])
     head = model.forward_u8(frames)
     outW, outH = outsize
-    res = D.decode_heads(head, insize_hw=(img.shape[0], img.shape[1]), local_grid=local_grid_size,
+    res = D.decode_heads(head, insize_hw=hw, local_grid=local_grid_size,
                          detection_thresh=detection_thresh)
     humans, scores = res.to_humans()[0]
     if draw is not None:

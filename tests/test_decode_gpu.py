@@ -150,3 +150,37 @@ def test_nms_golden(golden_dir):
     bb = g["0/bbox"]
     sc = np.array([-0.5, 0.25, -0.1, 0.0, 0.9, -2.0, 0.3], np.float32)
     assert np.array_equal(dec.non_maximum_suppression(bb, 0.3, sc), D.nms_ref(bb, 0.3, sc))
+
+
+def test_device_decode_feeds_ap_evaluation():
+    """SURVEY 8f-3 / datatest.py:298-327 -> evaluation: the device DecodeResult (to_humans()) goes through
+    evaluate.evaluation unchanged.  Ground truth = the planted people (centres of the oracle-decoded boxes of every
+    second person, slightly shifted), so AP is neither 0 nor trivially 1; the 8 AP values must equal those obtained
+    from the oracle's decode of the same heads (and the evaluator itself is pinned to the reference by
+    tests/test_oracle.py::test_ap_evaluation_golden)."""
+    from pytorch_pose_proposal_network_amd import decode, evaluate
+    heads = np.stack([synth.planted_crowd_head(40 + i) for i in range(6)])
+    res = decode.decode_heads(torch.from_numpy(heads).cuda())
+    dev_people = res.to_humans()
+    obj_dev, obj_ref = [[] for _ in range(7)], [[] for _ in range(7)]
+    for i in range(len(heads)):
+        exp = D.decode_ref(heads[i])
+        ref_h, ref_s = D.humans_from_compact(exp)
+        gt_kps, gt_boxes, vis, sizes = [], [], [], []
+        for p in range(0, exp["n"], 2):
+            bb = exp["bbox"][p]                                            # [K,4] (ymin,xmin,ymax,xmax)
+            pts = np.stack([(bb[1:, 1] + bb[1:, 3]) / 2 + 1.5, (bb[1:, 0] + bb[1:, 2]) / 2 - 1.0], 1).astype(np.float32)
+            gt_kps.append(pts)
+            cy, cx = (bb[0, 0] + bb[0, 2]) / 2, (bb[0, 1] + bb[0, 3]) / 2
+            gt_boxes.append((np.float32(cx), np.float32(cy), np.float32(bb[0, 3] - bb[0, 1]), np.float32(bb[0, 2] - bb[0, 0])))
+            vis.append(np.ones(17, bool))
+            sizes.append(np.float32(12.0))
+        for obj, (hm, sc) in ((obj_dev, dev_people[i]), (obj_ref, (ref_h, ref_s))):
+            obj[0].append(f"img_{i}.jpg")
+            obj[1].append(np.stack(gt_kps) if gt_kps else np.zeros((0, 17, 2), np.float32))
+            obj[2].append(hm); obj[3].append(sc); obj[4].append(gt_boxes); obj[5].append(vis); obj[6].append(sizes)
+    ap_dev = np.asarray(evaluate.evaluation(obj_dev), np.float64)
+    ap_ref = np.asarray(evaluate.evaluation(obj_ref), np.float64)
+    print("AP from the device decode:", np.round(ap_dev, 3).tolist())
+    assert np.array_equal(ap_dev, ap_ref, equal_nan=True)
+    assert np.isfinite(ap_dev[-1]) and 0.0 < ap_dev[-1] <= 100.0

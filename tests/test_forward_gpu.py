@@ -180,3 +180,33 @@ def test_fused_stem_variant(golden_dir, dtype):
         assert np.abs(m(x).cpu().numpy() - g["head"]).max() <= F32_TOL
     else:
         assert d.max() <= BF16_MAX_TOL and d.mean() <= BF16_MEAN_TOL
+
+
+def test_train_eval_toggle_on_the_same_object(golden_dir):
+    """main.py:643 / rt_test.py:65-66,94: `model.train()` and `model.eval()` switch ONE object.  Train mode: batch
+    statistics, running statistics advance (momentum 0.1); back in eval mode the folded-BN plan uses the advanced
+    statistics.  Both heads vs the CPU oracle (forward_ref with train_bn / with the new state_dict), 1e-4."""
+    from oracle import forward_ref as Fr
+    g = np.load(os.path.join(golden_dir, "forward_d22_96.npz"))
+    m = _model("drn_d_22", g, "float32")
+    sd0 = {k: (v.numpy().copy() if hasattr(v, "numpy") else np.array(v)) for k, v in m.state_dict().items()}
+    x = synth.normalized_frames(_frames(g))
+    xd = torch.from_numpy(x).cuda()
+    head_eval0 = m(xd).clone()
+    assert m.train() is m and m.training and m.trainer is not None
+    head_train = m(xd)
+    sd_ref = {k: v.copy() for k, v in sd0.items()}
+    ref_train = Fr.forward_ref(sd_ref, torch.from_numpy(x), "drn_d_22", train_bn=True, momentum=0.1).numpy()
+    assert np.abs(head_train.cpu().numpy() - ref_train).max() <= F32_TOL
+    with pytest.raises(RuntimeError):
+        m.forward_u8(torch.from_numpy(_frames(g)).cuda())
+    assert m.eval() is m and not m.training
+    sd1 = m.state_dict()
+    for k in sd_ref:                                   # forward_ref advanced sd_ref's running statistics in place
+        if k.endswith(("running_mean", "running_var")):
+            assert np.allclose(np.asarray(sd1[k]), sd_ref[k], rtol=2e-4, atol=2e-5), k
+    assert not np.allclose(np.asarray(sd1["bn2.running_mean"]), sd0["bn2.running_mean"])
+    head_eval1 = m(xd)
+    ref_eval1 = Fr.forward_ref(sd_ref, torch.from_numpy(x), "drn_d_22").numpy()
+    assert np.abs(head_eval1.cpu().numpy() - ref_eval1).max() <= F32_TOL
+    assert not torch.equal(head_eval1, head_eval0)

@@ -259,3 +259,27 @@ def test_target_encoder_oracle_equals_reference_fixture(golden_dir):
             assert np.array_equal(mine[k], g[f"case{i}/{k}"]), (i, k)
     # the edge cases are really in there: a negative offset (keypoint left of the frame, int() truncation)
     assert float(g["case3/tx"].min()) < 0 and float(g["case3/ty"].min()) < 0
+
+
+def test_ingest_oracle_properties():
+    """oracle/ingest_ref.py (rt_test.py:150-157; parity unpinned -- cv2 is absent): identity size is a pure 180-degree
+    rotation + channel swap; any resize stays within 1 LSB of real-valued bilinear interpolation with OpenCV's
+    half-pixel centres; exact halving is the 2x2 box mean."""
+    from oracle import ingest_ref as I
+    frame = prng.u8_frames(9, 1, (384, 384))[0]
+    assert np.array_equal(I.grab_frame_ref(frame), frame[::-1, ::-1, ::-1])
+    for (hs, ws) in ((480, 640), (720, 1280), (150, 200), (385, 383)):
+        src = prng.u8_frames(10 + hs, 1, (hs, ws))[0]
+        got = I.resize_linear_u8(src, (384, 384)).astype(np.float64)
+        fy = np.clip((np.arange(384) + 0.5) * hs / 384 - 0.5, 0, hs - 1)
+        fx = np.clip((np.arange(384) + 0.5) * ws / 384 - 0.5, 0, ws - 1)
+        y0, x0 = np.floor(fy).astype(int), np.floor(fx).astype(int)
+        y1, x1 = np.minimum(y0 + 1, hs - 1), np.minimum(x0 + 1, ws - 1)
+        wy, wx = (fy - y0)[:, None, None], (fx - x0)[None, :, None]
+        s = src.astype(np.float64)
+        ref = (s[y0][:, x0] * (1 - wy) * (1 - wx) + s[y0][:, x1] * (1 - wy) * wx + s[y1][:, x0] * wy * (1 - wx) +
+               s[y1][:, x1] * wy * wx)
+        assert np.abs(got - ref).max() <= 1.0, (hs, ws, np.abs(got - ref).max())
+    src = prng.u8_frames(12, 1, (768, 768))[0].astype(np.int64)
+    box = (src[0::2, 0::2] + src[0::2, 1::2] + src[1::2, 0::2] + src[1::2, 1::2] + 2) >> 2
+    assert np.array_equal(I.resize_linear_u8(src.astype(np.uint8), (384, 384)), box.astype(np.uint8))
