@@ -12,6 +12,10 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the CPU oracles run on torch-CPU: a 1-GPU box owns a 16-core share of a much larger host, and torch's default
+    # (one thread per host core) oversubscribes it badly
+    import torch
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
 
 
 @pytest.fixture(scope="session")
