@@ -272,6 +272,19 @@ int ppn_plan_add_stem(ppn_plan* p, int32_t dtype, int32_t src_is_u8, const void*
 int ppn_plan_add_stem01(ppn_plan* p, int32_t dtype, int32_t src_is_u8, const void* src, int32_t batch, int32_t h,
                         int32_t w, const float* w0, const float* scale0, const float* shift0, const float* mean,
                         const float* std_, const float* w1, const float* scale1, const float* shift1, void* out);
+/* The whole stem in one launch, bf16 mode (csrc/stem012.hip): layer0 7x7 3->16, layer1 3x3 16->16, layer2 3x3 stride 2
+ * 16->32, each + folded BN + ReLU (drn.py:123-133), input normalisation fused; out_raw = layer2's output, out_act =
+ * relu(out_raw * scale3 + shift3), the pre-activation of the first BasicBlock (either may be NULL).  Outputs NHWC bf16
+ * [B, (H+1)/2, (W+1)/2, 32].  Weights f32 in the reference layout; bit-identical to running ppn_stem7x7 +
+ * two ppn_conv2d_fused launches in bf16 mode. */
+int ppn_stem012(int32_t src_is_u8, const void* src, int32_t batch, int32_t h, int32_t w, const float* w0,
+                const float* scale0, const float* shift0, const float* mean, const float* std_, const float* w1,
+                const float* scale1, const float* shift1, const float* w2, const float* scale2, const float* shift2,
+                const float* scale3, const float* shift3, void* out_raw, void* out_act, void* stream);
+int ppn_plan_add_stem012(ppn_plan* p, int32_t src_is_u8, const void* src, int32_t batch, int32_t h, int32_t w,
+                         const float* w0, const float* scale0, const float* shift0, const float* mean, const float* std_,
+                         const float* w1, const float* scale1, const float* shift1, const float* w2, const float* scale2,
+                         const float* shift2, const float* scale3, const float* shift3, void* out_raw, void* out_act);
 /* Re-point the first layer's input (same shape/dtype as at ppn_plan_add_stem) before a run. */
 int ppn_plan_set_input(ppn_plan* p, const void* src);
 /* Issue every launch of the plan on `stream`.  After two launch-by-launch runs the sequence is captured into a

@@ -42,9 +42,10 @@ def _bf16(t):
     return t.to(torch.bfloat16).float()
 
 
-def fused_forward_ref(sd, x: torch.Tensor, arch: str = "drn_d_22", emulate_bf16: bool = False, taps=None):
+def fused_forward_ref(sd, x: torch.Tensor, arch: str = "drn_d_22", emulate_bf16: bool = False, taps=None,
+                      fuse_stem=False):
     """x f32 [B,3,H,W] (normalised) -> head f32 [B,C,H/16,W/16], walking the fused program."""
-    ops = A.build_program(arch)
+    ops = A.build_program(arch, fuse_stem=fuse_stem)
     q = _bf16 if emulate_bf16 else (lambda t: t)
     tensors = {"input": x.float()}
     with torch.no_grad():
@@ -80,6 +81,11 @@ def fused_forward_ref(sd, x: torch.Tensor, arch: str = "drn_d_22", emulate_bf16:
                 s2n, b2n = _fold(sd, n.bn1)
                 acc2 = F.conv2d(q(v), q(_t(sd[n.weight]).float()), None, n.stride, n.pad, n.dilation)
                 v = _ACT[n.act1](acc2 * s2n.float().view(1, -1, 1, 1) + b2n.float().view(1, -1, 1, 1))
+                if op.next_s2 is not None:           # ... and layer2 as well (csrc/stem012.hip)
+                    m = op.next_s2
+                    s3n, b3n = _fold(sd, m.bn1)
+                    acc3 = F.conv2d(q(v), q(_t(sd[m.weight]).float()), None, m.stride, m.pad, m.dilation)
+                    v = _ACT[m.act1](acc3 * s3n.float().view(1, -1, 1, 1) + b3n.float().view(1, -1, 1, 1))
             if op.residual:
                 v = v + tensors[op.residual]
             if op.out_raw:

@@ -62,6 +62,7 @@ class ConvOp:
     out_act: Optional[str] = None     # store act2(bn2(v))
     nchw_f32_out: bool = False        # head: sigmoid output in the reference's NCHW f32 layout
     next3x3: Optional["ConvOp"] = None  # layer0 only: layer1 (3x3 16->16 conv+BN+ReLU) fused into the same launch
+    next_s2: Optional["ConvOp"] = None  # layer0 only, with next3x3: layer2 (3x3 stride 2 16->32) fused too (stem012.hip)
     # fused projection shortcut: out = conv(src) + bn_ds(conv1x1_stride(ds_src))  (BasicBlock.downsample, drn.py:53-54)
     ds_src: Optional[str] = None
     ds_weight: Optional[str] = None
@@ -171,13 +172,14 @@ def _needs(u: Optional[Unit]):
         return True, ("bn0_1", ACT_LRELU)                # R is re-added at model.py:127
     return True, None                                    # cbr / bottleneck read raw x
 
-def build_program(arch: str = "drn_d_22", head_channels: Optional[int] = None, fuse_stem: bool = False,
+def build_program(arch: str = "drn_d_22", head_channels: Optional[int] = None, fuse_stem=False,
                   fuse_shortcut: bool = True) -> List[ConvOp]:
     """Lower the module list into fused conv launches.
 
-    fuse_stem: layer0 (7x7) and the first conv of layer1 (3x3 16->16) share one launch (csrc/stem01.hip): the
-    16x384x384 tensor between them never goes to HBM.  Off by default: measured on MI355X the fused kernel is
-    instruction-bound (235 us vs 83 + 133 us for the two separate launches at batch 32), see DESIGN.md."""
+    fuse_stem: True -- layer0 (7x7) and the first conv of layer1 (3x3 16->16) share one launch (csrc/stem01.hip):
+    the 16x384x384 tensor between them never goes to HBM (measured slower than the two launches, kept as an option).
+    "all" -- layer0, layer1 and layer2 (3x3 stride 2 16->32) in one launch (csrc/stem012.hip, bf16 mode): neither
+    16-channel full-resolution tensor goes to HBM; needs one conv per stem layer (every DRN-D variant has that)."""
     # fuse_shortcut: a BasicBlock's 1x1 projection shortcut (+BN) becomes extra GEMM depth of its second conv
     # (no separate launch, no residual tensor) when its input width is a multiple of 64 and the block is narrow.
     hc = head_channels or cfg.lastsize()
@@ -217,6 +219,16 @@ def build_program(arch: str = "drn_d_22", head_channels: Optional[int] = None, f
                 first.next3x3 = op
                 first.name = first.name + "+" + op.name
                 first.out_raw = None
+                op.src = "(on chip)"
+                finish(first, w.replace(".", "_"))
+                continue
+            if (fuse_stem == "all" and i == 2 and len(ops) == 1 and ops[-1].next3x3 is not None and
+                    ops[-1].next_s2 is None and u.cin == 16 and u.cout == 32 and u.k == 3 and u.stride == 2 and d == 1):
+                first = ops.pop()                      # layer0+layer1: their only consumer is this conv
+                first.next_s2 = op
+                first.name = first.name + "+" + op.name
+                first.out_raw = first.out_act = None
+                first.bn2, first.act2 = None, ACT_NONE
                 op.src = "(on chip)"
                 finish(first, w.replace(".", "_"))
                 continue
@@ -293,6 +305,9 @@ def tensor_shapes(ops: List[ConvOp], h: int, w: int) -> Dict[str, Tuple[int, int
         assert ic == op.cin, (op.name, ic, op.cin)
         oh, ow = out_hw(op, ih, iw)
         cout = op.next3x3.cout if op.next3x3 else op.cout
+        if op.next_s2:
+            oh, ow = out_hw(op.next_s2, oh, ow)
+            cout = op.next_s2.cout
         for name in (op.out_raw, op.out_act):
             if name:
                 shapes[name] = (oh, ow, cout)
@@ -311,7 +326,14 @@ def conv_flops(ops: List[ConvOp], h: int, w: int) -> int:
 def op_flops(op: ConvOp, shapes) -> int:
     """2*MACs of one launch for one image (a fused layer0+layer1 launch counts both convolutions)."""
     oh, ow, _ = shapes[op.out_raw or op.out_act]
-    fl = 2 * op.cin * op.cout * op.k * op.k * oh * ow
+    if op.next_s2:                                   # layer0 and layer1 run at the input resolution
+        m = op.next_s2
+        fl2 = 2 * m.cin * m.cout * m.k * m.k * oh * ow
+        ih, iw, _ = shapes[op.src]
+        oh, ow = out_hw(op, ih, iw)
+    else:
+        fl2 = 0
+    fl = 2 * op.cin * op.cout * op.k * op.k * oh * ow + fl2
     if op.ds_src:
         fl += 2 * op.ds_cin * op.cout * oh * ow
     if op.next3x3:

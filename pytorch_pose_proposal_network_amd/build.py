@@ -24,6 +24,7 @@ SOURCES = [
     ("stem.hip", []),
     ("stem3x3.hip", []),
     ("stem01.hip", []),
+    ("stem012.hip", []),
     ("plan.hip", []),
     ("loss.hip", []),
     ("train.hip", []),

@@ -36,15 +36,6 @@ using namespace ppnconv;
 #ifndef PPN_DIAG
 #define PPN_DIAG 0
 #endif
-// K-loop experiments (A/B with tools/ab_conv_inproc.py):
-//   PPN_DMA_SPLIT  1 = the younger half of the workgroup issues its LDS-DMA behind the last MFMA groups of a step
-//   PPN_PRIO_YOUNG 1 = s_setprio 1 for waves NW/2.. before the K loop (static priority, MI355X_MICROARCH item 4)
-#ifndef PPN_DMA_SPLIT
-#define PPN_DMA_SPLIT 0
-#endif
-#ifndef PPN_PRIO_YOUNG
-#define PPN_PRIO_YOUNG 0
-#endif
 constexpr unsigned kOOB = 0x80000000u;   // byte offset beyond any tensor this kernel accepts (< 2 GiB)
 
 template <typename F, int... I>
@@ -321,44 +312,26 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
     // in-kernel clock: shader cycles (s_memtime) over the 100 MHz constant clock (s_memrealtime) around the K loop
     const unsigned long long ck0 = __builtin_amdgcn_s_memtime(), rk0 = __builtin_amdgcn_s_memrealtime();
 #endif
-#if PPN_PRIO_YOUNG
-    if (NW == 8 && wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
-#endif
     for (int s = 1; s < nsteps; ++s) {
         const int buf = s & 1;
 #ifdef PPN_STAMP
         PPN_T(tq0);
 #endif
-        // The two waves of a SIMD (w and w + NW/2) run the same barrier-paced program; when both reach their LDS-DMA
-        // issues together, both stall at issue together and the SIMD's matrix pipe idles.  The older half issues
-        // its DMA behind the FIRST MFMA groups of the step, the younger half behind the LAST ones (same instructions,
-        // same order of MFMAs: results unchanged), so one partner is in plain MFMAs while the other issues.
-        auto first_half = [&](auto late_c) {
-            constexpr bool late = decltype(late_c)::value;
-            constexpr int G0 = late ? NG - (NL + LPG - 1) / LPG : 0;
-            static_for<NG>([&](auto gc) {
-                constexpr int g = decltype(gc)::value;
-                mma_group(gc, wB, xB);
+        static_for<NG>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            mma_group(gc, wB, xB);
 #if PPN_DIAG != 2 && PPN_DIAG != 4 && PPN_DIAG != 5 && PPN_DIAG != 6
-                if constexpr (g >= G0)
-                    static_for<LPG>([&](auto lc) {
-                        constexpr int l = (g - G0) * LPG + decltype(lc)::value;
-                        if constexpr (l < NL) issue_one(std::integral_constant<int, l>{}, buf ^ 1);
-                    });
-#endif
-                static_for<RPG>([&](auto rc) {
-                    constexpr int r = g * RPG + decltype(rc)::value;
-                    if constexpr (r < NRD) read_one(std::integral_constant<int, r>{}, wA, xA, buf, 0);
-                });
-                __builtin_amdgcn_sched_barrier(0);
+            static_for<LPG>([&](auto lc) {
+                constexpr int l = g * LPG + decltype(lc)::value;
+                if constexpr (l < NL) issue_one(std::integral_constant<int, l>{}, buf ^ 1);
             });
-        };
-#if PPN_DMA_SPLIT
-        if (NW == 8 && wave >= NW / 2) first_half(std::true_type{});
-        else first_half(std::false_type{});
-#else
-        first_half(std::false_type{});
 #endif
+            static_for<RPG>([&](auto rc) {
+                constexpr int r = g * RPG + decltype(rc)::value;
+                if constexpr (r < NRD) read_one(std::integral_constant<int, r>{}, wA, xA, buf, 0);
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        });
         advance();
 #ifdef PPN_STAMP
         PPN_T(tq1); st_b1 += tq1 - tq0;

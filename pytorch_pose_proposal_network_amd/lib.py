@@ -93,6 +93,10 @@ _SIGNATURES = {
                    [C.POINTER(C.c_float)] * 2 + [C.c_void_p] * 5),
     "ppn_plan_add_stem01": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32] +
                             [C.c_void_p] * 3 + [C.POINTER(C.c_float)] * 2 + [C.c_void_p] * 4),
+    "ppn_stem012": (C.c_int, [C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 3 +
+                    [C.POINTER(C.c_float)] * 2 + [C.c_void_p] * 11),
+    "ppn_plan_add_stem012": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32] +
+                             [C.c_void_p] * 3 + [C.POINTER(C.c_float)] * 2 + [C.c_void_p] * 10),
     "ppn_plan_create": (C.c_int, [C.POINTER(C.c_void_p)]),
     "ppn_plan_add_conv": (C.c_int, [C.c_void_p, C.POINTER(ConvDesc)]),
     "ppn_plan_add_memset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),

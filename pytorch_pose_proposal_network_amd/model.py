@@ -61,7 +61,7 @@ class _Plan:
 class PoseProposalNet:
     def __init__(self, backbone="drn_d_22", insize=(384, 384), outsize=(24, 24),
                  keypoint_names=cfg.KEYPOINT_NAMES, local_grid_size=(21, 21), edges=cfg.EDGES,
-                 compute_dtype: str = "float32", fuse_stem: bool = False, fuse_shortcut: Optional[bool] = None):
+                 compute_dtype: str = "float32", fuse_stem=None, fuse_shortcut: Optional[bool] = None):
         self.arch = _arch_of(backbone)
         self.insize = insize
         self.outsize = outsize
@@ -77,6 +77,12 @@ class PoseProposalNet:
                               "bf16": L.PPN_BF16}[compute_dtype]
         self.training = False
         self.device = torch.device("cuda")
+        if fuse_stem is None:
+            # bf16 mode: the three stem layers share one launch (csrc/stem012.hip; PPN_FUSE_STEM=0 keeps them apart);
+            # the exact-f32 parity mode runs them layer by layer
+            fuse_stem = "all" if (self.compute_dtype == L.PPN_BF16 and os.environ.get("PPN_FUSE_STEM", "1") != "0") else False
+        if fuse_stem == "all" and self.compute_dtype != L.PPN_BF16:
+            raise ValueError("fuse_stem='all' (csrc/stem012.hip) is a bf16-mode kernel")
         if fuse_shortcut is None:                             # tuning knob: PPN_FUSE_SHORTCUT=0 keeps the 1x1 shortcuts apart
             fuse_shortcut = os.environ.get("PPN_FUSE_SHORTCUT", "1") != "0"
         self._ops: List[A.ConvOp] = A.build_program(self.arch, self.lastsize, fuse_stem=fuse_stem,
@@ -198,6 +204,12 @@ class PoseProposalNet:
                     self._dev[op.name + ".w1"] = self._sd[n.weight].float().contiguous().to(dev)
                     self._dev[op.name + ".s1b"] = sn.float().to(dev)
                     self._dev[op.name + ".b1b"] = bn_.float().to(dev)
+                if op.next_s2 is not None:                     # ... and layer2
+                    m = op.next_s2
+                    sm, bm = self._fold_bn(m.bn1)
+                    self._dev[op.name + ".w2"] = self._sd[m.weight].float().contiguous().to(dev)
+                    self._dev[op.name + ".s1c"] = sm.float().to(dev)
+                    self._dev[op.name + ".b1c"] = bm.float().to(dev)
                 continue
             kstep, _, korder, ktot, cpad = L.conv_tiling(self.compute_dtype, op.cin, op.cout, op.k)
             wd = w.to(dev)
@@ -254,6 +266,19 @@ class PoseProposalNet:
             ih, iw, _ = shapes[op.src]
             oh, ow = A.out_hw(op, ih, iw)
             entries.append((op.name, A.op_flops(op, shapes) * batch))
+            if op.k == 7 and op.next_s2 is not None:
+                assert op.src == "input" and self.compute_dtype == L.PPN_BF16
+                L.check(lib.ppn_plan_add_stem012(handle, 1 if src_is_u8 else 0, src.data_ptr(), batch, h, w,
+                                                 self._ptr(op.name + ".w"), self._ptr(op.name + ".s1"),
+                                                 self._ptr(op.name + ".b1"), self._mean, self._std,
+                                                 self._ptr(op.name + ".w1"), self._ptr(op.name + ".s1b"),
+                                                 self._ptr(op.name + ".b1b"), self._ptr(op.name + ".w2"),
+                                                 self._ptr(op.name + ".s1c"), self._ptr(op.name + ".b1c"),
+                                                 self._ptr(op.name + ".s2"), self._ptr(op.name + ".b2"),
+                                                 bufs[op.out_raw].data_ptr() if op.out_raw else None,
+                                                 bufs[op.out_act].data_ptr() if op.out_act else None),
+                        "ppn_plan_add_stem012")
+                continue
             if op.k == 7 and op.next3x3 is not None:
                 assert op.src == "input" and op.out_act is None
                 L.check(lib.ppn_plan_add_stem01(handle, self.compute_dtype, 1 if src_is_u8 else 0, src.data_ptr(),

@@ -291,3 +291,71 @@ def test_fused_projection_shortcut(dtype_name, case):
     tol = 2e-5 if dtype == L.PPN_F32 else 2e-2
     assert (raw.double() - y).abs().max() <= tol * max(1.0, y.abs().max().item())
     assert (act.double() - u).abs().max() <= tol * max(1.0, u.abs().max().item())
+
+
+@pytest.mark.parametrize("shape", [(2, 37, 70), (1, 96, 96), (3, 384, 384), (1, 33, 200)], ids=str)
+@pytest.mark.parametrize("u8", [True, False])
+def test_fused_stem_equals_layer_by_layer(shape, u8):
+    """csrc/stem012.hip (layer0 + layer1 + layer2 in one launch, bf16) == ppn_stem7x7 -> stem3x3<16,1> -> stem3x3<32,2>
+    BIT FOR BIT (same MFMA sequences, same bf16 rounding points), both outputs, for ragged sizes, several bands and
+    strips; and within bf16 tolerance of the fp64 reference of drn.py:123-133 + the first block's relu(bn1(x))."""
+    from pytorch_pose_proposal_network_amd import lib as L, prng
+    lib = L.load()
+    B, H, W = shape
+    dev = torch.device("cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    frames = torch.from_numpy(prng.u8_frames(17, B, (H, W)))
+    mean, std = torch.tensor([0.485, 0.456, 0.406]), torch.tensor([0.229, 0.224, 0.225])
+    xn = ((frames.permute(0, 3, 1, 2).float() - mean.view(1, 3, 1, 1)) / std.view(1, 3, 1, 1)).contiguous()
+    w0, w1, w2 = rnd(16, 3, 7, 7, seed=31, scale=0.002), rnd(16, 16, 3, 3, seed=32, scale=0.12), rnd(32, 16, 3, 3, seed=33, scale=0.12)
+    gen = torch.Generator().manual_seed(34)
+    s = [0.5 + torch.rand(n, generator=gen) for n in (16, 16, 32, 32)]
+    b = [rnd(n, seed=35 + i, scale=0.3) for i, n in enumerate((16, 16, 32, 32))]
+    d = lambda t: t.contiguous().to(dev)
+    src = d(frames) if u8 else d(xn)
+    w0d, w1d, w2d = d(w0), d(w1), d(w2)
+    sd_, bd = [d(t) for t in s], [d(t) for t in b]
+    m3, s3 = (C.c_float * 3)(0.485, 0.456, 0.406), (C.c_float * 3)(0.229, 0.224, 0.225)
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    nan = lambda *sh: torch.full(sh, float("nan"), device=dev).to(torch.bfloat16)
+    # ---- one launch ----
+    raw_f, act_f = nan(B, Ho, Wo, 32), nan(B, Ho, Wo, 32)
+    L.check(lib.ppn_stem012(int(u8), src.data_ptr(), B, H, W, w0d.data_ptr(), sd_[0].data_ptr(), bd[0].data_ptr(), m3, s3,
+                            w1d.data_ptr(), sd_[1].data_ptr(), bd[1].data_ptr(), w2d.data_ptr(), sd_[2].data_ptr(),
+                            bd[2].data_ptr(), sd_[3].data_ptr(), bd[3].data_ptr(), raw_f.data_ptr(), act_f.data_ptr(), st),
+            "ppn_stem012")
+    # ---- layer by layer ----
+    t0, t1 = nan(B, H, W, 16), nan(B, H, W, 16)
+    raw_s, act_s = nan(B, Ho, Wo, 32), nan(B, Ho, Wo, 32)
+    L.check(lib.ppn_stem7x7(L.PPN_BF16, int(u8), src.data_ptr(), B, H, W, w0d.data_ptr(), sd_[0].data_ptr(),
+                            bd[0].data_ptr(), m3, s3, t0.data_ptr(), st), "ppn_stem7x7")
+    zero = torch.zeros(64, device=dev)
+
+    def conv3(x, wd, cout, stride, s1, b1, s2, b2, out_raw, out_act):
+        dsc = L.ConvDesc()
+        dsc.dtype, dsc.batch, dsc.in_h, dsc.in_w, dsc.cin = L.PPN_BF16, B, H, W, 16
+        dsc.out_h, dsc.out_w, dsc.cout = out_raw.shape[1], out_raw.shape[2], cout
+        dsc.ksize, dsc.stride, dsc.dilation, dsc.pad = 3, stride, 1, 1
+        dsc.k_total, dsc.cout_pad, dsc.act1, dsc.act2 = 144, cout, 1, (1 if out_act is not None else 0)
+        dsc.src, dsc.weight, dsc.zero_page = x.data_ptr(), wd.data_ptr(), zero.data_ptr()
+        dsc.scale1, dsc.shift1, dsc.out_raw = s1.data_ptr(), b1.data_ptr(), out_raw.data_ptr()
+        if out_act is not None:
+            dsc.scale2, dsc.shift2, dsc.out_act = s2.data_ptr(), b2.data_ptr(), out_act.data_ptr()
+        L.check(lib.ppn_conv2d_fused(C.byref(dsc), st), "ppn_conv2d_fused")
+        assert lib.ppn_last_conv_kernel().decode().startswith("stem3x3_kernel")
+
+    conv3(t0, w1d, 16, 1, sd_[1], bd[1], None, None, t1, None)
+    conv3(t1, w2d, 32, 2, sd_[2], bd[2], sd_[3], bd[3], raw_s, act_s)
+    torch.cuda.synchronize()
+    assert not torch.isnan(raw_f.float()).any() and not torch.isnan(act_f.float()).any()
+    assert torch.equal(raw_f, raw_s), float((raw_f.float() - raw_s.float()).abs().max())
+    assert torch.equal(act_f, act_s)
+    # ---- fp64 reference (bf16 tolerance) ----
+    v = lambda t: t.double().view(1, -1, 1, 1)
+    y = F.relu(F.conv2d(xn.double(), w0.double(), None, 1, 3) * v(s[0]) + v(b[0]))
+    y = F.relu(F.conv2d(y, w1.double(), None, 1, 1) * v(s[1]) + v(b[1]))
+    y = F.relu(F.conv2d(y, w2.double(), None, 2, 1) * v(s[2]) + v(b[2]))
+    u = F.relu(y * v(s[3]) + v(b[3]))
+    got_y, got_u = raw_f.float().cpu().permute(0, 3, 1, 2).double(), act_f.float().cpu().permute(0, 3, 1, 2).double()
+    assert float((got_y - y).abs().max()) <= 4e-2 * max(1.0, float(y.abs().max()))
+    assert float((got_u - u).abs().max()) <= 4e-2 * max(1.0, float(u.abs().max()))
