@@ -578,21 +578,25 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
         const bool vec = (a.HoWo & 3) == 0;
         auto chunk = [&](auto qc) {
             constexpr int q = decltype(qc)::value;
+            // The chunk goes to LDS as LOGITS t = acc * scale1 + shift1 (the affine is applied by the lane that holds the
+            // accumulator: 4 consecutive channels, two 16-byte loads of constants), so both consumers below read one
+            // value per element.
 #pragma unroll
-            for (int ii = 0; ii < IC; ++ii)
+            for (int ii = 0; ii < IC; ++ii) {
+                const int chl = (wc * IC + ii) * 16 + 4 * fq;            // row of this lane's first channel in the chunk
+                const int c = c0 + wc * (BC / 2) + (q * IC + ii) * 16 + 4 * fq;
+                float sc[4], sh[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    sc[r] = (a.scale1 && c + r < a.Cout) ? a.scale1[c + r] : 1.f;
+                    sh[r] = (a.shift1 && c + r < a.Cout) ? a.shift1[c + r] : 0.f;
+                }
 #pragma unroll
                 for (int j = 0; j < TP; ++j) {
                     const int px = wp * (BP / WP) + j * 16 + frow;
-                    const int ch = (wc * IC + ii) * 16 + 4 * fq;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) ct[(ch + r) * LD + px] = acc[q * IC + ii][j][r];
+                    for (int r = 0; r < 4; ++r) ct[(chl + r) * LD + px] = acc[q * IC + ii][j][r] * sc[r] + sh[r];
                 }
-            float* ct_affine = ct + 2 * IC * 16 * LD;                // [scale x 64][shift x 64] of this chunk's channels
-            if (a.amax_keys && tid < 2 * IC * 16) {
-                const int cw = tid / (IC * 16), r = tid % (IC * 16);
-                const int c = c0 + cw * (BC / 2) + q * IC * 16 + r;
-                ct_affine[tid] = (a.scale1 && c < a.Cout) ? a.scale1[c] : 1.f;
-                ct_affine[2 * IC * 16 + tid] = (a.shift1 && c < a.Cout) ? a.shift1[c] : 0.f;
             }
             lds_barrier();
             if (a.amax_keys) {
@@ -602,6 +606,17 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
                 // outputs are >= 0 so the bit pattern is monotonic; ~s makes the LOWEST window index win ties,
                 // np.argmax semantics of datatest.py:113).  A 32-channel run crosses at most one edge boundary
                 // (window >= 32), so it is processed as two branch-free segments.
+                //
+                // The key must hold max_k sigmoid(t_k) with the FIRST k that reaches it -- exactly what decoding the
+                // materialised head gives -- but evaluating 32 sigmoids per run (v_exp + v_rcp each) made this
+                // epilogue 40 % of the head conv.  The sigmoid is monotone up to its rounding, so the winner is the
+                // first maximum of the LOGITS unless another logit is so close to the maximum that both sigmoids may
+                // round to the same float (or swap by an ulp of the approximations).  One pass over the logits finds
+                // the maximum m, its first index and the runner-up m2; the preimage of one float of sigmoid around m
+                // is 2^-23 (1 + e^m) wide, and with a factor 8 for the <= 3 ulp of v_exp/v_rcp error the segment is
+                // decided by its logits alone when m2 < m - 2^-20 (1 + e^m): ONE sigmoid.  Otherwise (saturated
+                // heads: every logit above ~16.6 gives 1.0f, the lowest index must win) the lane falls back to the
+                // sigmoid of every element, as before.
                 constexpr int RUN = IC * 16;
                 const int nedges = (a.Cout - a.unary_ch) / a.window;
                 for (int item = tid; item < 2 * BP; item += NT) {
@@ -611,26 +626,37 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
                     const int nb = fast_div(m, a.div_howo), np = m - nb * a.HoWo;
                     const int cb = c0 + cw * (BC / 2) + q * RUN;     // first channel of this run
                     const float* row = ct + (cw * RUN) * LD + px;
-                    const float* aff = ct_affine + cw * RUN;
-                    auto value = [&](int r) { return sigmoid_fast(row[r * LD] * aff[r] + aff[2 * RUN + r]); };
                     int r = 0;
                     // unary part of the run (only the first channel tile of the layer has one)
                     for (; r < RUN && cb + r < a.unary_ch; ++r)
-                        a.unary_out[((size_t)nb * a.unary_ch + cb + r) * a.HoWo + np] = value(r);
+                        a.unary_out[((size_t)nb * a.unary_ch + cb + r) * a.HoWo + np] = sigmoid_fast(row[r * LD]);
                     const int rend = min(RUN, a.Cout - cb);           // padded channels past Cout do not compete
                     if (r < rend) {
                         const int l0 = cb + r - a.unary_ch;           // limb channel index of element r
                         int e = l0 / a.window, sidx = l0 - e * a.window;
                         while (r < rend) {
                             const int seg = min(rend - r, a.window - sidx);   // elements left in this edge's window
-                            float best = -1.f;
-                            int best_k = 0;
+                            float tm = -3.0e38f, tm2 = -3.0e38f;
+                            int km = 0;
 #pragma unroll 8
                             for (int k = 0; k < seg; ++k) {
-                                const float v = value(r + k);
-                                const bool gt = v > best;              // strict: first maximum of the segment
-                                best = gt ? v : best;
-                                best_k = gt ? k : best_k;
+                                const float t = row[(r + k) * LD];
+                                tm2 = fmaxf(tm2, fminf(tm, t));       // runner-up (equal maxima count: tm2 == tm)
+                                const bool gt = t > tm;                // strict: first maximum of the segment
+                                tm = gt ? t : tm;
+                                km = gt ? k : km;
+                            }
+                            float best = sigmoid_fast(tm);
+                            int best_k = km;
+                            if (!(tm2 < tm - 9.5367431640625e-7f * (1.0f + __expf(tm)))) {
+                                best = -1.f;
+                                best_k = 0;
+                                for (int k = 0; k < seg; ++k) {       // ambiguous: the sigmoid values themselves decide
+                                    const float v = sigmoid_fast(row[(r + k) * LD]);
+                                    const bool gt = v > best;
+                                    best = gt ? v : best;
+                                    best_k = gt ? k : best_k;
+                                }
                             }
                             if (e < nedges) {
                                 const unsigned long long key = ((unsigned long long)__float_as_uint(best) << 32) |
@@ -649,11 +675,10 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
                 const int c = c0 + cw * (BC / 2) + (q * IC + ci) * 16 + cr;
                 const int m = m0 + 4 * pq;
                 if (c < a.Cout && m < a.M) {
-                    const float s1 = a.scale1 ? a.scale1[c] : 1.f, b1 = a.shift1 ? a.shift1[c] : 0.f;
                     const f32x4 t4 = *reinterpret_cast<const f32x4*>(ct + chl * LD + 4 * pq);
                     float v[4] = {t4.x, t4.y, t4.z, t4.w};
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] = apply_act(v[i] * s1 + b1, a.act1);
+                    for (int i = 0; i < 4; ++i) v[i] = apply_act(v[i], a.act1);
                     if (vec) {
                         const int nb = fast_div(m, a.div_howo), np = m - nb * a.HoWo;
                         *reinterpret_cast<float4*>(out + ((size_t)nb * a.Cout + c) * a.HoWo + np) =

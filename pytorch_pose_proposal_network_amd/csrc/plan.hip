@@ -54,10 +54,29 @@ static const void* plan_src(const ppn_plan* p) {
     return nullptr;
 }
 
+// Zero fill as a kernel, not hipMemsetAsync: inside a captured hipGraph the memset NODE was observed to run out of order
+// with respect to the kernel nodes around it (the arg-max keys were cleared after the head conv had written them --
+// wrong people lists on replay, bench.py's `verified` check), a kernel node keeps its place in the chain.
+__global__ void __launch_bounds__(256) zero_fill_kernel(uint4* p, size_t n16, unsigned char* tail, int ntail) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) p[i] = make_uint4(0, 0, 0, 0);
+    if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = 0;
+}
+
 static int run_op(ppn_plan::Op& op, hipStream_t st) {
     if (op.kind == 2) {
-        if (op.kname.empty()) op.kname = "hipMemsetAsync";
-        PPN_HIP_CHECK(hipMemsetAsync(op.ms_ptr, 0, op.ms_bytes, st));
+        if (op.kname.empty()) op.kname = "zero_fill_kernel";
+        if ((reinterpret_cast<size_t>(op.ms_ptr) & 15) != 0) {
+            PPN_HIP_CHECK(hipMemsetAsync(op.ms_ptr, 0, op.ms_bytes, st));
+            return PPN_OK;
+        }
+        const size_t n16 = op.ms_bytes / 16;
+        const int ntail = (int)(op.ms_bytes - n16 * 16);
+        const size_t want = (n16 + 255) / 256;
+        const unsigned blocks = (unsigned)(want < 1 ? 1 : (want > 1024 ? 1024 : want));
+        hipLaunchKernelGGL(zero_fill_kernel, dim3(blocks), dim3(256), 0, st, static_cast<uint4*>(op.ms_ptr), n16,
+                           static_cast<unsigned char*>(op.ms_ptr) + n16 * 16, ntail);
+        PPN_LAUNCH_CHECK();
         return PPN_OK;
     }
     if (op.kind == 0) {

@@ -304,3 +304,51 @@ def test_full_size_head_conv3_argmax(dtype_name):
     info2 = {}
     run_conv(x, w, dtype, b1=bias, act1=3, nchw=True, argmax=(uch, win), want_raw=False, info=info2)
     assert torch.equal(info2["keys"], info["keys"]) and torch.equal(info2["unary"], info["unary"])
+
+
+@pytest.mark.parametrize("dtype_name", ["f32", "bf16"])
+@pytest.mark.parametrize("mode", ["saturated", "near_ties", "equal_logits"])
+def test_head_argmax_ambiguous_segments(force_tile, mode, dtype_name):
+    """The arg-max epilogue decides a window from its LOGITS when the runner-up is clearly below the maximum and falls
+    back to comparing the sigmoid values otherwise.  Force the fallback: (a) saturated heads -- many logits above 16.6
+    all give sigmoid == 1.0f and the LOWEST index must win (np.argmax, /root/reference/datatest.py:113); (b) logits a few
+    ulps apart whose sigmoids may round to one float; (c) exactly equal logits (duplicated weight rows).  In every
+    case keys == first maximum of the materialised head of the same launch, and keys-only == keys."""
+    dtype = _dt(dtype_name)
+    force_tile(192, 128)
+    uch, win, E = 108, 441, 3
+    Cout = uch + E * win
+    B, H, W = 2, 12, 16
+    x = q(rnd(B, 512, H, W, seed=101), dtype)
+    w = q(rnd(Cout, 512, 1, 1, seed=102, scale=0.06), dtype)
+    bias = rnd(Cout, seed=103, scale=0.1)
+    if mode == "saturated":
+        bias = bias + 30.0                                    # every logit far above 16.6: sigmoid == 1.0f everywhere
+        bias[uch + 5] -= 60.0                                 # ... except a few channels
+        bias[uch + win + 100: uch + win + 140] -= 25.0
+    elif mode == "near_ties":
+        w = w.clone()
+        w[uch + 7::50] = w[uch + 3]                           # same weights ...
+        bias[uch + 7::50] = bias[uch + 3] + 3e-7              # ... and a bias a few ulps above: logits a few ulps apart
+        bias[uch + 3] += 4.0                                  # make them the window's maxima
+        bias[uch + 7::50] += 4.0
+    else:
+        w = w.clone()
+        w[uch + 9], w[uch + 200], w[uch + 440] = w[uch + 2], w[uch + 2], w[uch + 2]
+        for c in (uch + 9, uch + 200, uch + 440):
+            bias[c] = bias[uch + 2]
+        for c in (uch + 2, uch + 9, uch + 200, uch + 440):
+            bias[c] += 5.0
+    info = {}
+    raw, _ = run_conv(x, w, dtype, b1=bias, act1=3, nchw=True, argmax=(uch, win), info=info)
+    ref, _ = ref_conv(x, w, b1=bias, act1=3)
+    assert float((raw - ref).abs().max()) <= (2e-6 if dtype_name == "f32" else 5e-3)
+    _check_keys(info, raw, uch, win)
+    limbs = raw.numpy()[:, uch:].reshape(B, E, win, H, W)
+    ties = (limbs == limbs.max(axis=2, keepdims=True)).sum(axis=2)
+    print(mode, dtype_name, "windows with a tied maximum:", int((ties > 1).sum()), "of", ties.size)
+    if mode != "near_ties":
+        assert int((ties > 1).sum()) > 0                      # the case really exercises the tie rule
+    info2 = {}
+    run_conv(x, w, dtype, b1=bias, act1=3, nchw=True, argmax=(uch, win), want_raw=False, info=info2)
+    assert torch.equal(info2["keys"], info["keys"]) and torch.equal(info2["unary"], info["unary"])
