@@ -32,7 +32,7 @@ using namespace ppnconv;
 // Build-time diagnostics (tools/build_variant.py NAME conv_big.hip -DPPN_DIAG=n): TIMING ONLY, results are wrong.
 //   1 = no wait for the DMA, 2 = no DMA in the K loop, 3 = 32x32x16 MFMAs (half the MFMA issue slots) on the same reads,
 //   4 = 2 and 3 together, 5 = 2 without the per-step barrier, 6 = 2 without the LDS fragment reads,
-//   7 = no global stores in the NHWC epilogue
+//   7 = no global stores in the NHWC epilogue, 8 = no arg-max pass in the head epilogue
 #ifndef PPN_DIAG
 #define PPN_DIAG 0
 #endif
@@ -599,7 +599,11 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
                 }
             }
             lds_barrier();
+#if PPN_DIAG == 8
+            if (a.amax_keys && a.M < 0) {
+#else
             if (a.amax_keys) {
+#endif
                 // Fused decode front end: one thread per (pixel, 32-channel run).  Channels < unary_ch (resp, conf,
                 // x, y, w, h) go to the compact tensor; every limb channel competes in its (image, edge, cell)
                 // arg-max through one 64-bit atomicMax per run and edge:  key = value bits << 32 | ~s  (sigmoid

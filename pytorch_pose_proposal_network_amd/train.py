@@ -136,6 +136,7 @@ class FlatAdam:
         n = self.param.numel()
         _f32(grad, n, "grad")
         self.step_count += 1
+        bump_param_version()                          # packed copies of the old parameters are stale
         lp = self.param_lp.data_ptr() if self.param_lp is not None else None
         L.check(L.load().ppn_adam_step(self.param.data_ptr(), grad.data_ptr(), self.exp_avg.data_ptr(),
                                        self.exp_avg_sq.data_ptr(), n, self.lr, self.betas[0], self.betas[1],
@@ -233,9 +234,20 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, stride: int = 1, dilation: int
     Ho, Wo = (H + 2 * pad - eff) // stride + 1, (W + 2 * pad - eff) // stride + 1
     kstep, _, korder, ktot, cpad = L.conv_tiling(dt, cin, cout, k)
     st = L.current_stream_ptr()
-    packed = torch.empty(cpad, ktot, dtype=torch.float32 if korder == 2 else x.dtype, device=x.device)
-    pack = lib.ppn_pack_weight_dgrad if dgrad_of else lib.ppn_pack_weight
-    L.check(pack(dt, w.data_ptr(), cout, cin, k, cpad, ktot, korder, kstep, packed.data_ptr(), st), "ppn_pack_weight")
+    # A parameter is packed once per optimiser step and layout (forward / input-gradient): the probe passes and the
+    # second-order tail run the same convolutions several times per iteration.  Keyed on the weight's storage, the
+    # parameter version (bumped by FlatAdam.step / load_state_dict) and the stream the pack kernel was queued on.
+    key = (w.data_ptr(), tuple(w.shape), bool(dgrad_of), dt, st) if w._base is not None else None
+    packed = _pack_cache.get(key) if key is not None else None
+    if packed is None or packed[0] != _param_version[0]:
+        buf = packed[1] if packed is not None else torch.empty(cpad, ktot, dtype=torch.float32 if korder == 2 else x.dtype,
+                                                               device=x.device)
+        pack = lib.ppn_pack_weight_dgrad if dgrad_of else lib.ppn_pack_weight
+        L.check(pack(dt, w.data_ptr(), cout, cin, k, cpad, ktot, korder, kstep, buf.data_ptr(), st), "ppn_pack_weight")
+        if key is not None:
+            _pack_cache[key] = (_param_version[0], buf)
+        packed = (_param_version[0], buf)
+    packed = packed[1]
     if nchw_f32:                                  # the head tensor the loss / decode kernels read (model.py:134-136)
         out = torch.empty(B, cout, Ho, Wo, dtype=torch.float32, device=x.device)
     else:
@@ -258,6 +270,16 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, stride: int = 1, dilation: int
 
 
 _zero_pages = {}
+# packed-weight cache of conv2d_nhwc (see there).  Only views of a larger buffer (the trainer's flat parameter
+# buffer) are cached: a free-standing weight tensor may be modified in place by the caller between two calls.
+_pack_cache: dict = {}
+_param_version = [0]
+
+
+def bump_param_version():
+    """Parameters changed (optimiser step, load_state_dict): packed weights of older versions are stale."""
+    _param_version[0] += 1
+
 
 
 def _zero_page(device) -> torch.Tensor:

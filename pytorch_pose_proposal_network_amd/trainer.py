@@ -237,6 +237,7 @@ class PPNTrainer:
             raise ValueError("x must be a float32 [B,3,H,W] device tensor")
         x = x.contiguous()
         B, _, H, W = x.shape
+        T.bump_param_version()        # parameters may have been edited in place since the last pass: repack once per forward
         tape = []
         # the 7x7 stem reads NCHW f32; its weight gradient reads an 8-channel NHWC copy (channels 3..7 zero)
         xin8 = torch.zeros(B, H, W, 8, dtype=self.tdt, device=self.device)

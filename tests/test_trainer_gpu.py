@@ -380,3 +380,37 @@ def test_trainer_bottleneck_arch():
     assert not bad, bad[:6]
     losses2, w = tr.train_step(xd, tgd)
     assert torch.isfinite(losses2).all() and torch.isfinite(tr.flat).all() and abs(float(w.mean()) - 1) < 1e-5
+
+
+def test_train_step_at_full_size_batch32_384():
+    """BASELINE configs[3] per-GPU shard at its real size (batch 32, 384x384, bf16): the step runs the tile
+    instantiations the benchmark runs (tests/test_conv_tiles_gpu.py holds each of them to an fp64 reference);
+    here: two identical steps from the same state give bit-identical losses, gradients and parameters
+    (reproducible kernels: fixed-order folds, no float atomics), the bf16 losses agree with the exact-f32 mode's,
+    and the gradient norms of both modes agree (bf16 storage noise on a random network)."""
+    from pytorch_pose_proposal_network_amd import lib as L, prng, synth, targets
+    from pytorch_pose_proposal_network_amd.trainer import PPNTrainer
+    B, S = 32, 384
+    dev = torch.device("cuda")
+    sd = synth.make_state_dict("drn_d_22", 0)
+    x = torch.from_numpy(synth.normalized_frames(prng.u8_frames(99, B, (S, S)))).to(dev)
+    tg = targets.synthetic_targets(99, B, (S, S), device=dev)
+    base = torch.tensor([2.0, 1.5, 0.6, 0.4, 3.0], device=dev)
+    runs = {}
+    for name, dt in (("bf16_a", L.PPN_BF16), ("bf16_b", L.PPN_BF16), ("f32", L.PPN_F32)):
+        tr = PPNTrainer("drn_d_22", sd, compute_dtype=dt, insize=(S, S))
+        tr.base = base.clone()
+        losses, w = tr.train_step(x, tg)
+        torch.cuda.synchronize()
+        runs[name] = (losses.cpu(), tr.grad.clone(), tr.flat.clone(), w.cpu())
+        assert torch.isfinite(losses).all() and torch.isfinite(tr.grad).all() and torch.isfinite(tr.flat).all()
+        del tr
+        torch.cuda.empty_cache()
+    a, b, f = runs["bf16_a"], runs["bf16_b"], runs["f32"]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
+    print("losses bf16", a[0].numpy().round(4).tolist(), "f32", f[0].numpy().round(4).tolist())
+    assert torch.allclose(a[0], f[0], rtol=3e-2)
+    gn_a, gn_f = float(a[1].double().norm()), float(f[1].double().norm())
+    cos = float((a[1].double() @ f[1].double()) / (gn_a * gn_f))
+    print(f"|grad| bf16 {gn_a:.4e} f32 {gn_f:.4e} cos {cos:.4f}")
+    assert abs(gn_a / gn_f - 1.0) < 0.15 and cos > 0.8
