@@ -32,7 +32,7 @@ using namespace ppnconv;
 // Build-time diagnostics (tools/build_variant.py NAME conv_big.hip -DPPN_DIAG=n): TIMING ONLY, results are wrong.
 //   1 = no wait for the DMA, 2 = no DMA in the K loop, 3 = 32x32x16 MFMAs (half the MFMA issue slots) on the same reads,
 //   4 = 2 and 3 together, 5 = 2 without the per-step barrier, 6 = 2 without the LDS fragment reads,
-//   7 = no global stores in the NHWC epilogue, 8 = no arg-max pass in the head epilogue
+//   7 = no global stores in the NHWC epilogue, 8 = no arg-max pass in the head epilogue, 9 = the pass without its atomics
 #ifndef PPN_DIAG
 #define PPN_DIAG 0
 #endif
@@ -662,7 +662,11 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
                                     best_k = gt ? k : best_k;
                                 }
                             }
+#if PPN_DIAG == 9
+                            if (e < nedges && best == 12345.678f) {
+#else
                             if (e < nedges) {
+#endif
                                 const unsigned long long key = ((unsigned long long)__float_as_uint(best) << 32) |
                                                                (unsigned)(0xFFFFFFFFu - (unsigned)(sidx + best_k));
                                 atomicMax(a.amax_keys + ((size_t)nb * nedges + e) * a.HoWo + np, key);

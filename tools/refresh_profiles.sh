@@ -7,17 +7,20 @@ cd /tmp; export TMPDIR=/tmp
 echo "[1/6] bench (unprofiled, with per-launch table and CPU baseline)"
 python3 $R/bench.py --layers > $O/bench.json 2> $O/bench_layers.txt
 echo "[2/6] rocprofv3 kernel stats of bench.py: one lane (per-dispatch durations comparable with the HIP-event table) and the default two lanes"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --lanes 1 > $O/bench_profiled.json 2> $O/bench_profiled.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats2 -o bench2 -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_profiled_2lanes.json 2> $O/bench_profiled_2lanes.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras --no-verify --lanes 1 > $O/bench_profiled.json 2> $O/bench_profiled.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats2 -o bench2 -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras --no-verify > $O/bench_profiled_2lanes.json 2> $O/bench_profiled_2lanes.err
 echo "[3/6] PMC pass FETCH_SIZE"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --lanes 1 > $O/fetch.json 2> $O/fetch.err
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras --no-verify --lanes 1 > $O/fetch.json 2> $O/fetch.err
 echo "[4/6] PMC pass WRITE_SIZE"
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --lanes 1 > $O/write.json 2> $O/write.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras --no-verify --lanes 1 > $O/write.json 2> $O/write.err
 echo "[5/6] training step (phases + JSON), bench.py --workload train"
 python3 $R/tools/bench_train.py --phases --first-order > $O/train_bench.txt 2>&1
 python3 $R/bench.py --workload train --steps 10 --warmup 2 > $O/bench_train.json 2> $O/bench_train.err
 echo "[6/6] rocprofv3 kernel stats of the training step"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/train_stats -o train -- python3 $R/tools/bench_train.py --steps 3 --warmup 1 --first-order > $O/train_profiled.txt 2>&1
+echo "[6b] rocprofv3 kernel stats + traffic of the stand-alone decode on planted-crowd heads (BASELINE configs[4])"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/decode_stats -o decode -- python3 $R/tools/bench_decode.py 32 > $O/decode_profiled.txt 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/decode_fetch -- python3 $R/tools/bench_decode.py 32 > /dev/null 2>&1 || true
 echo "[7] in-kernel clock and phase stamps of the dominant conv kernel (diagnostic build: python tools/build_variant.py clock conv_big.hip -DPPN_CLOCK)"
 if [ -f $R/tools/bin/libppn_clock.so ]; then
   (cd $R && python3 tools/clock_conv.py && python3 tools/clock_conv.py --head) 2>&1 | grep -v amdgpu.ids > $O/conv_clock.txt
