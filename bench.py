@@ -116,13 +116,19 @@ def main_train(args):
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    # PPN_BENCH_BACKEND=gloo rehearses the N>1 control flow on a box with fewer GPUs than ranks (ranks share devices)
+    backend = os.environ.get("PPN_BENCH_BACKEND", "nccl")
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dev = torch.device("cuda", local if backend == "nccl" else local % max(torch.cuda.device_count(), 1))
     torch.cuda.set_device(dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     B, S = args.batch, args.size
     tr = PPNTrainer(args.arch, synth.make_state_dict(args.arch, 0),
                     compute_dtype=L.PPN_BF16 if args.dtype == "bf16" else L.PPN_F32, insize=(S, S), device=dev,
@@ -145,7 +151,7 @@ def main_train(args):
     fence()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     if rank == 0:
@@ -157,6 +163,7 @@ def main_train(args):
             "value": round(world * B * args.steps / dt, 2), "unit": "images/sec", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "rccl_ranks": world if (dist is not None and backend == "nccl") else (1 if world == 1 else 0),
             "config": {"workload": f"{args.arch} PPN training step {args.dtype}, batch {B}/GPU synthetic {S}x{S} frames, "
                                    "targets of 1-4 synthetic people per frame encoded on the device "
                                    "(BASELINE configs[3] per-GPU shard; GradNorm "
