@@ -295,7 +295,8 @@ def extra_sections(args, dev, net, frames, dec):
             d54_.decode_fused(u, k)
         dt = _time_steps(step, dev, 5, warmup=3)
         fl = A.conv_flops(A.build_program("drn_d_54"), S, S) * B
-        return {"what": f"DRN-D-54 (Bottleneck trunk) end to end, bf16, batch {B}, fused decode, one lane",
+        return {"what": f"DRN-D-54 (Bottleneck trunk) end to end, bf16, batch {B}, fused decode, one lane (throughput only: on "
+                        "this random checkpoint bf16 D-54 finds other people than f32 D-54, tests/test_fullsize_gpu.py)",
                 "images_per_sec": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 3),
                 "tflops": round(fl / dt / 1e12, 1), "frac_of_mfma_peak": round(fl / dt / 1e12 / BF16_DENSE_PEAK_TFLOPS, 4)}
 

@@ -414,3 +414,27 @@ def test_train_step_at_full_size_batch32_384():
     cos = float((a[1].double() @ f[1].double()) / (gn_a * gn_f))
     print(f"|grad| bf16 {gn_a:.4e} f32 {gn_f:.4e} cos {cos:.4f}")
     assert abs(gn_a / gn_f - 1.0) < 0.15 and cos > 0.8
+
+
+def test_bf16_limb_probe_by_linearity_vs_direct_pass():
+    """GradNorm's limb probe gradient is taken by linearity, (dL/dW - sum_{i<4} c_i dL_i/dW) / c_4, unless that
+    remainder drowns in bf16 rounding noise (then the direct fifth pass runs, PPNTrainer._limb_probe).  In bf16 mode the
+    norm from the production path must agree with the direct pass, for balanced task weights and for a limb weight so
+    small that the subtraction would be pure noise."""
+    from pytorch_pose_proposal_network_amd import lib as L
+    from pytorch_pose_proposal_network_amd.trainer import PPNTrainer
+    g, sd, x, tg, size = _setup()
+    dev = torch.device("cuda")
+    xd = torch.as_tensor(x).to(dev)
+    tgd = {k: torch.from_numpy(v).to(dev) for k, v in tg.items()}
+    for w in ([1.0, 1.0, 1.0, 1.0, 1.0], [1.6, 1.2, 1.2, 0.99, 0.01]):
+        tr = PPNTrainer("drn_d_22", sd, compute_dtype=L.PPN_BF16, insize=(size, size), second_order=False)
+        head = tr.forward(xd)
+        coeff = [v / 5 for v in w]
+        _, ghead = tr.criterion.forward_backward(head, tgd, coeff=coeff)
+        tr.backward(ghead)
+        gn = tr.probe_norms(head, tgd, coeff, ghead).cpu().numpy()
+        _, g4 = tr.criterion.forward_backward(head, tgd, coeff=[0.0, 0.0, 0.0, 0.0, 1.0])
+        direct = float(tr.probe_grad(g4).double().norm().cpu())
+        print(f"task weights {w}: gnorm_4 production {gn[4]:.5e}  direct pass {direct:.5e}")
+        assert abs(gn[4] / direct - 1.0) < 0.05, (gn[4], direct)
