@@ -392,13 +392,14 @@ def main():
                     help="skip the extra sections (materialized_head, decode_stress, f32_parity_mode, d54_end_to_end, "
                          "train_shard) reported beside the headline at N=1")
     ap.add_argument("--layers", action="store_true", help="print the per-layer table to stderr")
-    ap.add_argument("--lanes", type=int, default=int(os.environ.get("PPN_LANES", "2")),
+    ap.add_argument("--lanes", type=int, default=int(os.environ.get("PPN_LANES", "3")),
                     help="stream lanes successive steps alternate between (rt.MultiLaneInference); 1 = one lane with "
                          "the same kernels (what the rocprofv3 per-kernel durations are compared with)")
     ap.add_argument("--first-order", action="store_true",
                     help="--workload train: model gradient = d loss/d theta only (skip d Lgrad/d theta of main.py:759)")
     ap.add_argument("--tile-policy", type=int, default=0, choices=[0, 1],
-                    help="1 = conv tiles by efficiency alone (ppn_set_conv_tile_policy; +4 %% with two lanes)")
+                    help="1 = conv tiles by efficiency alone (ppn_set_conv_tile_policy; +1.5 %% with three lanes, but the "
+                         "per-launch roofline then describes the 256x256 tile whose partial last round only the other lanes fill)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="plain serial path on the caller's stream: forward, then decode (single-stream tile policy)")
     ap.add_argument("--materialize-head", action="store_true",
@@ -527,7 +528,7 @@ def main():
             "config": {"workload": f"{args.arch} PPN inference {args.dtype}, batch {B}/GPU synthetic {S}x{S} u8 frames: "
                                    "fused normalise + conv stack + head + decode/NMS/limb-parse (BASELINE configs[1])"
                                    + ("" if fused else ", head tensor materialised")
-                                   + (", batches alternate between two stream lanes (rt.MultiLaneInference)"
+                                   + (f", batches go round-robin over {max(1, args.lanes)} stream lanes (rt.MultiLaneInference)"
                                       if pipe is not None else ""),
                        "frames_per_gpu": B, "input": f"{S}x{S}x3 u8 resident in HBM",
                        "head": (f"{cfg.lastsize()}x{S//16}x{S//16} f32 per image, NOT materialised: the head conv's "
@@ -540,8 +541,8 @@ def main():
             "roofline": {"bound": "mfma", "kernel": dk, "launches_per_step": dn // reps,
                          "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4),
-                         "timing": "HIP events on the launch stream, one launch in flight (as `--lanes 1`; with two "
-                                   "lanes two dispatches share the GPU and each one's begin-to-end time doubles)",
+                         "timing": "HIP events on the launch stream, one launch in flight (as `--lanes 1`; with several "
+                                   "lanes dispatches share the GPU and each one's begin-to-end time grows)",
                          "traffic": (pmc_traffic(dk) or {}).get("bytes_per_launch"),
                          "traffic_source": (pmc_traffic(dk) or {}).get("source"),
                          "avg_launch_us": round(dms / dn * 1e3, 2),
