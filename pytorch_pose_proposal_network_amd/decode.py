@@ -62,6 +62,26 @@ class DecodeResult:
                             bbox=bb[b, :n], score=sc[b, :n]))
         return out
 
+    def to_host_async(self, stage: "HostStage") -> "HostStage":
+        """Queue the D2H of the compact result on the CURRENT stream into `stage`'s pinned buffers (the first
+        `stage.cap` people slots per image: 32 x 64 slots = 1.0 MB) without waiting for the counts; call
+        `stage.unpack()` once an event recorded behind this call has completed.  No host synchronisation here."""
+        cap = stage.cap
+        if cap > self.max_humans:
+            raise ValueError(f"HostStage capacity {cap} exceeds the decoder's max_humans {self.max_humans}")
+        dv = stage.device_side(self.count.device)
+        # gather the first `cap` slots into contiguous device buffers (a strided D2H would be staged by torch anyway,
+        # synchronously), then one asynchronous copy per array
+        dv["kp_cell"].copy_(self.kp_cell[:, :cap]); dv["limb_arg"].copy_(self.limb_arg[:, :cap])
+        dv["bbox"].copy_(self.bbox[:, :cap]); dv["score"].copy_(self.score[:, :cap])
+        stage.count.copy_(self.count, non_blocking=True)
+        stage.kp_cell.copy_(dv["kp_cell"], non_blocking=True)
+        stage.limb_arg.copy_(dv["limb_arg"], non_blocking=True)
+        stage.bbox.copy_(dv["bbox"], non_blocking=True)
+        stage.score.copy_(dv["score"], non_blocking=True)
+        stage.source = self
+        return stage
+
     def to_humans(self) -> List[Tuple[list, list]]:
         """Per image the reference's (humans, scores): lists of {kp: f32[4]} / {kp: f32} (datatest.py:98-132)."""
         res = []
@@ -77,6 +97,41 @@ class DecodeResult:
                 scores.append(sm)
             res.append((humans, scores))
         return res
+
+
+class HostStage:
+    """Pinned host buffers for the compact decode result of one batch (DecodeResult.to_host_async)."""
+
+    def __init__(self, batch: int, cap: int = 64):
+        self.cap = cap
+        pin = lambda *shape, dtype: torch.empty(*shape, dtype=dtype).pin_memory()
+        self.count = pin(batch, dtype=torch.int32)
+        self.kp_cell = pin(batch, cap, cfg.K, dtype=torch.int32)
+        self.limb_arg = pin(batch, cap, cfg.E, dtype=torch.int32)
+        self.bbox = pin(batch, cap, cfg.K, 4, dtype=torch.float32)
+        self.score = pin(batch, cap, cfg.K, dtype=torch.float32)
+        self.source: Optional[DecodeResult] = None
+        self._dev = None
+
+    def device_side(self, device):
+        if self._dev is None:
+            self._dev = {k: torch.empty(getattr(self, k).shape, dtype=getattr(self, k).dtype, device=device)
+                         for k in ("kp_cell", "limb_arg", "bbox", "score")}
+        return self._dev
+
+    def unpack(self):
+        """Per-image dicts like DecodeResult.to_host() (the copies must have completed).  An image with more than
+        `cap` people falls back to the synchronous full read-back."""
+        cnt = self.count.numpy()
+        if int(cnt.max(initial=0)) > self.cap:
+            return self.source.to_host()
+        kp, la, bb, sc = self.kp_cell.numpy(), self.limb_arg.numpy(), self.bbox.numpy(), self.score.numpy()
+        out = []
+        for b in range(len(cnt)):
+            n = int(cnt[b])
+            out.append(dict(n=n, root_cell=kp[b, :n, 0].copy(), kp_cell=kp[b, :n].copy(), limb_arg=la[b, :n].copy(),
+                            bbox=bb[b, :n].copy(), score=sc[b, :n].copy()))
+        return out
 
 
 def people_agreement(expected: dict, got: dict):

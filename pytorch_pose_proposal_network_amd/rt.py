@@ -174,6 +174,7 @@ class MultiLaneInference:
         self.decoders = [D.Decoder(batch, (h, w), insize_hw, model.local_grid_size, detection_thresh, device=dev)
                          for _ in range(lanes)]
         self.streams = [torch.cuda.Stream(device=dev) for _ in range(lanes)]
+        self._stages = [None] * lanes                     # pinned read-back buffers, created on first use
         self.k = 0
         # tile_policy 1: conv tiles chosen by efficiency alone instead of whole rounds of workgroups (process-wide
         # setting of libppn, restored by close()); measured +4 % with two lanes, but the per-launch (one in flight)
@@ -187,17 +188,37 @@ class MultiLaneInference:
         self.flush()
         L.check(L.load().ppn_set_conv_tile_policy(0), "ppn_set_conv_tile_policy")
 
-    def submit(self, frames_u8: torch.Tensor) -> D.DecodeResult:
+    def submit(self, frames_u8: torch.Tensor, to_host: bool = False) -> D.DecodeResult:
+        """Queue one batch on the next lane.  `frames_u8`: u8 [B,S,S,3] on the device, or in PINNED host memory -- then
+        the H2D copy goes straight into the lane's own input buffer on the lane's stream (it overlaps the other
+        lanes' kernels and needs no staging tensor).  `to_host=True` also queues the D2H of the compact result into the
+        lane's pinned buffers behind the decode (no host synchronisation): after `result.ready.synchronize()`,
+        `result.hosted.unpack()` gives the per-image arrays."""
         k = self.k
         self.k = (k + 1) % len(self.streams)
-        main = torch.cuda.current_stream(frames_u8.device)
-        ready = torch.cuda.Event()
-        ready.record(main)                                   # the frames are complete on the caller's stream
         st = self.streams[k]
+        on_host = not frames_u8.is_cuda
+        if on_host:
+            if not frames_u8.is_pinned():
+                raise ValueError("host frames must be in pinned memory (tensor.pin_memory())")
+            b, h, w, _ = frames_u8.shape
+        else:
+            main = torch.cuda.current_stream(frames_u8.device)
+            ready = torch.cuda.Event()
+            ready.record(main)                               # the frames are complete on the caller's stream
         with torch.cuda.stream(st):
-            st.wait_event(ready)
+            if on_host:
+                buf = self.model.input_buffer(b, h, w, True, True, slot=k)
+                buf.copy_(frames_u8, non_blocking=True)
+                frames_u8 = buf
+            else:
+                st.wait_event(ready)
             unary, keys = self.model.forward_u8(frames_u8, fused_decode=True, slot=k)
             res = self.decoders[k].decode_fused(unary, keys)
+            if to_host:
+                if self._stages[k] is None:
+                    self._stages[k] = D.HostStage(self.decoders[k].batch, cap=min(64, self.decoders[k].out.max_humans))
+                res.hosted = res.to_host_async(self._stages[k])
             ev = torch.cuda.Event()
             ev.record(st)
         res.ready = ev

@@ -154,3 +154,42 @@ def test_grab_frame_feeds_inference_without_copies(golden_dir):
         assert sorted(a) == sorted(b)
         for k in a:
             assert np.array_equal(a[k], b[k]) and sa[k] == sb[k]
+
+
+def test_multi_lane_pinned_frames_and_async_readback(golden_dir):
+    """MultiLaneInference.submit(pinned host frames, to_host=True): H2D straight into the lane's input buffer and D2H
+    of the compact result into pinned buffers, both on the lane's stream, no host synchronisation inside -- results
+    equal the serial device path; an image with more people than the staging capacity falls back to the full read."""
+    from pytorch_pose_proposal_network_amd import decode, rt
+    g = np.load(os.path.join(golden_dir, "forward_d22_96.npz"))
+    stats = {k[3:]: g[k] for k in g.files if k.startswith("bn/")}
+    model, _, _ = rt.network(image_size=96, state_dict=synth.make_state_dict("drn_d_22", 0, bn_stats=stats))
+    hosts = [torch.from_numpy(prng.u8_frames(300 + i, 3, (96, 96))).pin_memory() for i in range(6)]
+    serial = [rt.inference_batch(h.cuda(), model).to_host() for h in hosts]
+    pipe = rt.MultiLaneInference(model, 3, (96, 96), lanes=2)
+    with pytest.raises(ValueError):
+        pipe.submit(torch.from_numpy(prng.u8_frames(1, 3, (96, 96))))          # pageable host memory
+    pending, results = [], []
+    for h in hosts:
+        pending.append(pipe.submit(h, to_host=True))
+        if len(pending) == 2:
+            r = pending.pop(0)
+            r.ready.synchronize()
+            results.append(r.hosted.unpack())
+    for r in pending:
+        r.ready.synchronize()
+        results.append(r.hosted.unpack())
+    pipe.close()
+    assert sum(x["n"] for res in serial for x in res) > 0
+    for s_, p_ in zip(serial, results):
+        for a, b in zip(s_, p_):
+            assert a["n"] == b["n"]
+            for k in ("kp_cell", "limb_arg", "bbox", "score"):
+                assert np.array_equal(a[k], b[k])
+    # capacity overflow -> synchronous fallback with the same content
+    st = decode.HostStage(3, cap=1)
+    res = rt.inference_batch(hosts[0].cuda(), model)
+    res.to_host_async(st)
+    torch.cuda.synchronize()
+    for a, b in zip(serial[0], st.unpack()):
+        assert a["n"] == b["n"] and np.array_equal(a["kp_cell"], b["kp_cell"])
