@@ -568,21 +568,42 @@ def main():
                 for r in [pipe.submit(host, to_host=True) for _ in range(max(1, args.lanes))]:
                     r.ready.synchronize()
             torch.cuda.synchronize(dev)
+            # the two copies alone (no compute queued): says whether a low PCIe-inclusive rate is the link / the NUMA
+            # placement of the pinned pages on this box, or the pipeline
+            h2d_dst = torch.empty_like(host, device=dev)
+            h2d_dst.copy_(host, non_blocking=True)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(10):
+                h2d_dst.copy_(host, non_blocking=True)
+            torch.cuda.synchronize(dev)
+            h2d_ms = (time.perf_counter() - t0) / 10 * 1e3
+            del h2d_dst
             t1 = time.perf_counter()
             if pipe is not None:
                 # pinned frames -> the lane's own input buffer (H2D on the lane's stream) -> step -> the compact result
                 # into the lane's pinned buffers (D2H behind the decode); the host unpacks batch i - lanes + 1 while the
                 # later batches run: no synchronous copy anywhere
                 pending = []
-                for it in range(n):
-                    pending.append(pipe.submit(host, to_host=True))
-                    if len(pending) == max(1, args.lanes):
-                        r = pending.pop(0)
-                        r.ready.synchronize()
-                        hosted = r.hosted.unpack()
-                for r in pending:
+                host_s = [0.0, 0.0, 0.0]             # host seconds in submit / waiting on the ready event / unpack
+
+                def collect(r):
+                    ta = time.perf_counter()
                     r.ready.synchronize()
-                    hosted = r.hosted.unpack()
+                    tb = time.perf_counter()
+                    out = r.hosted.unpack()
+                    host_s[1] += tb - ta
+                    host_s[2] += time.perf_counter() - tb
+                    return out
+
+                for it in range(n):
+                    ta = time.perf_counter()
+                    pending.append(pipe.submit(host, to_host=True))
+                    host_s[0] += time.perf_counter() - ta
+                    if len(pending) == max(1, args.lanes):
+                        hosted = collect(pending.pop(0))
+                for r in pending:
+                    hosted = collect(r)
                 pcie_people = sum(h["n"] for h in hosted)
             else:
                 for it in range(n):
@@ -593,6 +614,11 @@ def main():
             dt1 = time.perf_counter() - t1
             result["pcie_inclusive"] = {"value": round(B * n / dt1, 2), "unit": "images/sec",
                                         "ms_per_step": round(dt1 / n * 1e3, 4), "h2d_bytes_per_step": host.numel(),
+                                        "host_ms_per_step": ({k: round(v / n * 1e3, 4) for k, v in
+                                                              zip(("submit", "wait", "unpack"), host_s)}
+                                                             if pipe is not None else None),
+                                        "h2d_alone_ms": round(h2d_ms, 4),
+                                        "h2d_alone_gbps": round(host.numel() / h2d_ms / 1e6, 2),
                                         "people": int(pcie_people),
                                         "note": "per step: H2D of the pinned u8 frames into the lane's input buffer, the "
                                                 "step, D2H of the compact result (first 64 people slots per image) into pinned "
