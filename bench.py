@@ -397,7 +397,7 @@ def main():
                          "the same kernels (what the rocprofv3 per-kernel durations are compared with)")
     ap.add_argument("--first-order", action="store_true",
                     help="--workload train: model gradient = d loss/d theta only (skip d Lgrad/d theta of main.py:759)")
-    ap.add_argument("--tile-policy", type=int, default=0, choices=[0, 1],
+    ap.add_argument("--tile-policy", type=int, default=0, choices=[0, 1, 2],
                     help="1 = conv tiles by efficiency alone (ppn_set_conv_tile_policy; +1.5 %% with three lanes, but the "
                          "per-launch roofline then describes the 256x256 tile whose partial last round only the other lanes fill)")
     ap.add_argument("--no-pipeline", action="store_true",

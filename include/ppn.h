@@ -196,6 +196,11 @@ typedef struct ppn_conv_desc {
     uint64_t* argmax_keys;
     int32_t unary_channels;      /* 6K = 108                                                          */
     int32_t limb_window;         /* sH*sW = 441                                                       */
+    /* Output-pixel range of this launch, in the flattened [batch*out_h*out_w] order: pixels m_begin .. m_begin +
+     * m_count - 1 are computed, the rest of the output tensors is left untouched.  m_count = 0 (default): the whole
+     * tensor (under tile policy 2 ppn_conv2d_fused then cuts the range itself where ppn_conv_split says so; a plan
+     * lists the two ranges as separate entries so that each launch is timed and named). */
+    int32_t m_begin, m_count;
 } ppn_conv_desc;
 
 /* GEMM-depth step / channel tile the packer must pad to for a conv of this shape and dtype, and the order of
@@ -211,6 +216,14 @@ int ppn_conv_tiling(int32_t dtype, int32_t cin, int32_t cout, int32_t ksize, int
 
 int ppn_conv2d_fused(const ppn_conv_desc* d, void* stream);
 
+/* Where the launcher would cut the output pixels [0, m) of a conv with this Cin/Cout into two launches under tile
+ * policy 2 (ppn_set_conv_tile_policy): *m_split pixels run whole rounds (256 CUs) of the most efficient large tile, the
+ * remaining m - *m_split a smaller tile that fills one more round (e.g. 512 -> 512 at 32 x 48 x 48 = 73 728 pixels:
+ * 65 536 on 256 x 256 tiles = 2 rounds, 8 192 on 128 x 128 tiles = 1 round, instead of 3 rounds of 192 x 256).
+ * *m_split = 0: a single launch -- always under policies 0 and 1.  Each output element accumulates its GEMM depth in
+ * the same order whatever tile computes it, so results do not depend on the cut. */
+int ppn_conv_split(int32_t dtype, int32_t cin, int32_t cout, int64_t m, int64_t* m_split);
+
 /*
  * Frame ingest (rt_test.py:150-157 grab_frame): cv2.resize(frame, (dst_w, dst_h)) [INTER_LINEAR, 8-bit fixed point],
  * cv2.flip(.,0) + cv2.flip(.,1) when `flip`, cv2.COLOR_BGR2RGB when `swap_rb`, on the device.
@@ -224,6 +237,8 @@ int ppn_ingest_frames(const void* src_bgr, int32_t batch, int32_t src_h, int32_t
  * sized so that the workgroup count fills whole rounds of the 256 CUs.  1: several launches are in flight on
  * different streams (rt.MultiLaneInference) -- a partial last round is filled by the other stream's workgroups, so
  * the most efficient tile shape is taken regardless of the round count (measured +4..5 % with two lanes). */
+/* 2: as 0, plus two-segment launches where ppn_conv_split cuts (opt-in: measured 2-4 % slower end to end because the
+ * single round of small tiles is slower than modelled; conv_big.hip::big_split_for has the numbers). */
 int ppn_set_conv_tile_policy(int32_t policy);
 
 /* Force the (pixels x channels) tile of the large-tile convolution kernel for every later launch / plan entry whose

@@ -51,7 +51,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvKArgs a) {
         ptile = fast_div(logical, a.div_nct);
         ctile = logical - ptile * a.n_ctiles;
     }
-    const int m0 = ptile * BP, c0 = ctile * BC;
+    const int m0 = a.m_base + ptile * BP, c0 = ctile * BC;
 
     // ---- per-lane loader state -------------------------------------------------------------
     // LDS slot (row, s) holds global chunk s ^ ((row>>1)&7); for this lane the xor term is constant
@@ -453,7 +453,26 @@ int ppn::conv_launch(const ppn_conv_desc* d, hipStream_t st, const char** kname)
         kpad += d->cin2;
     }
     if (d->k_total != kpad) return ppn::fail(PPN_E_INVALID, "k_total %d != %d", d->k_total, kpad);
-    const long long m = (long long)d->batch * d->out_h * d->out_w;
+    const long long m_all = (long long)d->batch * d->out_h * d->out_w;
+    if (m_all > 0x7fffffffLL) return ppn::fail(PPN_E_UNSUPPORTED, "tensor too large for 32-bit indexing");
+    long long m_lo = 0, m_hi = m_all;
+    if (d->m_count != 0) {
+        if (d->m_begin < 0 || d->m_count < 0 || (long long)d->m_begin + d->m_count > m_all)
+            return ppn::fail(PPN_E_INVALID, "pixel range [%d, +%d) outside the %lld output pixels", d->m_begin, d->m_count, m_all);
+        m_lo = d->m_begin; m_hi = m_lo + d->m_count;
+    } else if (!smallc) {
+        // whole tensor: two launches with different tiles where that saves a round of workgroups (ppn_conv_split)
+        const long long cut = big_split_for(d->cout, m_all);
+        if (cut > 0 && cut < m_all) {
+            ppn_conv_desc part = *d;
+            part.m_begin = 0; part.m_count = (int32_t)cut;
+            const int rc = ppn::conv_launch(&part, st, kname);
+            if (rc != PPN_OK) return rc;
+            part.m_begin = (int32_t)cut; part.m_count = (int32_t)(m_all - cut);
+            return ppn::conv_launch(&part, st, nullptr);
+        }
+    }
+    const long long m = m_hi - m_lo;                                  // pixels of THIS launch: the tile is chosen for them
     TileChoice tc = choose_tile(d->cout);
     BigTile bt{0, 0};
     const bool big = !smallc && big_tile_for(d->cout, m, &bt);
@@ -476,7 +495,7 @@ int ppn::conv_launch(const ppn_conv_desc* d, hipStream_t st, const char** kname)
         return ppn::fail(PPN_E_UNSUPPORTED, "NHWC output needs cout %% 8 == 0 (got %d)", d->cout);
     }
     const long long in_elems = (long long)d->batch * d->in_h * d->in_w * d->cin;
-    if (m > 0x7fffffffLL || in_elems > 0x7fffffffLL) return ppn::fail(PPN_E_UNSUPPORTED, "tensor too large for 32-bit indexing");
+    if (in_elems > 0x7fffffffLL) return ppn::fail(PPN_E_UNSUPPORTED, "tensor too large for 32-bit indexing");
     ConvKArgs a;
     a.src = static_cast<const char*>(d->src);
     a.wgt = static_cast<const char*>(d->weight);
@@ -488,7 +507,7 @@ int ppn::conv_launch(const ppn_conv_desc* d, hipStream_t st, const char** kname)
     a.zero = static_cast<const char*>(d->zero_page);
     a.B = d->batch; a.H = d->in_h; a.W = d->in_w; a.Cin = d->cin; a.Ho = d->out_h; a.Wo = d->out_w; a.Cout = d->cout;
     a.ks = d->ksize; a.stride = d->stride; a.dil = d->dilation; a.pad = d->pad;
-    a.Ktot = d->k_total; a.M = (int)m; a.HoWo = d->out_h * d->out_w;
+    a.Ktot = d->k_total; a.M = (int)m_hi; a.m_base = (int)m_lo; a.HoWo = d->out_h * d->out_w;
     a.div_howo = make_fastdiv((unsigned)a.HoWo); a.div_wo = make_fastdiv((unsigned)d->out_w);
     a.act1 = d->act1; a.act2 = d->act2; a.nchw = d->out_nchw_f32;
     a.log2Cin = log2c < 0 ? 0 : log2c;
@@ -511,6 +530,15 @@ int ppn::conv_launch(const ppn_conv_desc* d, hipStream_t st, const char** kname)
     if (d->src2) return ppn::fail(PPN_E_UNSUPPORTED, "the fused shortcut is implemented by the large-tile kernel only");
     if (d->dtype == PPN_F32) return launch_dtype<float>(a, smallc, tc, st, kname);
     return launch_dtype<__bf16>(a, smallc, tc, st, kname);
+}
+
+extern "C" int ppn_conv_split(int32_t dtype, int32_t cin, int32_t cout, int64_t m, int64_t* m_split) {
+    if (dtype != PPN_F32 && dtype != PPN_BF16) return ppn::fail(PPN_E_INVALID, "bad dtype %d", dtype);
+    if (cin < 1 || cout < 1 || m < 1 || !m_split) return ppn::fail(PPN_E_INVALID, "ppn_conv_split: bad arguments");
+    const int bk = dtype == PPN_F32 ? 32 : 64;
+    const long long cut = (cin % bk == 0) ? big_split_for(cout, m) : 0;
+    *m_split = (cut > 0 && cut < m) ? cut : 0;
+    return PPN_OK;
 }
 
 static thread_local const char* g_last_conv_kernel = "";

@@ -18,6 +18,7 @@
 // of the next stage, so the matrix pipe restarts immediately after the per-step barrier.
 // Epilogue through LDS in 64-pixel (NHWC) / 64-channel (NCHW head) chunks: 16-byte coalesced stores.  The head
 // conv can additionally (or instead) run the decode's limb arg-max in its epilogue (ppn_conv_desc.argmax_keys).
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
@@ -116,7 +117,7 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
         ptile = fast_div(logical, a.div_nct);
         ctile = logical - ptile * a.n_ctiles;
     }
-    const int m0 = ptile * BP, c0 = ctile * BC;
+    const int m0 = a.m_base + ptile * BP, c0 = ctile * BC;
 
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.src, 0, src_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.wgt, 0, wgt_bytes, 0x00020000);
@@ -841,6 +842,45 @@ bool big_tile_for(int cout, long long m, BigTile* out) {
     return true;
 }
 
+// Two-segment launch (tile policy 2, opt-in): the most efficient tile (256x256: 1.27 vs 1.10 for 192x256) wastes most
+// of a round when its workgroup count is not a multiple of the 256 CUs (73 728 pixels x 512 channels = 576 tiles =
+// 2.25 rounds), which is why the single-tile choice settles for 192x256 there (768 = 3 rounds).  Cutting the pixel
+// range instead -- whole rounds of the big tile, then ONE round of a small tile over the remaining pixels -- should cost
+// 2 x 51.6 k + 18.8 k = 122 k units instead of 134 k.  MEASURED (round 2, tools/ab_split.sh): the 256x256 segments do
+// run at 1.28-1.46 PFLOP/s (0.51-0.58 of peak) instead of 1.14-1.28, but the lone 128x128 round takes 55-58 us instead of
+// the ~35 the model assumes (one small workgroup per CU stages 2x the bytes per FLOP of the big tile through the same
+// L2->LDS path; a four-stage pipeline changed nothing), so the layer is not faster (277 us either way) and the extra
+// launches cost 1.8 % (three lanes) to 3.6 % (one lane) of throughput.  Not the default; kept for the pixel-range
+// interface it exercises.  Returns the cut (0: single launch).  Only for Cout >= 256, where efficiencies were measured.
+long long big_split_for(int cout, long long m) {
+    BigTile single;
+    if (g_tile_policy != 2 || cout < 256 || cout >= 4096 || !big_tile_for(cout, m, &single) || g_ov_bp > 0) return 0;
+    struct Cand { int bp, bc; double eff; };
+    static const Cand cands[] = {{256, 256, 1.27}, {192, 256, 1.10}, {128, 256, 0.92}, {256, 128, 0.90},
+                                 {192, 128, 0.95}, {128, 128, 0.87}};
+    auto rounds_cost = [&](const Cand& cd, long long mm) {
+        const long long tiles = ((mm + cd.bp - 1) / cd.bp) * ((cout + cd.bc - 1) / cd.bc);
+        return (double)((tiles + 255) / 256) * cd.bp * cd.bc / cd.eff;
+    };
+    double best_single = 1e30;
+    for (const Cand& cd : cands) best_single = std::min(best_single, rounds_cost(cd, m));
+    double best = best_single * 0.96;                    // the second launch must pay for its own start-up
+    long long cut = 0;
+    for (const Cand& p : cands) {
+        const long long ct = (cout + p.bc - 1) / p.bc;
+        if (256 % ct != 0) continue;
+        const long long rounds = (m / p.bp) * ct / 256;  // whole rounds of whole tiles
+        if (rounds < 1) continue;
+        const long long m1 = rounds * 256 / ct * p.bp;
+        if (m1 >= m) continue;
+        double tail = 1e30;
+        for (const Cand& q : cands) tail = std::min(tail, rounds_cost(q, m - m1));
+        const double cost = (double)rounds * p.bp * p.bc / p.eff + tail;
+        if (cost < best) { best = cost; cut = m1; }
+    }
+    return cut;
+}
+
 int launch_big(const ConvKArgs& a, int dtype, BigTile t, hipStream_t st, const char** kname) {
     // buffer descriptors address up to 2 GiB with the out-of-range marker used for padding
     const size_t es = dtype == PPN_F32 ? 4 : 2;
@@ -861,7 +901,7 @@ extern "C" int ppn_set_conv_tile_override(int32_t bp, int32_t bc) {
 }
 
 extern "C" int ppn_set_conv_tile_policy(int32_t policy) {
-    if (policy != 0 && policy != 1) return ppn::fail(PPN_E_INVALID, "ppn_set_conv_tile_policy: 0 or 1");
+    if (policy < 0 || policy > 2) return ppn::fail(PPN_E_INVALID, "ppn_set_conv_tile_policy: 0, 1 or 2");
     ppnconv::g_tile_policy = policy;
     return PPN_OK;
 }

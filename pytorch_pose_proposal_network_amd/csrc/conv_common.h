@@ -40,7 +40,8 @@ struct ConvKArgs {
     const char* zero;
     int B, H, W, Cin, Ho, Wo, Cout, ks, stride, dil, pad;
     int Ktot;      // padded GEMM depth (multiple of BK)
-    int M;         // B*Ho*Wo
+    int M;         // end of this launch's output-pixel range (B*Ho*Wo for a whole-tensor launch)
+    int m_base;    // first output pixel of this launch (ppn_conv_desc.m_begin): tile p covers m_base + p*BP ...
     int HoWo;
     FastDiv div_howo, div_wo, div_nct;   // dividers by HoWo, Wo, n_ctiles
     int act1, act2, nchw;
@@ -135,6 +136,9 @@ struct BigTile {
     int bp, bc;
 };
 bool big_tile_for(int cout, long long m, BigTile* out);
+// Split point of a two-segment launch (0 = single launch): pixels [0, split) run whole rounds of the most efficient
+// tile, the rest a smaller tile that fills one more round (conv_big.hip).
+long long big_split_for(int cout, long long m);
 int launch_big(const ConvKArgs& a, int dtype, BigTile t, hipStream_t st, const char** kname);
 
 }  // namespace ppnconv

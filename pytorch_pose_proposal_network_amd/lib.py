@@ -36,7 +36,7 @@ class ConvDesc(C.Structure):
         ("out_act", C.c_void_p), ("zero_page", C.c_void_p),
         ("src2", C.c_void_p), ("in2_h", C.c_int32), ("in2_w", C.c_int32), ("cin2", C.c_int32), ("stride2", C.c_int32),
         ("unary_out", C.c_void_p), ("argmax_keys", C.c_void_p), ("unary_channels", C.c_int32),
-        ("limb_window", C.c_int32),
+        ("limb_window", C.c_int32), ("m_begin", C.c_int32), ("m_count", C.c_int32),
     ]
 
 
@@ -87,6 +87,7 @@ _SIGNATURES = {
     "ppn_conv_tiling": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32),
                                   C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "ppn_conv2d_fused": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
+    "ppn_conv_split": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.POINTER(C.c_int64)]),
     "ppn_stem7x7": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32] +
                     [C.c_void_p] * 3 + [C.POINTER(C.c_float)] * 2 + [C.c_void_p, C.c_void_p]),
     "ppn_stem01": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 3 +

@@ -321,6 +321,17 @@ class PoseProposalNet:
             d.scale2, d.shift2 = self._ptr(op.name + ".s2"), self._ptr(op.name + ".b2")
             d.out_act = bufs[op.out_act].data_ptr() if op.out_act else None
             d.zero_page = self._dev["zero"].data_ptr()
+            # two launches with different tiles where the launcher would cut the pixel range (ppn_conv_split): listed as
+            # two plan entries so that each launch is timed and named by itself
+            m_all, cut = batch * oh * ow, C.c_int64(0)
+            L.check(lib.ppn_conv_split(self.compute_dtype, op.cin, op.cout, m_all, C.byref(cut)), "ppn_conv_split")
+            if cut.value:
+                name, flops = entries.pop()
+                for lo, n in ((0, cut.value), (cut.value, m_all - cut.value)):
+                    d.m_begin, d.m_count = lo, n
+                    L.check(lib.ppn_plan_add_conv(handle, C.byref(d)), f"ppn_plan_add_conv({op.name})")
+                    entries.append((f"{name}[{lo}:{lo + n}]", flops * n // m_all))
+                continue
             L.check(lib.ppn_plan_add_conv(handle, C.byref(d)), f"ppn_plan_add_conv({op.name})")
         head = (bufs["unary"], bufs["keys"]) if fused else bufs["head"]
         return _Plan(handle, bufs, head, entries, A.conv_flops(self._ops, h, w) * batch, src)

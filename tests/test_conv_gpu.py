@@ -19,12 +19,14 @@ def _act(v, a):
 
 
 def run_conv(x, w, dtype, stride=1, dil=1, pad=0, s1=None, b1=None, act1=0, residual=None, s2=None, b2=None, act2=0,
-             want_raw=True, want_act=False, nchw=False, shortcut=None, argmax=None, info=None):
+             want_raw=True, want_act=False, nchw=False, shortcut=None, argmax=None, info=None, ranges=None):
     """x [B,Cin,H,W], w [Cout,Cin,k,k] CPU f32 -> (raw, act) as NCHW CPU f32 tensors via libppn.
 
     argmax=(unary_channels, window): NCHW head mode with the decode's limb arg-max fused into the epilogue; the
     compact unary tensor and the u64 keys are returned through ``info`` (a dict, which also receives the name of
-    the kernel instantiation that ran)."""
+    the kernel instantiation that ran).  ranges=[(m_begin, m_count, (bp, bc) or None), ...]: one launch per entry over
+    that range of the flattened output pixels (ppn_conv_desc.m_begin/m_count), each with its own forced tile; pixels
+    outside every range keep the NaN fill."""
     from pytorch_pose_proposal_network_amd import lib as L
     lib = L.load()
     dev = torch.device("cuda")
@@ -87,10 +89,21 @@ def run_conv(x, w, dtype, stride=1, dil=1, pad=0, s1=None, b1=None, act1=0, resi
         keys = torch.zeros(B, (Cout - uch) // win, Ho, Wo, dtype=torch.int64, device=dev)
         keep += [unary, keys]
         d.unary_out, d.argmax_keys, d.unary_channels, d.limb_window = unary.data_ptr(), keys.data_ptr(), uch, win
-    L.check(lib.ppn_conv2d_fused(C.byref(d), st), "ppn_conv2d_fused")
+    kernels = []
+    for lo, n, tile in (ranges if ranges is not None else [(0, 0, None)]):
+        d.m_begin, d.m_count = lo, n
+        if tile is not None:
+            L.check(lib.ppn_set_conv_tile_override(*tile), "ppn_set_conv_tile_override")
+        try:
+            L.check(lib.ppn_conv2d_fused(C.byref(d), st), "ppn_conv2d_fused")
+        finally:
+            if tile is not None:
+                L.check(lib.ppn_set_conv_tile_override(0, 0), "ppn_set_conv_tile_override")
+        kernels.append(lib.ppn_last_conv_kernel().decode())
     torch.cuda.synchronize()
     if info is not None:
-        info["kernel"] = lib.ppn_last_conv_kernel().decode()
+        info["kernel"] = kernels[0]
+        info["kernels"] = kernels
         if argmax is not None:
             info["unary"], info["keys"] = unary.cpu(), keys.cpu()
     out = []

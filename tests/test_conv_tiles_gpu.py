@@ -189,6 +189,9 @@ def _sampled_rows(M, tiles=(128, 192, 256), n_random=96, seed=0):
                     rows.add(r)
     g = np.random.default_rng(seed)
     rows.update(int(v) for v in g.integers(0, M, n_random))
+    if M > 65536:                                                    # the two-segment launch's cut (ppn_conv_split)
+        rows.update(65536 + d for d in (-256, -129, -2, -1, 0, 1, 127, 128) if 65536 + d < M)
+        rows.update(int(v) for v in g.integers(65536, M, 32))
     return np.array(sorted(rows))
 
 
@@ -214,7 +217,7 @@ FULL = [
     ("L5_c2_256_d2",           32, 256, 256, 48, 48, 3, 1, 2, 2, (192, 128)),
     ("L4_c1_64_128_s2",        32, 64, 128, 96, 96, 3, 2, 1, 1, (192, 128)),
     ("L3_c2_64_96x96",         32, 64, 64, 96, 96, 3, 1, 1, 1, None),
-    ("B1_c1_512_s2_24x24",     32, 512, 512, 48, 48, 3, 2, 1, 1, None),
+    ("B1_c1_512_s2_24x24",     32, 512, 512, 48, 48, 3, 2, 1, 1, (192, 256)),
     ("ragged_M_31",            31, 512, 512, 47, 45, 3, 1, 2, 2, None),
 ]
 
@@ -352,3 +355,66 @@ def test_head_argmax_ambiguous_segments(force_tile, mode, dtype_name):
     info2 = {}
     run_conv(x, w, dtype, b1=bias, act1=3, nchw=True, argmax=(uch, win), want_raw=False, info=info2)
     assert torch.equal(info2["keys"], info["keys"]) and torch.equal(info2["unary"], info["unary"])
+
+
+@pytest.mark.parametrize("dtype_name", ["f32", "bf16"])
+def test_pixel_ranges_with_different_tiles_equal_one_launch(dtype_name):
+    """ppn_conv_desc.m_begin / m_count: a conv cut into pixel ranges, each launched with a DIFFERENT tile, gives the
+    bits of the single launch (every output accumulates its GEMM depth in the same order whatever tile computes it);
+    cuts fall inside an image row and off every tile multiple; a launch leaves the pixels outside its range alone."""
+    dtype = _dt(dtype_name)
+    B, Cin, H, W, Cout = 3, 128, 20, 23, 320                    # M = 1380
+    x = q(rnd(B, Cin, H, W, seed=71), dtype)
+    w = q(rnd(Cout, Cin, 3, 3, seed=72, scale=(2.0 / (Cin * 9)) ** 0.5), dtype)
+    s1 = 0.5 + torch.rand(Cout, generator=torch.Generator().manual_seed(73))
+    b1 = rnd(Cout, seed=74, scale=0.3)
+    res = q(rnd(B, Cout, H, W, seed=75), dtype)
+    s2 = 0.5 + torch.rand(Cout, generator=torch.Generator().manual_seed(76))
+    b2 = rnd(Cout, seed=77, scale=0.3)
+    kw = dict(stride=1, dil=2, pad=2, s1=s1, b1=b1, act1=1, residual=res, s2=s2, b2=b2, act2=1, want_act=True)
+    whole_raw, whole_act = run_conv(x, w, dtype, **kw)
+    info = {}
+    M = B * H * W
+    cuts = [(0, 512, (256, 256)), (512, 301, (128, 128)), (813, M - 813, (192, 256))]
+    raw, act = run_conv(x, w, dtype, info=info, ranges=cuts, **kw)
+    print(info["kernels"])
+    assert info["kernels"] == [_kname(dtype_name, 256, 256), _kname(dtype_name, 128, 128), _kname(dtype_name, 192, 256)]
+    assert torch.equal(raw, whole_raw) and torch.equal(act, whole_act)
+    # a single range: everything outside it keeps the NaN fill, everything inside equals the whole launch
+    raw1, _ = run_conv(x, w, dtype, ranges=[(512, 301, (128, 128))], **kw)
+    flat1 = raw1.permute(0, 2, 3, 1).reshape(M, Cout)
+    flatw = whole_raw.permute(0, 2, 3, 1).reshape(M, Cout)
+    assert torch.isnan(flat1[:512]).all() and torch.isnan(flat1[813:]).all()
+    assert torch.equal(flat1[512:813], flatw[512:813])
+
+
+def test_conv_split_plan_and_automatic_two_segment_launch():
+    """Tile policy 2 (opt-in; measured slower end to end, conv_big.hip::big_split_for): ppn_conv_split reports where the
+    launcher cuts the pixel range (whole rounds of 256x256 tiles, then one round of a small tile), a whole-tensor
+    ppn_conv2d_fused at such a size performs the two launches itself and equals the same conv forced onto a single
+    192x256 launch; under the default policy nothing is cut.  512 -> 512 1x1 at 32 x 48 x 48 (M = 73 728)."""
+    import ctypes as C
+    from pytorch_pose_proposal_network_amd import lib as L
+    lib = L.load()
+    cut = C.c_int64(-1)
+    L.check(lib.ppn_conv_split(L.PPN_BF16, 512, 512, 73728, C.byref(cut)), "ppn_conv_split")
+    assert cut.value == 0
+    dtype = L.PPN_BF16
+    B, Cin, H, W, Cout = 32, 512, 48, 48, 512
+    x = q(rnd(B, Cin, H, W, seed=81), dtype)
+    w = q(rnd(Cout, Cin, 1, 1, seed=82, scale=(2.0 / Cin) ** 0.5), dtype)
+    b1 = rnd(Cout, seed=83, scale=0.3)
+    info = {}
+    L.check(lib.ppn_set_conv_tile_policy(2), "ppn_set_conv_tile_policy")
+    try:
+        for cin, cout, m, want in [(512, 512, 73728, 65536), (256, 256, 73728, 65536), (128, 128, 294912, 0),
+                                   (512, 512, 18432, 0), (512, 7605, 18432, 0), (512, 512, 4608, 0)]:
+            L.check(lib.ppn_conv_split(L.PPN_BF16, cin, cout, m, C.byref(cut)), "ppn_conv_split")
+            assert cut.value == want, (cin, cout, m, cut.value)
+        auto, _ = run_conv(x, w, dtype, b1=b1, act1=1, info=info)
+    finally:
+        L.check(lib.ppn_set_conv_tile_policy(0), "ppn_set_conv_tile_policy")
+    print(info["kernels"])
+    assert info["kernel"] == _kname("bf16", 256, 256)            # the first of the two launches
+    single, _ = run_conv(x, w, dtype, b1=b1, act1=1, ranges=[(0, 0, (192, 256))])
+    assert not torch.isnan(auto).any() and torch.equal(auto, single)
