@@ -418,3 +418,25 @@ def test_conv_split_plan_and_automatic_two_segment_launch():
     assert info["kernel"] == _kname("bf16", 256, 256)            # the first of the two launches
     single, _ = run_conv(x, w, dtype, b1=b1, act1=1, ranges=[(0, 0, (192, 256))])
     assert not torch.isnan(auto).any() and torch.equal(auto, single)
+
+
+@pytest.mark.parametrize("dtype_name", ["f32", "bf16"])
+def test_pixel_ranges_small_channel_kernel(dtype_name):
+    """The same range interface through the small-channel kernel (Cin below the K step: csrc/conv.hip), stride 2."""
+    dtype = _dt(dtype_name)
+    B, Cin, H, W, Cout = 3, 16, 38, 42, 64
+    x = q(rnd(B, Cin, H, W, seed=95), dtype)
+    w = q(rnd(Cout, Cin, 3, 3, seed=96, scale=(2.0 / (Cin * 9)) ** 0.5), dtype)
+    s1 = 0.5 + torch.rand(Cout, generator=torch.Generator().manual_seed(97))
+    b1 = rnd(Cout, seed=98, scale=0.3)
+    kw = dict(stride=2, dil=1, pad=1, s1=s1, b1=b1, act1=1)
+    info = {}
+    whole, _ = run_conv(x, w, dtype, info=info, **kw)
+    assert info["kernel"].startswith("conv_igemm_kernel<"), info["kernel"]
+    M = B * 19 * 21
+    parts, _ = run_conv(x, w, dtype, ranges=[(0, 130, None), (130, 700, None), (830, M - 830, None)], **kw)
+    assert not torch.isnan(whole).any() and torch.equal(parts, whole)
+    one, _ = run_conv(x, w, dtype, ranges=[(130, 700, None)], **kw)
+    flat = one.permute(0, 2, 3, 1).reshape(M, Cout)
+    assert torch.isnan(flat[:130]).all() and torch.isnan(flat[830:]).all()
+    assert torch.equal(flat[130:830], whole.permute(0, 2, 3, 1).reshape(M, Cout)[130:830])

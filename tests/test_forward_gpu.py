@@ -211,3 +211,51 @@ def test_train_eval_toggle_on_the_same_object(golden_dir):
     ref_eval1 = Fr.forward_ref(sd_ref, torch.from_numpy(x), "drn_d_22").numpy()
     assert np.abs(head_eval1.cpu().numpy() - ref_eval1).max() <= F32_TOL
     assert not torch.equal(head_eval1, head_eval0)
+
+
+@pytest.mark.parametrize("hw", [(128, 208), (176, 112), (400, 272)], ids=lambda s: "%dx%d" % s)
+def test_non_square_inputs(golden_dir, hw):
+    """Input sizes other than 384x384 (the reference's insize is a constructor argument, model.py:31-37): H != W,
+    grids that are not multiples of the conv tiles' or the fused stem's strip widths (8x13, 11x7, 25x17 cells).
+    f32 head vs the CPU oracle (1e-4); bf16 (fused three-layer stem, bf16 MFMA) within its stated tolerance of the f32
+    head; for both the fused decode == the stand-alone decode of the materialised head, bit for bit."""
+    from oracle import forward_ref as Fr
+    from pytorch_pose_proposal_network_amd import decode, drn, model, rt
+    g = np.load(os.path.join(golden_dir, "forward_d22_96.npz"))
+    stats = {k[3:]: g[k] for k in g.files if k.startswith("bn/")}
+    sd = synth.make_state_dict("drn_d_22", int(g["seed_w"]), bn_stats=stats)
+    H, W = hw
+    u8 = prng.u8_frames(4242, 3, (H, W))
+    x = synth.normalized_frames(u8)
+    ref = Fr.forward_ref({k: np.asarray(v) for k, v in sd.items()}, torch.from_numpy(x), "drn_d_22").numpy()
+    assert ref.shape[2:] == (H // 16, W // 16)
+    heads = {}
+    for dtype in ("float32", "bfloat16"):
+        m = model.PoseProposalNet(drn.drn_d_22(), insize=(W, H), outsize=(W // 16, H // 16), compute_dtype=dtype).cuda()
+        m.load_state_dict(sd)
+        m.eval()
+        frames = torch.from_numpy(u8).cuda()
+        head = m.forward_u8(frames).clone()
+        heads[dtype] = head.cpu().numpy()
+        assert heads[dtype].shape == ref.shape
+        a = rt.inference_batch(frames, m).to_host()
+        b = decode.decode_heads(head, insize_hw=(H, W)).to_host()
+        for ra, rb in zip(a, b):
+            assert ra["n"] == rb["n"]
+            for k in ("kp_cell", "limb_arg", "bbox", "score"):
+                assert np.array_equal(ra[k], rb[k]), (dtype, k)
+    from oracle import fused_ref
+    emu = fused_ref.fused_forward_ref(sd, Fr.normalize_u8(u8), "drn_d_22", emulate_bf16=True, fuse_stem="all").numpy()
+    err = np.abs(heads["float32"] - ref).max()
+    d, de = np.abs(heads["bfloat16"] - ref), np.abs(heads["bfloat16"] - emu)
+    print(f"{H}x{W}: f32 |hip-oracle| {err:.2e}; bf16 vs f32 oracle max {d.max():.3f} mean {d.mean():.4f}, "
+          f"vs emulated-bf16 oracle max {de.max():.4f} mean {de.mean():.5f}")
+    assert err <= F32_TOL
+    # kernel error proper: against the oracle with bf16 storage emulated at the same points.  Against the f32 head the
+    # quantisation noise of this checkpoint (BN statistics calibrated on 96x96 frames) reaches 0.17 on single elements
+    # of the 2.4 M, so only the mean is gated there.
+    # The emulation rounds at the same points but sums in another order, so single bf16 roundings flip and the flips
+    # are amplified by the layers behind them: the MAXIMUM over 1-3 M head elements is a tail statistic (0.05-0.08 on
+    # these frames).  Gated: the mean and the 99.99th percentile at the fixture tolerances, the maximum at 0.15.
+    assert de.mean() <= BF16_EMU_MEAN_TOL and np.quantile(de, 0.9999) <= BF16_EMU_MAX_TOL and de.max() <= BF16_MAX_TOL
+    assert d.mean() <= BF16_MEAN_TOL
