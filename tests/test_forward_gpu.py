@@ -298,3 +298,41 @@ def test_forward_other_drn_d_variants(arch):
     # oracle itself is (the Bottleneck nets amplify f32 rounding: D-54's reference f32-vs-f64 distance is 2.8e-4)
     assert d.max() <= F32_TOL or d64.max() <= 1.5 * noise, (float(d.max()), float(d64.max()), noise)
     assert np.isfinite(heads["bfloat16"]).all() and heads["bfloat16"].min() >= 0 and heads["bfloat16"].max() <= 1
+
+
+@pytest.mark.parametrize("grid", [(9, 9), (5, 5), (7, 11)], ids=lambda g: "%dx%d" % g)
+def test_other_local_grid_sizes(golden_dir, grid):
+    """local_grid_size is a constructor argument (model.py:31-37): lastsize = 6K + E*sH*sW and the limb window change.
+    5x5 = 25 channels per edge is SHORTER than the 32-channel runs of the fused arg-max epilogue (a run then spans
+    several edges); 7x11 is not square.  f32 head vs the CPU oracle, the head conv's fused arg-max + parse == the
+    stand-alone decode of the materialised head == the NumPy decode oracle (every index, box, score)."""
+    from oracle import decode_ref, forward_ref as Fr
+    from pytorch_pose_proposal_network_amd import decode, drn, model, rt
+    g = np.load(os.path.join(golden_dir, "forward_d22_96.npz"))
+    stats = {k[3:]: g[k] for k in g.files if k.startswith("bn/")}
+    sW, sH = grid
+    nch = 6 * 18 + 17 * sW * sH
+    sd = synth.make_state_dict("drn_d_22", int(g["seed_w"]), bn_stats=stats, head_channels=nch)
+    u8 = prng.u8_frames(909, 3, (96, 96))
+    ref = Fr.forward_ref({k: np.asarray(v) for k, v in sd.items()}, torch.from_numpy(synth.normalized_frames(u8)),
+                         "drn_d_22").numpy()
+    assert ref.shape == (3, nch, 6, 6)
+    for dtype in ("float32", "bfloat16"):
+        m = model.PoseProposalNet(drn.drn_d_22(), insize=(96, 96), outsize=(6, 6), local_grid_size=grid,
+                                  compute_dtype=dtype).cuda()
+        m.load_state_dict(sd)
+        m.eval()
+        frames = torch.from_numpy(u8).cuda()
+        head = m.forward_u8(frames).clone()
+        if dtype == "float32":
+            assert np.abs(head.cpu().numpy() - ref).max() <= F32_TOL
+        fused = rt.inference_batch(frames, m).to_host()
+        alone = decode.decode_heads(head, insize_hw=(96, 96), local_grid=grid).to_host()
+        hh = head.cpu().numpy()
+        assert sum(r["n"] for r in alone) > 0
+        for i, (ra, rb) in enumerate(zip(fused, alone)):
+            want = decode_ref.decode_ref(hh[i], insize=(96, 96), local_grid=grid)
+            assert ra["n"] == rb["n"] == want["n"]
+            for k in ("kp_cell", "limb_arg", "bbox", "score"):
+                assert np.array_equal(ra[k], rb[k]), (dtype, k)
+                assert np.array_equal(rb[k], want[k][:rb["n"]] if k != "n" else want[k]), (dtype, k, "oracle")
