@@ -17,6 +17,9 @@
 // All floating-point arithmetic follows the reference's fp32 operation order; this file is
 // compiled with -ffp-contract=off so no multiply-add is fused (the IoU >= 0.3 and
 // delta < 0.15 tests are knife edges).
+#include <algorithm>
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -36,7 +39,16 @@ struct DecodeParams {
     int ncell;   // H*W
     int S;       // sH*sW
     const unsigned long long* keys;   // fused path: arg-max keys u64 [B][E][ncell] instead of the int arg-max map
+    const int* early;                 // root NMS done inside the arg-max launch (early_root_nms) or nullptr
 };
+
+// Root candidates + NMS of an image do not depend on the limb arg-max: in the stand-alone decode one workgroup per
+// image of the arg-max launch (its first, so the extra ~9 us disappear in the launch's dynamic schedule) runs them
+// BEFORE its arg-max share and leaves the survivors for the parse kernel:  early[b][0] = number kept (or -1: more than
+// kEarlyMax candidates -- a dense random head -- the parse kernel then runs the phases itself), early[b][1..] = their
+// cells in kept order.  Same device functions, same order of operations: results are identical either way.
+constexpr int kEarlyMax = 128;
+constexpr int kEarlyStride = 1 + kEarlyMax;
 
 // ------------------------------------------------------------------------------------------
 // Kernel 1: dense limb arg-max.  grid = (E, batch); thread t -> (column group q, row slice r).
@@ -61,61 +73,6 @@ __device__ __forceinline__ void vec_to_arr<4>(const float4& v, float* a) {
 template <>
 __device__ __forceinline__ void vec_to_arr<1>(const float& v, float* a) {
     a[0] = v;
-}
-
-template <int V>
-__global__ void __launch_bounds__(1024)
-limb_argmax_kernel(const float* __restrict__ head, int* __restrict__ out_arg, int C, int e_chan0, int S,
-                   int ncell, int ncl, int Q, int NS, int E) {
-    // grid = (E, batch, cell groups): a workgroup owns `ncl` consecutive cells of one (edge, image) and streams all S
-    // channels of them; cell groups only exist to cut the work finer than E*batch workgroups (smooth tail)
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* s_val = reinterpret_cast<float*>(smem);                 // [NS][ncl]
-    int* s_idx = reinterpret_cast<int*>(smem + sizeof(float) * NS * ncl);
-
-    const int edge = blockIdx.x, b = blockIdx.y, cell0 = blockIdx.z * ncl;
-    const int t = threadIdx.x;
-    const int q = t % Q, r = t / Q;
-    const float* base = head + ((size_t)b * C + e_chan0 + (size_t)edge * S) * ncell + cell0;
-    using vec = typename VecT<V>::type;
-
-    if (r < NS) {
-        float best[V];
-        int bidx[V];
-#pragma unroll
-        for (int i = 0; i < V; ++i) { best[i] = -INFINITY; bidx[i] = 0x7fffffff; }
-        if (r < S) {
-            float a[V];
-            vec_to_arr<V>(*reinterpret_cast<const vec*>(base + (size_t)r * ncell + V * q), a);
-#pragma unroll
-            for (int i = 0; i < V; ++i) { best[i] = a[i]; bidx[i] = r; }
-        }
-#pragma unroll 8
-        for (int s = r + NS; s < S; s += NS) {
-            float a[V];
-            vec_to_arr<V>(*reinterpret_cast<const vec*>(base + (size_t)s * ncell + V * q), a);
-#pragma unroll
-            for (int i = 0; i < V; ++i) {
-                if (a[i] > best[i]) { best[i] = a[i]; bidx[i] = s; }   // strict: first max within a slice
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < V; ++i) {
-            s_val[r * ncl + V * q + i] = best[i];
-            s_idx[r * ncl + V * q + i] = bidx[i];
-        }
-    }
-    __syncthreads();
-    for (int cell = t; cell < ncl; cell += blockDim.x) {
-        float bv = s_val[cell];
-        int bi = s_idx[cell];
-        for (int rr = 1; rr < NS; ++rr) {
-            float v = s_val[rr * ncl + cell];
-            int i = s_idx[rr * ncl + cell];
-            if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }     // lowest s wins ties
-        }
-        out_arg[((size_t)b * E + edge) * ncell + cell0 + cell] = bi;
-    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -233,6 +190,123 @@ __device__ __forceinline__ void greedy_nms(int n, int nwords, const float4* s_bo
     __syncthreads();
 }
 
+// Phases 1-4 of the parse (candidates, rank sort, greedy NMS) for one image, bounded to kEarlyMax candidates.
+// Called by a whole workgroup with blockDim.x >= ncell; LDS: early_lds_bytes().
+__device__ __forceinline__ void early_root_nms(const ppn_decode_cfg& c, const float* __restrict__ img, int ncell,
+                                               char* smem, int* __restrict__ out) {
+    const int t = threadIdx.x, K = c.K, W = c.W, H = c.H;
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { char* ptr = smem + off; off += (bytes + 15) & ~size_t(15); return ptr; };
+    float4* s_box = reinterpret_cast<float4*>(carve(sizeof(float4) * kEarlyMax));
+    unsigned long long* s_key = reinterpret_cast<unsigned long long*>(carve(8 * kEarlyMax));
+    unsigned long long* s_mask = reinterpret_cast<unsigned long long*>(carve(8 * kEarlyMax * (kEarlyMax / 64)));
+    float* s_area = reinterpret_cast<float*>(carve(4 * kEarlyMax));
+    int* s_cell = reinterpret_cast<int*>(carve(4 * kEarlyMax));
+    int* s_sel = reinterpret_cast<int*>(carve(4 * kEarlyMax));
+    int* s_misc = reinterpret_cast<int*>(carve(4 * 40));
+    float d0 = 0.0f;
+    bool is_c = false;
+    if (t < ncell) {
+        d0 = img[t] * img[(size_t)K * ncell + t];                     // delta of the root keypoint (rt_test.py:130)
+        is_c = d0 > c.det_thr;
+    }
+    const int pos = block_compact(is_c, s_misc, s_misc + 32);
+    const int n = s_misc[32];
+    if (n > kEarlyMax) {                                              // workgroup-uniform
+        if (t == 0) out[0] = -1;
+        return;
+    }
+    if (is_c) s_key[pos] = ((unsigned long long)(~__float_as_uint(d0)) << 32) | (unsigned)t;
+    __syncthreads();
+    if (is_c) {
+        const unsigned long long my = s_key[pos];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) rank += (s_key[j] < my) ? 1 : 0;
+        const float gridW = (float)(c.inW / W), gridH = (float)(c.inH / H);
+        const float x = img[(size_t)(2 * K) * ncell + t], y = img[(size_t)(3 * K) * ncell + t];
+        const float w = img[(size_t)(4 * K) * ncell + t], h = img[(size_t)(5 * K) * ncell + t];
+        const float X = (float)(t % W), Y = (float)(t / W);
+        const float rx = (x + X) * gridW, ry = (y + Y) * gridH;       // datatest.py:63-84, as parse_kernel::bbox_at
+        const float rw = (float)c.inW * w, rh = (float)c.inH * h;
+        float4 bb;
+        bb.x = ry - rh / 2.0f; bb.y = rx - rw / 2.0f; bb.z = ry + rh / 2.0f; bb.w = rx + rw / 2.0f;
+        s_box[rank] = bb;
+        s_area[rank] = box_area(bb);
+        s_cell[rank] = t;
+    }
+    __syncthreads();
+    greedy_nms(n, (n + 63) >> 6, s_box, s_area, s_mask, s_sel, s_misc + 33, c.nms_thr, 0);
+    const int nsel = s_misc[33];
+    if (t == 0) out[0] = nsel;
+    if (t < nsel) out[1 + t] = s_cell[s_sel[t]];
+}
+
+size_t early_lds_bytes() {
+    return 16 * kEarlyMax + 8 * kEarlyMax + 8 * kEarlyMax * (kEarlyMax / 64) + 3 * 4 * kEarlyMax + 4 * 40 + 7 * 16;
+}
+
+// ------------------------------------------------------------------------------------------
+// Kernel 1 (defined here, after the helpers its early-NMS role calls)
+// ------------------------------------------------------------------------------------------
+template <int V>
+__global__ void __launch_bounds__(1024)
+limb_argmax_kernel(const float* __restrict__ head, int* __restrict__ out_arg, int C, int e_chan0, int S,
+                   int ncell, int ncl, int Q, int NS, int E, ppn_decode_cfg cfg, int* __restrict__ early) {
+    // grid = (E, batch, cell groups): a workgroup owns `ncl` consecutive cells of one (edge, image) and streams all S
+    // channels of them; cell groups only exist to cut the work finer than E*batch workgroups (smooth tail)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* s_val = reinterpret_cast<float*>(smem);                 // [NS][ncl]
+    int* s_idx = reinterpret_cast<int*>(smem + sizeof(float) * NS * ncl);
+
+    const int edge = blockIdx.x, b = blockIdx.y, cell0 = blockIdx.z * ncl;
+    const int t = threadIdx.x;
+    if (early && edge == 0 && blockIdx.z == 0) {                   // workgroup-uniform
+        early_root_nms(cfg, head + (size_t)b * C * ncell, ncell, smem, early + (size_t)b * kEarlyStride);
+        __syncthreads();                                           // the arg-max phase reuses the LDS
+    }
+    const int q = t % Q, r = t / Q;
+    const float* base = head + ((size_t)b * C + e_chan0 + (size_t)edge * S) * ncell + cell0;
+    using vec = typename VecT<V>::type;
+
+    if (r < NS) {
+        float best[V];
+        int bidx[V];
+#pragma unroll
+        for (int i = 0; i < V; ++i) { best[i] = -INFINITY; bidx[i] = 0x7fffffff; }
+        if (r < S) {
+            float a[V];
+            vec_to_arr<V>(*reinterpret_cast<const vec*>(base + (size_t)r * ncell + V * q), a);
+#pragma unroll
+            for (int i = 0; i < V; ++i) { best[i] = a[i]; bidx[i] = r; }
+        }
+#pragma unroll 8
+        for (int s = r + NS; s < S; s += NS) {
+            float a[V];
+            vec_to_arr<V>(*reinterpret_cast<const vec*>(base + (size_t)s * ncell + V * q), a);
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+                if (a[i] > best[i]) { best[i] = a[i]; bidx[i] = s; }   // strict: first max within a slice
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            s_val[r * ncl + V * q + i] = best[i];
+            s_idx[r * ncl + V * q + i] = bidx[i];
+        }
+    }
+    __syncthreads();
+    for (int cell = t; cell < ncl; cell += blockDim.x) {
+        float bv = s_val[cell];
+        int bi = s_idx[cell];
+        for (int rr = 1; rr < NS; ++rr) {
+            float v = s_val[rr * ncl + cell];
+            int i = s_idx[rr * ncl + cell];
+            if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }     // lowest s wins ties
+        }
+        out_arg[((size_t)b * E + edge) * ncell + cell0 + cell] = bi;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // Kernel 2: per-image parse.  One workgroup per image, blockDim = 64*ceil(ncell/64).
 // ------------------------------------------------------------------------------------------
@@ -306,42 +380,57 @@ parse_kernel(DecodeParams p, const float* __restrict__ head, const int* __restri
     }
 
     PPN_DT(0);
-    // 1. candidates: delta[0] > thr, row-major (datatest.py:89)
-    float d0 = 0.0f;
-    bool is_c = false;
-    if (t < ncell) {
-        d0 = delta_at(0, t);
-        is_c = d0 > c.det_thr;
-    }
-    const int pos = block_compact(is_c, s_misc, s_misc + 32);
-    const int n = s_misc[32];
-    if (is_c) {
-        // ascending key == descending score, ties by ascending cell (documented tie rule)
-        s_key[pos] = ((unsigned long long)(~__float_as_uint(d0)) << 32) | (unsigned)t;
-    }
-    __syncthreads();
-    PPN_DT(1);
-    // 2. rank sort; boxes/areas stored in priority order
-    if (is_c) {
-        const unsigned long long my = s_key[pos];
-        int rank = 0;
-        for (int j = 0; j < n; ++j) rank += (s_key[j] < my) ? 1 : 0;
-        const float4 bb = bbox_at(0, t);
-        s_box[rank] = bb;
-        s_area[rank] = box_area(bb);
-        s_cell[rank] = t;
-    }
-    // the arg-max table has its own LDS region: park the prefetched entries there before the NMS needs registers
+    // phases 1-4 may already have run inside the arg-max launch (early_root_nms): workgroup-uniform
+    const int* early_b = p.early ? p.early + (size_t)b * kEarlyStride : nullptr;
+    const int early_n = early_b ? early_b[0] : -1;
+    int nsel;
+    if (early_n < 0) {
+        // 1. candidates: delta[0] > thr, row-major (datatest.py:89)
+        float d0 = 0.0f;
+        bool is_c = false;
+        if (t < ncell) {
+            d0 = delta_at(0, t);
+            is_c = d0 > c.det_thr;
+        }
+        const int pos = block_compact(is_c, s_misc, s_misc + 32);
+        const int n = s_misc[32];
+        if (is_c) {
+            // ascending key == descending score, ties by ascending cell (documented tie rule)
+            s_key[pos] = ((unsigned long long)(~__float_as_uint(d0)) << 32) | (unsigned)t;
+        }
+        __syncthreads();
+        PPN_DT(1);
+        // 2. rank sort; boxes/areas stored in priority order
+        if (is_c) {
+            const unsigned long long my = s_key[pos];
+            int rank = 0;
+            for (int j = 0; j < n; ++j) rank += (s_key[j] < my) ? 1 : 0;
+            const float4 bb = bbox_at(0, t);
+            s_box[rank] = bb;
+            s_area[rank] = box_area(bb);
+            s_cell[rank] = t;
+        }
+        // the arg-max table has its own LDS region: park the prefetched entries there before the NMS needs registers
 #pragma unroll
-    for (int u = 0; u < PF; ++u) {
-        const int i = t + u * pstride;
-        if (i < na) s_am[i] = (unsigned short)pf_a[u];
+        for (int u = 0; u < PF; ++u) {
+            const int i = t + u * pstride;
+            if (i < na) s_am[i] = (unsigned short)pf_a[u];
+        }
+        __syncthreads();
+        PPN_DT(2);
+        // 3./4. greedy NMS on the root boxes (datatest.py:134-160)
+        greedy_nms(n, nwords, s_box, s_area, s_mask, s_sel, s_misc + 33, c.nms_thr, 0);
+        nsel = s_misc[33];
+    } else {
+        PPN_DT(1);
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int i = t + u * pstride;
+            if (i < na) s_am[i] = (unsigned short)pf_a[u];
+        }
+        PPN_DT(2);
+        nsel = early_n;
     }
-    __syncthreads();
-    PPN_DT(2);
-    // 3./4. greedy NMS on the root boxes (datatest.py:134-160)
-    greedy_nms(n, nwords, s_box, s_area, s_mask, s_sel, s_misc + 33, c.nms_thr, 0);
-    const int nsel = s_misc[33];
     PPN_DT(3);
 
     // 5. one lane per surviving root: tree walk through the arg-max map (datatest.py:103-127).
@@ -349,7 +438,7 @@ parse_kernel(DecodeParams p, const float* __restrict__ head, const int* __restri
     // (keypoint, cell) and this image's arg-max map -- are first staged in LDS with coalesced loads.
     const unsigned short NONE = 0xFFFFu;
     int root_cell = 0;
-    if (t < nsel) root_cell = s_cell[s_sel[t]];
+    if (t < nsel) root_cell = early_n < 0 ? s_cell[s_sel[t]] : early_b[1 + t];
     __syncthreads();                                                  // everyone is done with box/key/mask
     if (nsel > 0) {
         // the first PF entries per thread are already in registers; larger grids finish with batched loads
@@ -539,11 +628,13 @@ int check_cfg(const ppn_decode_cfg* c) {
 
 extern "C" size_t ppn_decode_workspace_bytes(const ppn_decode_cfg* cfg, int32_t batch) {
     if (!cfg || batch < 0) return 0;
-    return (size_t)batch * cfg->E * cfg->H * cfg->W * sizeof(int32_t);
+    // the arg-max map + the early root-NMS lists (kEarlyStride ints per image)
+    return (size_t)batch * cfg->E * cfg->H * cfg->W * sizeof(int32_t) + (size_t)batch * kEarlyStride * sizeof(int32_t);
 }
 
-extern "C" int ppn_limb_argmax(const ppn_decode_cfg* cfg, const float* head, int32_t batch, int32_t* out_arg,
-                               void* stream) {
+static int launch_limb_argmax(const ppn_decode_cfg* cfg, const float* head, int32_t batch, int32_t* out_arg,
+                              int32_t* early, void* stream, bool* early_used) {
+    if (early_used) *early_used = false;
     if (int rc = check_cfg(cfg)) return rc;
     if (batch == 0 || cfg->E == 0) return PPN_OK;
     if (!head || !out_arg || batch < 0) return ppn::fail(PPN_E_INVALID, "ppn_limb_argmax: NULL pointer or batch<0");
@@ -564,7 +655,11 @@ extern "C" int ppn_limb_argmax(const ppn_decode_cfg* cfg, const float* head, int
     if (NS > S) NS = S;
     int threads = ((NS * Q + 63) / 64) * 64;
     if (threads > 1024) { NS = 1024 / Q; threads = ((NS * Q + 63) / 64) * 64; }
-    const size_t lds = (size_t)NS * ncl * 8;
+    // the early root-NMS role needs one thread per cell and its own (small) LDS carve
+    static const bool early_off = getenv("PPN_DECODE_EARLY_NMS") && atoi(getenv("PPN_DECODE_EARLY_NMS")) == 0;
+    if (early_off || threads < ncell) early = nullptr;
+    if (early_used) *early_used = early != nullptr;
+    const size_t lds = std::max((size_t)NS * ncl * 8, early ? early_lds_bytes() : (size_t)0);
     if (lds > 160 * 1024) return ppn::fail(PPN_E_UNSUPPORTED, "limb_argmax LDS %zu too large", lds);
     dim3 grid(cfg->E, batch, CS);
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -575,7 +670,7 @@ extern "C" int ppn_limb_argmax(const ppn_decode_cfg* cfg, const float* head, int
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         }
         hipLaunchKernelGGL(limb_argmax_kernel<4>, grid, dim3(threads), lds, st, head, out_arg, C, 6 * cfg->K, S,
-                           ncell, ncl, Q, NS, cfg->E);
+                           ncell, ncl, Q, NS, cfg->E, *cfg, early);
     } else {
         {
             static int max_lds_set = 0;   // the attribute sticks to the function: set it when it grows
@@ -583,10 +678,15 @@ extern "C" int ppn_limb_argmax(const ppn_decode_cfg* cfg, const float* head, int
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         }
         hipLaunchKernelGGL(limb_argmax_kernel<1>, grid, dim3(threads), lds, st, head, out_arg, C, 6 * cfg->K, S,
-                           ncell, ncl, Q, NS, cfg->E);
+                           ncell, ncl, Q, NS, cfg->E, *cfg, early);
     }
     PPN_LAUNCH_CHECK();
     return PPN_OK;
+}
+
+extern "C" int ppn_limb_argmax(const ppn_decode_cfg* cfg, const float* head, int32_t batch, int32_t* out_arg,
+                               void* stream) {
+    return launch_limb_argmax(cfg, head, batch, out_arg, nullptr, stream, nullptr);
 }
 
 extern "C" int ppn_decode(const ppn_decode_cfg* cfg, const float* head, int32_t batch, void* workspace,
@@ -605,13 +705,16 @@ extern "C" int ppn_decode(const ppn_decode_cfg* cfg, const float* head, int32_t 
     if (ncell > 1024 || lds > 160 * 1024)
         return ppn::fail(PPN_E_UNSUPPORTED, "grid of %d cells needs %zu B of LDS (max 163840)", ncell, lds);
     int32_t* argmap = static_cast<int32_t*>(workspace);
-    if (int rc = ppn_limb_argmax(cfg, head, batch, argmap, stream)) return rc;
+    int32_t* early = argmap + (size_t)batch * cfg->E * ncell;
+    bool early_used = false;
+    if (int rc = launch_limb_argmax(cfg, head, batch, argmap, cfg->E > 0 ? early : nullptr, stream, &early_used)) return rc;
     DecodeParams p;
     p.c = *cfg;
     p.ncell = ncell;
     p.S = cfg->sH * cfg->sW;
     p.C = 6 * cfg->K + cfg->E * p.S;
     p.keys = nullptr;
+    p.early = early_used ? early : nullptr;
     const int threads = ((ncell + 63) / 64) * 64;
     {
         static int max_lds_set = 0;   // the attribute sticks to the function: set it when it grows
@@ -645,6 +748,7 @@ extern "C" int ppn_decode_fused(const ppn_decode_cfg* cfg, const float* unary, c
     p.S = cfg->sH * cfg->sW;
     p.C = 6 * cfg->K;                                                 // compact unary tensor
     p.keys = reinterpret_cast<const unsigned long long*>(keys);
+    p.early = nullptr;
     const int threads = ((ncell + 63) / 64) * 64;
     {
         static int max_lds_set = 0;

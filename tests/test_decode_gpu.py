@@ -184,3 +184,28 @@ def test_device_decode_feeds_ap_evaluation():
     print("AP from the device decode:", np.round(ap_dev, 3).tolist())
     assert np.array_equal(ap_dev, ap_ref, equal_nan=True)
     assert np.isfinite(ap_dev[-1]) and 0.0 < ap_dev[-1] <= 100.0
+
+
+def test_early_root_nms_candidate_cap_boundary():
+    """The stand-alone decode runs candidates + root NMS inside the arg-max launch for images with <= 128 root
+    candidates and inside the parse kernel beyond that (csrc/decode.hip early_root_nms).  One batch mixing images with
+    0, 1, 127, 128, 129, 200 and 576 candidates (random heads whose root delta is pushed under the threshold except in
+    the chosen cells): every image equals the NumPy oracle whichever kernel ran its NMS."""
+    dec = _decode_mod()
+    counts = [0, 1, 127, 128, 129, 200, 576, 64]
+    heads = []
+    for i, n in enumerate(counts):
+        h = make_head("random", 700 + i)
+        g = np.random.default_rng(900 + i)
+        cells = g.permutation(576)[:n]
+        resp = np.full(576, 0.05, np.float32)                    # delta = resp * conf stays far below 0.15
+        resp[cells] = g.uniform(0.6, 1.0, n).astype(np.float32)   # distinct scores
+        h[0] = resp.reshape(24, 24)
+        h[18] = np.float32(0.9)                                   # conf of the root keypoint
+        heads.append(h)
+    heads = np.stack(heads)
+    out = dec.decode_heads(torch.from_numpy(heads).cuda()).to_host()
+    for i, n in enumerate(counts):
+        exp = D.decode_ref(heads[i])
+        assert len(exp["cand"]) == n, (i, len(exp["cand"]), n)
+        _assert_same(out[i], exp, f"{n} candidates")
