@@ -63,23 +63,28 @@ def timed(jobs):
     return (time.perf_counter() - t0) * 1e3
 
 
-sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
-host = conv_job(512, 512, 48, 3, 1, 2)
-guests = {"copy 75 MB (torch)": (copy_job(75), 60), "conv 64->64 3x3 96x96 (128x64 tile)": (conv_job(64, 64, 96, 3, 1, 1), 60)}
-NH = 20
-for _ in range(3):
-    host(sa)
-torch.cuda.synchronize()
-t_host = min(timed([(host, sa, NH)]) for _ in range(3))
-print(f"host alone: {NH} launches {t_host:.3f} ms ({t_host / NH * 1e3:.1f} us each)")
-for name, (g, ng) in guests.items():
+def main():
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    host = conv_job(512, 512, 48, 3, 1, 2)
+    guests = {"copy 75 MB (torch)": (copy_job(75), 60), "conv 64->64 3x3 96x96 (128x64 tile)": (conv_job(64, 64, 96, 3, 1, 1), 60)}
+    NH = 20
     for _ in range(3):
-        g(sb)
+        host(sa)
     torch.cuda.synchronize()
-    t_g = min(timed([(g, sb, ng)]) for _ in range(3))
-    ng2 = max(1, int(ng * t_host / t_g))           # about as long as the host batch
-    t_g = min(timed([(g, sb, ng2)]) for _ in range(3))
-    t_serial = min(timed([(host, sa, NH), (g, sa, ng2)]) for _ in range(3))
-    t_both = min(timed([(host, sa, NH), (g, sb, ng2)]) for _ in range(3))
-    print(f"{name}: alone {ng2} x {t_g / ng2 * 1e3:.1f} us = {t_g:.3f} ms | one stream {t_serial:.3f} ms | two streams "
-          f"{t_both:.3f} ms  -> overlap hides {100 * (t_host + t_g - t_both) / min(t_host, t_g):.0f} % of the shorter job")
+    t_host = min(timed([(host, sa, NH)]) for _ in range(3))
+    print(f"host alone: {NH} launches {t_host:.3f} ms ({t_host / NH * 1e3:.1f} us each)")
+    for name, (g, ng) in guests.items():
+        for _ in range(3):
+            g(sb)
+        torch.cuda.synchronize()
+        t_g = min(timed([(g, sb, ng)]) for _ in range(3))
+        ng2 = max(1, int(ng * t_host / t_g))           # about as long as the host batch
+        t_g = min(timed([(g, sb, ng2)]) for _ in range(3))
+        t_serial = min(timed([(host, sa, NH), (g, sa, ng2)]) for _ in range(3))
+        t_both = min(timed([(host, sa, NH), (g, sb, ng2)]) for _ in range(3))
+        print(f"{name}: alone {ng2} x {t_g / ng2 * 1e3:.1f} us = {t_g:.3f} ms | one stream {t_serial:.3f} ms | two streams "
+              f"{t_both:.3f} ms  -> overlap hides {100 * (t_host + t_g - t_both) / min(t_host, t_g):.0f} % of the shorter job")
+
+
+if __name__ == "__main__":
+    main()
