@@ -1,0 +1,55 @@
+"""Race / determinism screen of the kernels whose synchronisation structure is new in round 2 (run on the GPU box):
+  * csrc/stem012.hip (persistent workgroups, LDS rings, LDS-DMA one chunk ahead): the network with the fused stem must
+    equal the network with the three stem launches BIT FOR BIT, at several sizes, and 25 repeated forwards of the same
+    frames must all be identical (a read that races a DMA shows up as rare differing tiles);
+  * csrc/decode.hip early_root_nms (root NMS inside the arg-max launch): 96 heads (crowds and dense random heads) vs the
+    NumPy oracle, five times over.
+Prints one line per check; exits non-zero on the first mismatch."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+from pytorch_pose_proposal_network_amd import decode, drn, model, prng, rt, synth
+from oracle import decode_ref as D
+
+torch.set_num_threads(min(16, os.cpu_count() or 1))
+g = np.load(os.path.join(ROOT, "pytorch_pose_proposal_network_amd", "data", "bn_calib_drn_d_22_seed0.npz"))
+sd = synth.make_state_dict("drn_d_22", 0, bn_stats={k: g[k] for k in g.files})
+
+
+def net(size_hw, fuse):
+    h, w = size_hw
+    m = model.PoseProposalNet(drn.drn_d_22(), insize=(w, h), outsize=(w // 16, h // 16), compute_dtype="bfloat16",
+                              fuse_stem=fuse).cuda()
+    m.load_state_dict(sd)
+    return m.eval()
+
+
+for (h, w), B in (((384, 384), 32), ((256, 320), 5), ((96, 96), 7), ((400, 272), 3)):
+    frames = torch.from_numpy(prng.u8_frames(31 + h, B, (h, w))).cuda()
+    a, b = net((h, w), "all"), net((h, w), False)
+    ha = a.forward_u8(frames).clone()
+    hb = b.forward_u8(frames).clone()
+    assert torch.equal(ha, hb), f"fused stem != three launches at {h}x{w}"
+    first = rt.inference_batch(frames, a).to_host()
+    for rep in range(25):
+        assert torch.equal(a.forward_u8(frames), ha), f"forward {rep} differs at {h}x{w}"
+        res = rt.inference_batch(frames, a).to_host()
+        for x, y in zip(res, first):
+            assert x["n"] == y["n"] and all(np.array_equal(x[k], y[k]) for k in ("kp_cell", "limb_arg", "bbox", "score"))
+    print(f"stem012 {h}x{w} batch {B}: fused == three launches, 25 repeats identical, people {sum(r['n'] for r in first)}", flush=True)
+    del a, b
+
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from test_oracle import make_head  # noqa: E402
+heads = np.stack([synth.planted_crowd_head(100 + i) for i in range(64)] + [make_head("random", 300 + i) for i in range(32)])
+exp = [D.decode_ref(hd) for hd in heads]
+hd_dev = torch.from_numpy(heads).cuda()
+for rep in range(5):
+    out = decode.decode_heads(hd_dev).to_host()
+    for i, (r, e) in enumerate(zip(out, exp)):
+        assert r["n"] == int(e["n"]), (rep, i)
+        for k in ("root_cell", "kp_cell", "limb_arg", "bbox", "score"):
+            assert np.array_equal(r[k], e[k]), (rep, i, k)
+print(f"decode: 96 heads x 5 repeats == oracle ({sum(int(e['n']) for e in exp)} people, "
+      f"{sum(1 for e in exp if len(e['cand']) > 128)} heads over the early-NMS cap)")
