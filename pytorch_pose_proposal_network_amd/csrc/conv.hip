@@ -475,7 +475,7 @@ int ppn::conv_launch(const ppn_conv_desc* d, hipStream_t st, const char** kname)
     const long long m = m_hi - m_lo;                                  // pixels of THIS launch: the tile is chosen for them
     TileChoice tc = choose_tile(d->cout);
     BigTile bt{0, 0};
-    const bool big = !smallc && big_tile_for(d->cout, m, &bt);
+    const bool big = !smallc && big_tile_for(d->cout, m, &bt, kpad / bk);
     const int bc = big ? bt.bc : tc.bc, bp = big ? bt.bp : tc.bp;
     if (d->cout_pad % bc != 0 || d->cout_pad < d->cout)
         return ppn::fail(PPN_E_INVALID, "cout_pad %d must be a multiple of %d and >= cout", d->cout_pad, bc);

@@ -800,7 +800,7 @@ static bool tile_shape_ok(int bp, int bc) {
     return (bp == 128 || bp == 192 || bp == 256) && (bc == 64 || bc == 128 || bc == 256) && !(bc == 64 && bp == 192);
 }
 
-bool big_tile_for(int cout, long long m, BigTile* out) {
+bool big_tile_for(int cout, long long m, BigTile* out, int ksteps) {
     if (cout < 64) return false;
     if (g_ov_bp < 0) {                                   // first call: the environment knob
         g_ov_bp = g_ov_bc = 0;
@@ -827,8 +827,12 @@ bool big_tile_for(int cout, long long m, BigTile* out) {
     struct Cand { int bp, bc; double eff; };
     static const Cand cands[] = {{256, 256, 1.27}, {192, 256, 1.10}, {128, 256, 0.92}, {256, 128, 0.90},
                                  {192, 128, 0.95}, {128, 128, 0.87}, {256, 64, 0.60},  {128, 64, 0.55}};
-    const int bc_max = cout >= 256 ? 256 : (cout >= 128 ? 128 : 64);
+    int bc_max = cout >= 256 ? 256 : (cout >= 128 ? 128 : 64);
     const int bc_min = cout >= 256 ? 128 : bc_max;
+    // 1x1 projections (<= 8 K steps) are prologue/epilogue-bound: the 128-channel tile's shorter epilogue wins over the
+    // 256-channel tile's staging efficiency (tools/ab_tiles.py: 256->512 at 48x48 32.5 vs 38.4 us, 512->512 stride 2
+    // 15.9 vs 17.1, 128->512 at 24x24 10.7 vs 11.6)
+    if (ksteps > 0 && ksteps <= 8 && bc_max == 256) bc_max = 128;
     double best = 1e30;
     for (const Cand& cd : cands) {
         if (cd.bc > bc_max || cd.bc < bc_min) continue;

@@ -392,7 +392,7 @@ def test_conv_split_plan_and_automatic_two_segment_launch():
     """Tile policy 2 (opt-in; measured slower end to end, conv_big.hip::big_split_for): ppn_conv_split reports where the
     launcher cuts the pixel range (whole rounds of 256x256 tiles, then one round of a small tile), a whole-tensor
     ppn_conv2d_fused at such a size performs the two launches itself and equals the same conv forced onto a single
-    192x256 launch; under the default policy nothing is cut.  512 -> 512 1x1 at 32 x 48 x 48 (M = 73 728)."""
+    192x256 launch; under the default policy nothing is cut.  128 -> 512 3x3 at 32 x 48 x 48 (M = 73 728)."""
     import ctypes as C
     from pytorch_pose_proposal_network_amd import lib as L
     lib = L.load()
@@ -400,9 +400,9 @@ def test_conv_split_plan_and_automatic_two_segment_launch():
     L.check(lib.ppn_conv_split(L.PPN_BF16, 512, 512, 73728, C.byref(cut)), "ppn_conv_split")
     assert cut.value == 0
     dtype = L.PPN_BF16
-    B, Cin, H, W, Cout = 32, 512, 48, 48, 512
+    B, Cin, H, W, Cout = 32, 128, 48, 48, 512                      # 3x3: 18 K steps (1x1 layers take 128-channel tiles)
     x = q(rnd(B, Cin, H, W, seed=81), dtype)
-    w = q(rnd(Cout, Cin, 1, 1, seed=82, scale=(2.0 / Cin) ** 0.5), dtype)
+    w = q(rnd(Cout, Cin, 3, 3, seed=82, scale=(2.0 / (9 * Cin)) ** 0.5), dtype)
     b1 = rnd(Cout, seed=83, scale=0.3)
     info = {}
     L.check(lib.ppn_set_conv_tile_policy(2), "ppn_set_conv_tile_policy")
@@ -411,12 +411,12 @@ def test_conv_split_plan_and_automatic_two_segment_launch():
                                    (512, 512, 18432, 0), (512, 7605, 18432, 0), (512, 512, 4608, 0)]:
             L.check(lib.ppn_conv_split(L.PPN_BF16, cin, cout, m, C.byref(cut)), "ppn_conv_split")
             assert cut.value == want, (cin, cout, m, cut.value)
-        auto, _ = run_conv(x, w, dtype, b1=b1, act1=1, info=info)
+        auto, _ = run_conv(x, w, dtype, 1, 1, 1, b1=b1, act1=1, info=info)
     finally:
         L.check(lib.ppn_set_conv_tile_policy(0), "ppn_set_conv_tile_policy")
     print(info["kernels"])
     assert info["kernel"] == _kname("bf16", 256, 256)            # the first of the two launches
-    single, _ = run_conv(x, w, dtype, b1=b1, act1=1, ranges=[(0, 0, (192, 256))])
+    single, _ = run_conv(x, w, dtype, 1, 1, 1, b1=b1, act1=1, ranges=[(0, 0, (192, 256))])
     assert not torch.isnan(auto).any() and torch.equal(auto, single)
 
 
