@@ -102,9 +102,28 @@ def test_train_step_updates(dtype_name):
     torch.cuda.synchronize()
     tol = 2e-4 if dtype_name == "f32" else 3e-2
     assert np.allclose(losses.cpu().numpy(), g["losses"], rtol=tol)
-    # G_i carry the f32 noise of this network (see module docstring); the weights move by at most lr_w per step
-    assert np.allclose(tr.task.log[:5].cpu().numpy(), g["G_f64"], rtol=0.15 if dtype_name == "f32" else 0.3)
-    assert np.allclose(w.cpu().numpy(), g["w_final"], atol=2e-3 if dtype_name == "f32" else 2e-2)
+    # G_i = w_i * ||dL_i/dW|| carry the f32 rounding noise of this network (see module docstring): the bound is the
+    # oracle's own f32-vs-f64 distance on the same quantity, as for the gradients above -- not a flat percentage
+    from oracle import train_ref
+    torch.set_num_threads(8)
+    r64 = train_ref.train_iteration_ref(sd, x, tg, g["w_before"], g["base"], "drn_d_22", (size, size), float(g["alpha"]))
+    r32 = train_ref.train_iteration_ref(sd, x, tg, g["w_before"], g["base"], "drn_d_22", (size, size), float(g["alpha"]),
+                                        dtype=torch.float32)
+    noise = np.abs(r32["gnorm"] - r64["gnorm"]) / r64["gnorm"]
+    G = tr.task.log[:5].cpu().numpy().astype(np.float64)
+    relG = np.abs(G - g["G_f64"]) / g["G_f64"]
+    print(f"{dtype_name}: |G - G_f64| / G_f64 = {[float('%.2e' % v) for v in relG]}, oracle f32-vs-f64 noise "
+          f"{[float('%.2e' % v) for v in noise]}")
+    # measured: f32 < 1e-4 on every G_i (the NORMS are far less noisy than single gradient entries), bf16 0.4-1.8 %
+    if dtype_name == "f32":
+        assert np.all(relG <= np.maximum(3 * noise, 1e-4)), (relG, noise)
+    else:
+        assert np.all(relG <= 0.05), relG
+    dw = np.abs(w.cpu().numpy() - g["w_final"]).max()
+    print(f"{dtype_name}: max |w - w_final| = {dw:.2e}")
+    # measured 1.2e-7 in both modes: Adam's first step moves every w_i by exactly lr_w (2.5e-2) in the direction of
+    # sign(dLgrad/dw_i), so this line checks the SIGNS of the GradNorm weight gradient and the renormalisation
+    assert dw <= 1e-5
     assert abs(float(w.mean().cpu()) - 1.0) < 1e-6
     # Adam, step 1: |delta| = lr * |g| / (|g| + eps) <= lr, and == lr wherever the gradient is not tiny
     delta = (tr.flat - p0).abs()
