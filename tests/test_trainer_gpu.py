@@ -428,11 +428,11 @@ def test_train_step_at_full_size_batch32_384():
     a, b, f = runs["bf16_a"], runs["bf16_b"], runs["f32"]
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
     print("losses bf16", a[0].numpy().round(4).tolist(), "f32", f[0].numpy().round(4).tolist())
-    assert torch.allclose(a[0], f[0], rtol=3e-2)
+    assert torch.allclose(a[0], f[0], rtol=1e-2)                 # measured: 0.4 % at most
     gn_a, gn_f = float(a[1].double().norm()), float(f[1].double().norm())
     cos = float((a[1].double() @ f[1].double()) / (gn_a * gn_f))
     print(f"|grad| bf16 {gn_a:.4e} f32 {gn_f:.4e} cos {cos:.4f}")
-    assert abs(gn_a / gn_f - 1.0) < 0.15 and cos > 0.8
+    assert abs(gn_a / gn_f - 1.0) < 0.02 and cos > 0.93          # measured: ratio 0.9997, cosine 0.961
 
 
 def test_bf16_limb_probe_by_linearity_vs_direct_pass():
