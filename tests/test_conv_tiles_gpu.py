@@ -219,6 +219,10 @@ FULL = [
     ("L3_c2_64_96x96",         32, 64, 64, 96, 96, 3, 1, 1, 1, None),
     ("B1_c1_512_s2_24x24",     32, 512, 512, 48, 48, 3, 2, 1, 1, (192, 256)),
     ("ragged_M_31",            31, 512, 512, 47, 45, 3, 1, 2, 2, None),
+    # layer3's first block on the 32-channel stem output (bf16: the small-channel kernel of csrc/conv.hip) at full size
+    ("L3_c1_32_64_s2_192",     32, 32, 64, 192, 192, 3, 2, 1, 1, None),
+    ("L3_ds_32_64_1x1_s2",     32, 32, 64, 192, 192, 1, 2, 1, 0, None),
+    ("c32_5x5_d2_ragged",      3, 32, 96, 45, 51, 5, 1, 2, 4, None),
 ]
 
 
@@ -243,6 +247,7 @@ def test_full_size_layer_sampled(case, dtype_name):
     print(name, dtype_name, "M =", M, info["kernel"])
     if want is not None:
         assert info["kernel"] == _kname(dtype_name, *want)
+
     got = raw.permute(0, 2, 3, 1).reshape(M, Cout)[rows].double()
     ref = torch.relu(acc * s1.double() + b1.double())
     tol = (F32_TOL if dtype_name == "f32" else BF16_TOL) * max(1.0, float(ref.abs().max()))
