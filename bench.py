@@ -109,6 +109,13 @@ def cpu_baseline_train(arch, size):
                       f"(train-mode forward, loss, backward, 5 GradNorm probe gradients), {dt:.1f} s"}
 
 
+def _fail_hook(rank):
+    """Test hook (tests/test_bench_child_gpu.py): PPN_BENCH_FAIL_RANK=r makes rank r raise after the process group is
+    up, to prove that a failing rank fails the whole run (non-zero exit, no JSON line) instead of hanging it."""
+    if os.environ.get("PPN_BENCH_FAIL_RANK") == str(rank):
+        raise RuntimeError(f"PPN_BENCH_FAIL_RANK: rank {rank} fails on request")
+
+
 def main_train(args):
     """--workload train: BASELINE configs[3] per-GPU shard -- one PPNTrainer.train_step per step (train-mode forward,
     PPNLoss fwd+bwd, backward, GradNorm probes + task-weight step, gradient all-reduce over RCCL, Adam)."""
@@ -130,6 +137,7 @@ def main_train(args):
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+    _fail_hook(rank)
     B, S = args.batch, args.size
     tr = PPNTrainer(args.arch, synth.make_state_dict(args.arch, 0),
                     compute_dtype=L.PPN_BF16 if args.dtype == "bf16" else L.PPN_F32, insize=(S, S), device=dev,
@@ -194,7 +202,9 @@ def _people_equal(a, b):
 def verify_against_slices(net, frames, out):
     """Outside the timed region: the last step's people lists (batch B, the tile instantiations the timed steps ran)
     must equal, bit for bit, what B/2 independent batch-2 passes return (frames are independent units; the batch-2
-    path is the one the golden-vector tests pin to the reference).  Returns the `verified` object of the JSON line."""
+    path is the one the golden-vector tests pin to the reference).  Returns the `batch_consistency` object of the JSON
+    line: SELF-consistency of the benchmarked dtype, not parity with the reference -- that is `reference_agreement`
+    (printed inside the same object) and the f32 parity mode."""
     from pytorch_pose_proposal_network_amd import rt
     if getattr(out, "ready", None) is not None:
         out.ready.synchronize()
@@ -206,7 +216,8 @@ def verify_against_slices(net, frames, out):
         for j in range(2):
             if not _people_equal(full[i + j], part[j]):
                 bad.append(i + j)
-    return {"check": f"last timed step's decode result == {B // 2} independent batch-2 passes (every index, box, score)",
+    return {"check": f"last timed step's decode result == {B // 2} independent batch-2 passes of the SAME dtype (every "
+                     "index, box, score): self-consistency of the timed path, not parity with the reference",
             "frames": B, "people": int(sum(r["n"] for r in full)), "mismatching_frames": bad, "ok": not bad}
 
 
@@ -298,6 +309,7 @@ def extra_sections(args, dev, net, frames, dec):
         fl = A.conv_flops(A.build_program("drn_d_54"), S, S) * B
         return {"what": f"DRN-D-54 (Bottleneck trunk) end to end, bf16, batch {B}, fused decode, one lane (throughput only: on "
                         "this random checkpoint bf16 D-54 finds other people than f32 D-54, tests/test_fullsize_gpu.py)",
+                "task_equivalent": False,
                 "images_per_sec": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 3),
                 "tflops": round(fl / dt / 1e12, 1), "frac_of_mfma_peak": round(fl / dt / 1e12 / BF16_DENSE_PEAK_TFLOPS, 4)}
 
@@ -333,7 +345,35 @@ def extra_sections(args, dev, net, frames, dec):
                 "keypoint_cells_compared": kp_all, "same_root_frac": round(same / max(n, 1), 4),
                 "keypoint_cell_agreement": round(kp_eq / max(kp_all, 1), 4)}
 
+    def ap_vs_reference():
+        # what the reduced-precision modes cost in the TASK metric: the reference pipeline's people (fixture) taken as
+        # ground truth, the HIP pipeline's people scored with the reference's own matcher/metric (evaluate.evaluation ==
+        # datatest.evaluation).  `self` = the reference people scored against themselves: the metric's ceiling on these
+        # dense synthetic crowds (overlapping people tie in the matcher), NOT 100.
+        from pytorch_pose_proposal_network_amd import evaluate
+        g = np.load(os.path.join(ROOT, "tests", "golden", "e2e_d22_384.npz"))
+        nb, sz = int(g["batch"]), int(g["size"])
+        if args.arch != str(g["arch"]) or S != sz:
+            return {"skipped": "fixture is drn_d_22 384x384"}
+        fr = torch.from_numpy(prng.u8_frames(int(g["seed_in"]), nb, (sz, sz))).to(dev)
+        exp = [{k: g[f"{i}/{k}"] for k in ("n", "kp_cell", "limb_arg", "bbox", "score")} for i in range(nb)]
+        names = ["head", "shoulder", "elbow", "wrist", "hip", "knee", "ankle", "total"]
+        res = {"what": "8 AP values (datatest.evaluation's metric, PCKh@0.5 matching) of each mode's people on the 8 "
+                       "calibrated frames, the reference pipeline's 260 people as ground truth (keypoint = box centre, "
+                       "head box = instance box)", "order": names,
+               "self": [round(v, 2) for v in evaluate.ap_against_people(exp, exp)]}
+        for mode in ("float32", "bfloat16") + (("float16",) if hasattr(L, "PPN_F16") else ()):
+            n_ = model.PoseProposalNet(getattr(drn, args.arch)(), insize=(S, S), outsize=(S // 16, S // 16),
+                                       compute_dtype=mode).cuda(dev)
+            n_.load_state_dict(net.state_dict())
+            got = rt.inference_batch(fr, n_).to_host()
+            res[{"float32": "f32", "bfloat16": "bf16", "float16": "f16"}[mode]] = \
+                [round(v, 2) for v in evaluate.ap_against_people(exp, got)]
+            del n_
+        return res
+
     section("bf16_agreement", bf16_agreement)
+    section("ap_vs_reference", ap_vs_reference)
     section("materialized_head", materialized)
     section("decode_stress", decode_stress)
     section("f32_parity_mode", f32_mode)
@@ -381,13 +421,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--windows", type=int, default=10,
+                    help="timing windows of --steps steps each (the first is `value`; all go into `value_windows`)")
     ap.add_argument("--batch", type=int, default=32, help="frames per GPU")
     ap.add_argument("--size", type=int, default=384)
     ap.add_argument("--arch", default="drn_d_22")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true",
-                    help="skip the output check of the last timed step (profiling runs: its batch-2 passes would mix "
+                    help="skip the batch-consistency check of the last timed step (profiling runs: its batch-2 passes would mix "
                          "other kernel instantiations into the per-kernel statistics)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the extra sections (materialized_head, decode_stress, f32_parity_mode, d54_end_to_end, "
@@ -435,12 +477,16 @@ def main():
 
     from pytorch_pose_proposal_network_amd import decode, drn, model
 
+    _fail_hook(rank)
     B, S = args.batch, args.size
     net = model.PoseProposalNet(getattr(drn, args.arch)(), insize=(S, S), outsize=(S // 16, S // 16),
                                 compute_dtype="bfloat16" if args.dtype == "bf16" else "float32").cuda(dev)
     net.load_state_dict(synth.make_state_dict(args.arch, 0, bn_stats=load_bn_stats(args.arch)))
     net.eval()
-    frames = torch.from_numpy(prng.u8_frames(1234 + rank, B, (S, S))).to(dev)      # resident in HBM
+    # resident in HBM: NROT distinct batches, step i reads batch i % NROT (no step re-reads its predecessor's frames)
+    NROT = 3
+    frame_sets = [torch.from_numpy(prng.u8_frames(1234 + rank + 7919 * j, B, (S, S))).to(dev) for j in range(NROT)]
+    frames = frame_sets[0]
     dec = decode.Decoder(B, (S // 16, S // 16), (S, S), device=dev)
 
     fused = not args.materialize_head
@@ -450,13 +496,17 @@ def main():
         pipe = rt.MultiLaneInference(net, B, (S, S), device=dev, lanes=max(1, args.lanes),
                                      tile_policy=args.tile_policy)
 
+    step_no = [0]
+
     def step():
+        fr = frame_sets[step_no[0] % NROT]
+        step_no[0] += 1
         if pipe is not None:   # conv stack of step i+1 overlaps the NMS/limb-parse kernel of step i (side stream)
-            return pipe.submit(frames)
+            return pipe.submit(fr)
         if fused:       # rt_test.inference path: the head conv's epilogue runs the limb arg-max, no head tensor
-            unary, keys = net.forward_u8(frames, fused_decode=True)
+            unary, keys = net.forward_u8(fr, fused_decode=True)
             return dec.decode_fused(unary, keys)
-        head = net.forward_u8(frames)
+        head = net.forward_u8(fr)
         return dec(head)
 
     if pipe is not None:            # set-up, not measurement: every lane's plan reaches its captured-graph state
@@ -485,11 +535,44 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = world * B * args.steps / dt
     people = int(out.count.sum().item())
+    last_frames = frame_sets[(step_no[0] - 1) % NROT]            # what the last timed step read
+    if fused and rank == 0 and not args.no_verify:
+        # `out` lives in its lane's / decoder's buffers: read it before the extra timing windows below reuse them
+        if getattr(out, "ready", None) is not None:
+            out.ready.synchronize()
+        out_host_early = out.to_host()
+    else:
+        out_host_early = None
+    # ---- the same K-step window nine more times (every rank takes part: the fences are collective) --------------
+    # `value` stays the FIRST window (the contract's exactly-K timed steps); `value_windows` says how representative
+    # that one ~60 ms window is.
+    win = [dt]
+    for _ in range(0 if args.windows < 2 else args.windows - 1):
+        fence()
+        t0w = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        dtw = time.perf_counter() - t0w
+        if dist is not None:
+            t = torch.tensor([dtw], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dtw = float(t.item())
+        win.append(dtw)
+    win_vals = sorted(world * B * args.steps / w for w in win)
 
     result = None
     if rank == 0:
         # the people lists of the last timed step, checked before anything else reuses the lanes' buffers
-        verified = verify_against_slices(net, frames, out) if (fused and B % 2 == 0 and not args.no_verify) else None
+        if out_host_early is not None:
+            class _Held:                               # the early host copy of the last timed step's result
+                ready = None
+
+                @staticmethod
+                def to_host():
+                    return out_host_early
+            out = _Held
+        verified = verify_against_slices(net, last_frames, out) if (fused and B % 2 == 0 and not args.no_verify) else None
         # ---- per-kernel durations: HIP events on the launch stream around every launch ----------------
         # per-launch durations with one launch in flight (what rocprofv3 shows for `--lanes 1`)
         # Primary figures: every launch ONCE in plan order (in sequence: each launch finds the caches as the previous
@@ -547,12 +630,23 @@ def main():
             "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "lanes": (max(1, args.lanes) if pipe is not None else 1),
+            "value_windows": {"what": f"{len(win)} consecutive windows of {args.steps} steps each, same fences; `value` "
+                                      "is the first", "n": len(win), "min": round(win_vals[0], 2),
+                              "median": round(win_vals[len(win_vals) // 2], 2), "max": round(win_vals[-1], 2)},
             "config": {"workload": f"{args.arch} PPN inference {args.dtype}, batch {B}/GPU synthetic {S}x{S} u8 frames: "
                                    "fused normalise + conv stack + head + decode/NMS/limb-parse (BASELINE configs[1])"
                                    + ("" if fused else ", head tensor materialised")
                                    + (f", batches go round-robin over {max(1, args.lanes)} stream lanes (rt.MultiLaneInference)"
                                       if pipe is not None else ""),
-                       "frames_per_gpu": B, "input": f"{S}x{S}x3 u8 resident in HBM",
+                       "frames_per_gpu": B,
+                       "input": f"{S}x{S}x3 u8 resident in HBM, {NROT} distinct batches read round-robin by the steps",
+                       "tolerances": ("bf16 (BASELINE configs[1]'s dtype) does NOT meet north_star's 1e-4 head / bit-exact "
+                                      "index tolerance (head within 0.15 max / 0.02 mean of the reference head; "
+                                      "`reference_agreement` and `ap_vs_reference` say what that costs); the mode that "
+                                      "does is `f32_parity_mode`.  D-54 f32 deviates from 1e-4 by rule: its head must be "
+                                      "within 1e-4 of the reference OR within 1.5x the reference's own f32-vs-f64 distance "
+                                      "(2.8e-4 @96, 4e-4 @384) of the fp64 head"),
                        "head": (f"{cfg.lastsize()}x{S//16}x{S//16} f32 per image, NOT materialised: the head conv's "
                                 "epilogue keeps the 108 unary channels and one arg-max key per (edge, cell)"
                                 if fused else f"{cfg.lastsize()}x{S//16}x{S//16} f32 written to HBM"),
@@ -650,12 +744,17 @@ def main():
                                                 "step, D2H of the compact result (first 64 people slots per image) into pinned "
                                                 "buffers, all queued on the lane's stream; the host unpacks a batch while the "
                                                 "next ones run"}
-        if verified is not None:
-            result["verified"] = verified
         if world == 1 and not args.no_extras:
             if pipe is not None:
                 pipe.close()
             result.update(extra_sections(args, dev, net, frames, dec))
+        if verified is not None:
+            if "bf16_agreement" in result or "reference_agreement" in result:
+                ra = result.get("reference_agreement", result.get("bf16_agreement"))
+                verified["reference_agreement"] = {k: ra[k] for k in ("reference_people", "reproduced_exactly", "same_root",
+                                                                      "same_root_frac", "keypoint_cell_agreement")
+                                                   if k in ra}
+            result["batch_consistency"] = verified
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args.arch, 4, S)
     if dist is not None:
@@ -663,7 +762,7 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(result), flush=True)
-        if result.get("verified") is not None and not result["verified"]["ok"]:
+        if result.get("batch_consistency") is not None and not result["batch_consistency"]["ok"]:
             raise SystemExit("bench.py: the timed path's output differs from the batch-2 reference path")
 
 

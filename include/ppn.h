@@ -280,7 +280,8 @@ int ppn_stem01(int32_t dtype, int32_t src_is_u8, const void* src, int32_t batch,
 typedef struct ppn_plan ppn_plan;
 int ppn_plan_create(ppn_plan** out);
 int ppn_plan_add_conv(ppn_plan* p, const ppn_conv_desc* d);
-/* hipMemsetAsync(ptr, 0, bytes) as a step of the plan (zeroes the arg-max keys of the fused head conv). */
+/* Zero `bytes` at `ptr` as a step of the plan (the arg-max keys of the fused head conv); runs as a KERNEL with
+ * 16-byte stores, never a memset node of the captured graph: `ptr` must be 16-byte aligned (PPN_E_INVALID else). */
 int ppn_plan_add_memset(ppn_plan* p, void* ptr, size_t bytes);
 int ppn_plan_add_stem(ppn_plan* p, int32_t dtype, int32_t src_is_u8, const void* src, int32_t batch, int32_t h,
                       int32_t w, const float* weight, const float* scale, const float* shift, const float* mean,

@@ -460,6 +460,12 @@ int ppn::conv_launch(const ppn_conv_desc* d, hipStream_t st, const char** kname)
         if (d->m_begin < 0 || d->m_count < 0 || (long long)d->m_begin + d->m_count > m_all)
             return ppn::fail(PPN_E_INVALID, "pixel range [%d, +%d) outside the %lld output pixels", d->m_begin, d->m_count, m_all);
         m_lo = d->m_begin; m_hi = m_lo + d->m_count;
+        // The NCHW f32 epilogues store four consecutive pixels of one channel plane as a float4 when HoWo % 4 == 0:
+        // a cut that is not a multiple of 4 would store misaligned, write up to 3 pixels of the neighbouring range
+        // (a race with the launch that owns it) or run into the next channel plane.
+        if (d->out_nchw_f32 && ((d->out_h * d->out_w) & 3) == 0 && ((m_lo & 3) != 0 || ((m_hi & 3) != 0 && m_hi != m_all)))
+            return ppn::fail(PPN_E_INVALID, "NCHW output: pixel range [%d, +%d) must begin on a multiple of 4 and end on one "
+                                            "(or at the last pixel)", d->m_begin, d->m_count);
     } else if (!smallc) {
         // whole tensor: two launches with different tiles where that saves a round of workgroups (ppn_conv_split)
         const long long cut = big_split_for(d->cout, m_all);

@@ -66,10 +66,6 @@ __global__ void __launch_bounds__(256) zero_fill_kernel(uint4* p, size_t n16, un
 static int run_op(ppn_plan::Op& op, hipStream_t st) {
     if (op.kind == 2) {
         if (op.kname.empty()) op.kname = "zero_fill_kernel";
-        if ((reinterpret_cast<size_t>(op.ms_ptr) & 15) != 0) {
-            PPN_HIP_CHECK(hipMemsetAsync(op.ms_ptr, 0, op.ms_bytes, st));
-            return PPN_OK;
-        }
         const size_t n16 = op.ms_bytes / 16;
         const int ntail = (int)(op.ms_bytes - n16 * 16);
         const size_t want = (n16 + 255) / 256;
@@ -118,6 +114,10 @@ extern "C" int ppn_plan_add_conv(ppn_plan* p, const ppn_conv_desc* d) {
 
 extern "C" int ppn_plan_add_memset(ppn_plan* p, void* ptr, size_t bytes) {
     if (!p || !ptr) return ppn::fail(PPN_E_INVALID, "ppn_plan_add_memset: NULL argument");
+    // the fill runs as a kernel with 16-byte stores (never a memset node: see zero_fill_kernel), so the destination
+    // must be 16-byte aligned -- every torch allocation is
+    if ((reinterpret_cast<size_t>(ptr) & 15) != 0)
+        return ppn::fail(PPN_E_INVALID, "ppn_plan_add_memset: destination must be 16-byte aligned");
     ppn_plan::Op op{};
     op.kind = 2;
     op.ms_ptr = ptr;

@@ -72,13 +72,10 @@ class DecodeResult:
         dv = stage.device_side(self.count.device)
         # gather the first `cap` slots into contiguous device buffers (a strided D2H would be staged by torch anyway,
         # synchronously), then one asynchronous copy per array
+        dv["count"].copy_(self.count)
         dv["kp_cell"].copy_(self.kp_cell[:, :cap]); dv["limb_arg"].copy_(self.limb_arg[:, :cap])
         dv["bbox"].copy_(self.bbox[:, :cap]); dv["score"].copy_(self.score[:, :cap])
-        stage.count.copy_(self.count, non_blocking=True)
-        stage.kp_cell.copy_(dv["kp_cell"], non_blocking=True)
-        stage.limb_arg.copy_(dv["limb_arg"], non_blocking=True)
-        stage.bbox.copy_(dv["bbox"], non_blocking=True)
-        stage.score.copy_(dv["score"], non_blocking=True)
+        stage.flat.copy_(stage._dev_flat, non_blocking=True)          # ONE D2H for the whole compact result
         stage.source = self
         return stage
 
@@ -100,23 +97,36 @@ class DecodeResult:
 
 
 class HostStage:
-    """Pinned host buffers for the compact decode result of one batch (DecodeResult.to_host_async)."""
+    """Pinned host buffers for the compact decode result of one batch (DecodeResult.to_host_async): ONE pinned
+    allocation and one device mirror holding count | kp_cell | limb_arg | bbox | score back to back, so the read-back
+    is a single D2H copy per batch (five separate copies cost five trips through the copy queue per step)."""
 
     def __init__(self, batch: int, cap: int = 64):
         self.cap = cap
-        pin = lambda *shape, dtype: torch.empty(*shape, dtype=dtype).pin_memory()
-        self.count = pin(batch, dtype=torch.int32)
-        self.kp_cell = pin(batch, cap, cfg.K, dtype=torch.int32)
-        self.limb_arg = pin(batch, cap, cfg.E, dtype=torch.int32)
-        self.bbox = pin(batch, cap, cfg.K, 4, dtype=torch.float32)
-        self.score = pin(batch, cap, cfg.K, dtype=torch.float32)
+        self._shapes = [("count", (batch,), torch.int32), ("kp_cell", (batch, cap, cfg.K), torch.int32),
+                        ("limb_arg", (batch, cap, cfg.E), torch.int32), ("bbox", (batch, cap, cfg.K, 4), torch.float32),
+                        ("score", (batch, cap, cfg.K), torch.float32)]
+        self._words = sum(int(np.prod(shp)) for _, shp, _ in self._shapes)
+        self.flat = torch.empty(self._words, dtype=torch.int32).pin_memory()
+        for name, view in self._views(self.flat).items():
+            setattr(self, name, view)
         self.source: Optional[DecodeResult] = None
         self._dev = None
+        self._dev_flat = None
+
+    def _views(self, flat):
+        out, o = {}, 0
+        for name, shp, dt in self._shapes:
+            n = int(np.prod(shp))
+            v = flat[o:o + n]
+            out[name] = (v.view(torch.float32) if dt == torch.float32 else v).view(shp)
+            o += n
+        return out
 
     def device_side(self, device):
         if self._dev is None:
-            self._dev = {k: torch.empty(getattr(self, k).shape, dtype=getattr(self, k).dtype, device=device)
-                         for k in ("kp_cell", "limb_arg", "bbox", "score")}
+            self._dev_flat = torch.empty(self._words, dtype=torch.int32, device=device)
+            self._dev = self._views(self._dev_flat)
         return self._dev
 
     def unpack(self):

@@ -142,3 +142,35 @@ def evaluation(list_: Sequence) -> List[float]:
         gxy = np.asarray(gt_kps, np.float32).reshape(len(gt_bboxes), N_JOINTS, 2)
         frames.append((pxy, psc, gxy, _head_sizes(gt_bboxes)))
     return get_cum(compute_metrics(*assign_gt_multi(frames)))
+
+
+def people_as_ground_truth(res: dict):
+    """One image's compact people list (DecodeResult.to_host() / oracle / fixture format: n, kp_cell [n,K], bbox
+    [n,K,4] as [ymin,xmin,ymax,xmax], score [n,K]) as the ground truth of `evaluation`: every keypoint at its box centre
+    (a keypoint the person does not have sits at (0, 0), which is also where datatest.py:314-325 puts a missing
+    PREDICTED joint, so an identical people list scores 100), the instance box (keypoint 0) as (cx, cy, w, h)."""
+    n = int(res["n"])
+    humans, scores = [], []
+    for i in range(n):
+        hm = {k: np.asarray(res["bbox"][i, k], np.float32) for k in range(res["kp_cell"].shape[1]) if res["kp_cell"][i, k] >= 0}
+        humans.append(hm)
+        scores.append({k: np.float32(res["score"][i, k]) for k in hm})
+    gxy, _ = _pred_arrays(humans, scores)
+    boxes = []
+    for i in range(n):
+        ymin, xmin, ymax, xmax = (float(v) for v in res["bbox"][i, 0])
+        boxes.append(((xmin + xmax) / 2, (ymin + ymax) / 2, xmax - xmin, ymax - ymin))
+    return humans, scores, gxy.reshape(n, N_JOINTS * 2), boxes
+
+
+def ap_against_people(expected: Sequence[dict], got: Sequence[dict]) -> List[float]:
+    """The 8 AP values of `got` (per-image compact people lists) scored against `expected` taken as ground truth
+    (people_as_ground_truth), with the reference's own matcher and metric (`evaluation`): what a reduced-precision
+    mode costs in the task metric, instead of exact-match counts."""
+    fnames, gt_kps, humans, scores, gt_boxes, vis, size = [], [], [], [], [], [], []
+    for i, (e, g) in enumerate(zip(expected, got)):
+        _, _, gxy, boxes = people_as_ground_truth(e)
+        hm, sc, _, _ = people_as_ground_truth(g)
+        fnames.append(f"frame{i}"); gt_kps.append(gxy); humans.append(hm); scores.append(sc); gt_boxes.append(boxes)
+        vis.append(None); size.append(None)
+    return evaluation([fnames, gt_kps, humans, scores, gt_boxes, vis, size])

@@ -237,7 +237,8 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, stride: int = 1, dilation: int
     # A parameter is packed once per optimiser step and layout (forward / input-gradient): the probe passes and the
     # second-order tail run the same convolutions several times per iteration.  Keyed on the weight's storage, the
     # parameter version (bumped by FlatAdam.step / load_state_dict) and the stream the pack kernel was queued on.
-    key = (w.data_ptr(), tuple(w.shape), bool(dgrad_of), dt, st) if w._base is not None else None
+    sp = w.untyped_storage().data_ptr()
+    key = (w.data_ptr(), tuple(w.shape), bool(dgrad_of), dt, st) if sp in _param_storages else None
     packed = _pack_cache.get(key) if key is not None else None
     if packed is None or packed[0] != _param_version[0]:
         buf = packed[1] if packed is not None else torch.empty(cpad, ktot, dtype=torch.float32 if korder == 2 else x.dtype,
@@ -245,7 +246,7 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, stride: int = 1, dilation: int
         pack = lib.ppn_pack_weight_dgrad if dgrad_of else lib.ppn_pack_weight
         L.check(pack(dt, w.data_ptr(), cout, cin, k, cpad, ktot, korder, kstep, buf.data_ptr(), st), "ppn_pack_weight")
         if key is not None:
-            _pack_cache[key] = (_param_version[0], buf)
+            _pack_cache[key] = (_param_version[0], buf, sp)
         packed = (_param_version[0], buf)
     packed = packed[1]
     if nchw_f32:                                  # the head tensor the loss / decode kernels read (model.py:134-136)
@@ -270,10 +271,30 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, stride: int = 1, dilation: int
 
 
 _zero_pages = {}
-# packed-weight cache of conv2d_nhwc (see there).  Only views of a larger buffer (the trainer's flat parameter
-# buffer) are cached: a free-standing weight tensor may be modified in place by the caller between two calls.
+# packed-weight cache of conv2d_nhwc (see there).  Only views of a buffer a trainer REGISTERED (its flat parameter
+# buffer, register_param_storage) are cached: any other weight tensor -- free-standing or a view of a temporary the
+# caching allocator may hand out again at the same address -- is packed on every call.
 _pack_cache: dict = {}
 _param_version = [0]
+_param_storages: dict = {}          # storage data_ptr -> number of live registrations
+
+
+def register_param_storage(flat: torch.Tensor):
+    """The caller owns `flat` for its lifetime and calls bump_param_version() after every in-place edit of it."""
+    sp = flat.untyped_storage().data_ptr()
+    _param_storages[sp] = _param_storages.get(sp, 0) + 1
+    return sp
+
+
+def unregister_param_storage(sp):
+    """Drop a registration and every packed copy made of views of that storage (a dead trainer pins nothing)."""
+    n = _param_storages.get(sp, 0) - 1
+    if n > 0:
+        _param_storages[sp] = n
+        return
+    _param_storages.pop(sp, None)
+    for key in [k for k, v in _pack_cache.items() if v[2] == sp]:
+        del _pack_cache[key]
 
 
 def bump_param_version():

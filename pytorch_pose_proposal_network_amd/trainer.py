@@ -71,6 +71,7 @@ class PPNTrainer:
                 if n.endswith("var"):
                     self.buffers[n].fill_(1.0)
         self.num_batches_tracked = 0
+        self._storage_key = T.register_param_storage(self.flat)               # packed-weight cache (train.conv2d_nhwc)
         if state_dict is not None:
             self.load_state_dict(state_dict)
         self.opt = T.FlatAdam(self.flat, lr=lr)                               # optimizerM, main.py:278
@@ -91,7 +92,14 @@ class PPNTrainer:
         self.second_order = second_order
 
     # ---- state ------------------------------------------------------------------------------------------------
+    def __del__(self):
+        try:
+            T.unregister_param_storage(self._storage_key)
+        except Exception:
+            pass
+
     def load_state_dict(self, sd):
+        T.bump_param_version()                     # parameters are overwritten in place: packed copies are stale
         for n in self.param_names:
             v = sd[n] if n in sd else sd["module." + n]
             self.P[n].copy_(torch.as_tensor(np.asarray(v) if not isinstance(v, torch.Tensor) else v).float())
@@ -593,7 +601,9 @@ class PPNTrainer:
             rest = total - acc
             trusted = True
             if self.compute_dtype != L.PPN_F32:
-                n_rest, n_tot = float(T.sumsq(rest.contiguous().view(-1))), float(T.sumsq(total.contiguous().view(-1)))
+                # both norms in one device tensor: ONE read-back (a host sync on the main stream) instead of two
+                n_rest, n_tot = torch.stack([T.sumsq(rest.contiguous().view(-1)).reshape(()),
+                                             T.sumsq(total.contiguous().view(-1)).reshape(())]).tolist()
                 trusted = n_rest > (16.0 * 2.0 ** -8) ** 2 * n_tot
             if trusted:
                 return rest / float(coeff[4])

@@ -1,7 +1,7 @@
 """One data-parallel rank of tests/test_dp_gpu.py (not a test module): joins a gloo group of `world` processes that
 share cuda:0, runs ONE PPNTrainer.train_step on its own minibatch shard and saves what the parent compares.
 
-    python tests/dp_worker.py RANK WORLD PORT OUT.pt SECOND_ORDER DTYPE
+    python tests/dp_worker.py RANK WORLD PORT OUT.pt SECOND_ORDER DTYPE [SIZE]
 """
 import os
 import sys
@@ -34,13 +34,14 @@ def make_trainer(second_order, dtype_name, size=96):
 def main():
     rank, world, port, out, second_order, dtype_name = (int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4],
                                                         sys.argv[5] == "1", sys.argv[6])
+    size = int(sys.argv[7]) if len(sys.argv) > 7 else 96
     import torch
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    tr = make_trainer(second_order, dtype_name)
-    x, tg = shard_inputs(rank)
+    tr = make_trainer(second_order, dtype_name, size)
+    x, tg = shard_inputs(rank, size)
     xd = torch.as_tensor(x).cuda()
     tgd = {k: torch.from_numpy(v).cuda() for k, v in tg.items()}
     losses, w = tr.train_step(xd, tgd)

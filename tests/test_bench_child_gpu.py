@@ -1,0 +1,56 @@
+"""GPU: `python bench.py --gpus 2` as the driver starts it WITHOUT a launcher -- bench.py starts its own ranks as a child
+`torch.distributed.run` (before this process touches the GPU, never exec) -- rehearsed on the one GPU of the box with
+PPN_BENCH_BACKEND=gloo (both ranks share cuda:0; the driver's multi-GPU runs use "nccl" = RCCL, same code otherwise;
+/root/reference/main.py:240-245,289,769-771,1233-1238 is the DDP set-up this replaces).  Checks the contract of the N>1
+line and that a failing rank fails the run instead of hanging it."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra, env_extra=None, timeout=420):
+    env = dict(os.environ, PPN_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.update(env_extra or {})
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--windows", "2",
+           "--no-extras", "--no-cpu-baseline"] + extra
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout, cwd=ROOT)
+    return p
+
+
+def test_self_launched_two_rank_inference_line():
+    p = _run([])
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["rccl_ranks"] == 0 and r["scaling"] == "weak" and r["steps"] == 3
+    assert r["batch_consistency"]["ok"] and r["batch_consistency"]["frames"] == 32
+    assert r["value"] > 0 and r["value_windows"]["n"] == 2
+    assert r["value_windows"]["min"] <= r["value_windows"]["median"] <= r["value_windows"]["max"]
+    assert "cpu_baseline" not in r                              # rank 0 at N=1 only
+
+
+def test_self_launched_two_rank_training_line():
+    p = _run(["--workload", "train", "--batch", "4"])
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["rccl_ranks"] == 0 and r["value"] > 0
+    assert len(r["losses"]) == 5 and all(v == v for v in r["losses"])         # finite, not NaN
+    assert abs(sum(r["task_weights"]) - 5.0) < 1e-2                              # renormalised to sum 5 (main.py:773-777)
+
+
+@pytest.mark.parametrize("workload", ["inference", "train"])
+def test_a_failing_rank_fails_the_run_without_hanging(workload):
+    p = _run(["--workload", workload, "--batch", "4"], {"PPN_BENCH_FAIL_RANK": "1"}, timeout=300)
+    assert p.returncode != 0
+    assert not [l for l in p.stdout.splitlines() if l.lstrip().startswith("{")], p.stdout
+    assert "PPN_BENCH_FAIL_RANK" in p.stderr

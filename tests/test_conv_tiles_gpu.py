@@ -445,3 +445,33 @@ def test_pixel_ranges_small_channel_kernel(dtype_name):
     flat = one.permute(0, 2, 3, 1).reshape(M, Cout)
     assert torch.isnan(flat[:130]).all() and torch.isnan(flat[830:]).all()
     assert torch.equal(flat[130:830], whole.permute(0, 2, 3, 1).reshape(M, Cout)[130:830])
+
+
+def test_pixel_ranges_nchw_head_need_aligned_cuts():
+    """NCHW f32 head output (model.py:134-136 layout): the epilogue stores four consecutive pixels of a channel plane as
+    one float4 when Ho*Wo % 4 == 0, so a pixel range must begin and end on multiples of 4 (ppn_conv2d_fused rejects any
+    other cut: it would store misaligned and write into the neighbouring range); aligned cuts equal the single launch
+    and leave the rest of the tensor untouched."""
+    from pytorch_pose_proposal_network_amd import lib as L
+    dtype = L.PPN_BF16
+    B, Cin, H, W, Cout = 3, 128, 12, 12, 200                    # HoWo = 144 (multiple of 4), M = 432
+    x = q(rnd(B, Cin, H, W, seed=171), dtype)
+    w = q(rnd(Cout, Cin, 1, 1, seed=172, scale=(2.0 / Cin) ** 0.5), dtype)
+    bias = rnd(Cout, seed=173, scale=0.3)
+    kw = dict(b1=bias, act1=3, nchw=True)
+    whole, _ = run_conv(x, w, dtype, **kw)
+    M = B * H * W
+    parts, _ = run_conv(x, w, dtype, ranges=[(0, 100, (128, 128)), (100, 200, (192, 128)), (300, M - 300, (128, 128))], **kw)
+    assert not torch.isnan(whole).any() and torch.equal(parts, whole)
+    one, _ = run_conv(x, w, dtype, ranges=[(100, 200, (128, 128))], **kw)
+    flat = one.permute(0, 2, 3, 1).reshape(M, Cout)
+    assert torch.isnan(flat[:100]).all() and torch.isnan(flat[300:]).all()
+    assert torch.equal(flat[100:300], whole.permute(0, 2, 3, 1).reshape(M, Cout)[100:300])
+    for lo, n in ((2, 200), (100, 201), (101, 99)):             # misaligned begin / end
+        with pytest.raises(RuntimeError, match="multiple of 4"):
+            run_conv(x, w, dtype, ranges=[(lo, n, (128, 128))], **kw)
+    # a grid whose planes are not a multiple of 4 pixels takes the scalar store path: any cut is fine there
+    x2 = q(rnd(2, Cin, 7, 9, seed=174), dtype)
+    whole2, _ = run_conv(x2, w, dtype, **kw)
+    parts2, _ = run_conv(x2, w, dtype, ranges=[(0, 61, (128, 128)), (61, 126 - 61, (128, 128))], **kw)
+    assert torch.equal(parts2, whole2)

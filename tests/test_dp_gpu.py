@@ -23,15 +23,16 @@ def _free_port():
         return str(s.getsockname()[1])
 
 
-@pytest.mark.parametrize("second_order", [False, True], ids=["first_order", "second_order"])
-def test_two_ranks_equal_mean_of_single_rank_runs(tmp_path, second_order):
+@pytest.mark.parametrize("second_order,dtype,size", [(False, "f32", 96), (True, "f32", 96), (True, "bf16", 384)],
+                         ids=["first_order", "second_order", "second_order_bf16_384"])
+def test_two_ranks_equal_mean_of_single_rank_runs(tmp_path, second_order, dtype, size):
     sys.path.insert(0, HERE)
     import dp_worker as W
     port = _free_port()
     outs = [str(tmp_path / f"rank{r}.pt") for r in range(2)]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dp_worker.py"), str(r), "2", port, outs[r],
-                               "1" if second_order else "0", "f32"], env=env) for r in range(2)]
+                               "1" if second_order else "0", dtype, str(size)], env=env) for r in range(2)]
     try:
         rcs = [p.wait(timeout=600) for p in procs]
     finally:
@@ -48,8 +49,8 @@ def test_two_ranks_equal_mean_of_single_rank_runs(tmp_path, second_order):
     # ---- expected, from single-rank pieces in this process ------------------------------------------------------
     trs, local = [], []
     for r in range(2):
-        tr = W.make_trainer(second_order, "f32")
-        x, tg = W.shard_inputs(r)
+        tr = W.make_trainer(second_order, dtype, size)
+        x, tg = W.shard_inputs(r, size)
         losses, gn, scale = tr.local_pass(torch.as_tensor(x).cuda(),
                                           {k: torch.from_numpy(v).cuda() for k, v in tg.items()})
         assert scale == 1.0

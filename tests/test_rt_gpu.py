@@ -193,3 +193,36 @@ def test_multi_lane_pinned_frames_and_async_readback(golden_dir):
     torch.cuda.synchronize()
     for a, b in zip(serial[0], st.unpack()):
         assert a["n"] == b["n"] and np.array_equal(a["kp_cell"], b["kp_cell"])
+
+
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
+def test_graph_replay_equals_direct_launches(golden_dir, dtype):
+    """The fused-decode plan launches directly twice and is then captured into a hipGraph (csrc/plan.hip): every replay
+    must leave the unary tensor, the arg-max keys and the people lists bit-equal to the direct run -- the check that a
+    graph node running out of order (the memset-node bug of round 2, csrc/plan.hip zero_fill_kernel) cannot pass."""
+    from pytorch_pose_proposal_network_amd import decode, rt
+    g = np.load(os.path.join(golden_dir, "forward_d22_96.npz"))
+    stats = {k[3:]: g[k] for k in g.files if k.startswith("bn/")}
+    model, _, _ = rt.network(image_size=96, state_dict=synth.make_state_dict("drn_d_22", 0, bn_stats=stats),
+                             compute_dtype=dtype)
+    st = torch.cuda.Stream()                                  # the legacy default stream cannot be captured
+    with torch.cuda.stream(st):
+        sets = [torch.from_numpy(prng.u8_frames(300 + i, 4, (96, 96))).cuda() for i in range(2)]
+        dec = decode.Decoder(4, (6, 6), (96, 96), device="cuda")
+        first = {}
+        for rnd_ in range(6):                                 # runs 0-1 direct, the capture happens in run 2
+            for i, fr in enumerate(sets):
+                unary, keys = model.forward_u8(fr, fused_decode=True)
+                people = dec.decode_fused(unary, keys).to_host()
+                snap = (unary.clone(), keys.clone(), people)
+                if rnd_ == 0:
+                    first[i] = snap
+                    continue
+                assert torch.equal(snap[0], first[i][0]) and torch.equal(snap[1], first[i][1]), (rnd_, i)
+                for a, b in zip(people, first[i][2]):
+                    assert a["n"] == b["n"]
+                    for k in ("kp_cell", "limb_arg", "bbox", "score"):
+                        assert np.array_equal(a[k], b[k]), (rnd_, i, k)
+        assert not torch.equal(first[0][1], first[1][1])      # the two frame sets really differ
+    caps = model.graph_captures()
+    assert sum(caps.values()) >= 1, caps                      # the later runs were graph replays

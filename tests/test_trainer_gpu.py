@@ -457,3 +457,93 @@ def test_bf16_limb_probe_by_linearity_vs_direct_pass():
         direct = float(tr.probe_grad(g4).double().norm().cpu())
         print(f"task weights {w}: gnorm_4 production {gn[4]:.5e}  direct pass {direct:.5e}")
         assert abs(gn[4] / direct - 1.0) < 0.05, (gn[4], direct)
+
+
+def test_trainer_f32_matches_oracle_at_384_batch4():
+    """The training step at the benchmarked RESOLUTION (384x384; batch 4 so that the CPU autograd oracle of
+    main.py:664-777 finishes in seconds on the box's 16 threads), f32 mode: head 1e-4, losses 1e-4, every parameter
+    gradient by the noise rule of this module, G_i 1e-4 (or 3x the oracle's own f32-vs-f64 noise).  The batch-32 shard
+    then follows from the additivity checked in test_batch32_step_is_assembled_from_its_halves."""
+    from pytorch_pose_proposal_network_amd import lib as L, prng, synth
+    from pytorch_pose_proposal_network_amd.trainer import PPNTrainer
+    from oracle import forward_ref as Fr, targets_ref as T, train_ref
+    size, batch, alpha = 384, 4, 0.12
+    sd = synth.make_state_dict("drn_d_22", 0)
+    x = Fr.normalize_u8(prng.u8_frames(4242, batch, (size, size)))
+    tg = T.synthetic_batch(4343, batch, insize=(size, size), outsize=(size // 16, size // 16))
+    w0, base = np.array([1.3, 0.8, 1.1, 0.7, 1.1]), np.array([2.0, 1.5, 0.6, 0.4, 3.0])
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    r64 = train_ref.train_iteration_ref(sd, x, tg, w0, base, "drn_d_22", (size, size), alpha)
+    r32 = train_ref.train_iteration_ref(sd, x, tg, w0, base, "drn_d_22", (size, size), alpha, dtype=torch.float32)
+    dev = torch.device("cuda")
+    tr = PPNTrainer("drn_d_22", sd, compute_dtype=L.PPN_F32, insize=(size, size), lr_weights=0.025, alpha=alpha)
+    tr.task.w.copy_(torch.from_numpy(w0).float())
+    xd = torch.as_tensor(x).to(dev)
+    tgd = {k: torch.from_numpy(v).to(dev) for k, v in tg.items()}
+    head = tr.forward(xd)
+    err = float(np.abs(head.cpu().numpy() - r64["head"]).max())
+    print(f"384x384 batch 4 train-mode head: max|hip - f64 oracle| = {err:.3e}")
+    assert err <= 1e-4
+    for n, b in tr.buffers.items():
+        assert np.allclose(b.cpu().numpy(), r64["buffers"][n], rtol=2e-4, atol=2e-5), n
+    coeff = [float(v) / 5 for v in w0]
+    losses, ghead = tr.criterion.forward_backward(head, tgd, coeff=coeff)
+    assert np.allclose(losses.cpu().numpy(), r64["losses"], rtol=1e-4), (losses, r64["losses"])
+    tr.backward(ghead)
+    torch.cuda.synchronize()
+    bad, worst = [], (None, 0.0, 0.0)
+    for n in tr.param_names:
+        noise = _rel(r32["grads"][n], r64["grads"][n])
+        e = _rel(tr.G[n].cpu().numpy().astype(np.float64), r64["grads"][n])
+        if e > worst[1]:
+            worst = (n, e, noise)
+        if e > max(3 * noise, 1e-2):
+            bad.append((n, e, noise))
+    print(f"gradients: worst relative L2 error {worst[1]:.2e} ({worst[0]}; the oracle's own f32-vs-f64 gap there {worst[2]:.2e})")
+    assert not bad, bad[:8]
+    gn = tr.probe_norms(head, tgd, coeff, ghead).cpu().numpy().astype(np.float64)
+    noise = np.abs(r32["gnorm"] - r64["gnorm"]) / r64["gnorm"]
+    rel = np.abs(gn - r64["gnorm"]) / r64["gnorm"]
+    print(f"||dL_i/dW||: relative error {[float('%.2e' % v) for v in rel]} (oracle f32 noise {[float('%.2e' % v) for v in noise]})")
+    assert np.all(rel <= np.maximum(3 * noise, 1e-4)), (rel, noise)
+
+
+def test_batch32_step_is_assembled_from_its_halves():
+    """What carries the batch-4 oracle check to the benchmarked batch 32 (f32, 384x384): the loss is a batch MEAN and the
+    BN sums are ADDITIVE, so a batch-32 pass equals what its two halves give where the algebra allows it -- the five
+    losses and the head gradient of a batch-32 head from its halves, and the first BN's batch statistics (its input does
+    not depend on the batch) from the halves' statistics."""
+    from pytorch_pose_proposal_network_amd import lib as L, prng, synth, targets
+    from pytorch_pose_proposal_network_amd.trainer import PPNTrainer
+    size, B = 384, 32
+    dev = torch.device("cuda")
+    sd = synth.make_state_dict("drn_d_22", 0)
+    x = torch.from_numpy(synth.normalized_frames(prng.u8_frames(77, B, (size, size)))).to(dev)
+    tg = targets.synthetic_targets(78, B, (size, size), device=dev)
+    stats = []
+    for lo, hi in ((0, B), (0, B // 2), (B // 2, B)):
+        tr = PPNTrainer("drn_d_22", sd, compute_dtype=L.PPN_F32, insize=(size, size))
+        head = tr.forward(x[lo:hi].contiguous())
+        n = (hi - lo) * size * size
+        mean = tr.buffers["backbone.0.1.running_mean"].double() / 0.1                     # momentum 0.1, start 0
+        var = (tr.buffers["backbone.0.1.running_var"].double() - 0.9) / 0.1 * (n - 1) / n   # unbiased -> biased
+        stats.append((mean.cpu(), var.cpu(), head if lo == 0 and hi == B else None, tr if hi - lo == B else None))
+        if hi - lo != B:
+            del tr
+        torch.cuda.empty_cache()
+    (m, v, head, tr), (ma, va, _, _), (mb, vb, _, _) = stats
+    m_exp = (ma + mb) / 2
+    v_exp = (va + ma ** 2 + vb + mb ** 2) / 2 - m_exp ** 2
+    assert torch.allclose(m, m_exp, rtol=1e-5, atol=1e-6), float((m - m_exp).abs().max())
+    assert torch.allclose(v, v_exp, rtol=1e-4, atol=1e-6), float((v - v_exp).abs().max())
+    coeff = [0.26, 0.16, 0.22, 0.14, 0.22]
+    l32, g32 = tr.criterion.forward_backward(head, tg, coeff=coeff)
+    g32 = g32.clone()
+    parts = []
+    for lo, hi in ((0, B // 2), (B // 2, B)):
+        th = {k: t[lo:hi].contiguous() for k, t in tg.items()}
+        lh, gh = tr.criterion.forward_backward(head[lo:hi].contiguous(), th, coeff=coeff)
+        parts.append((lh.clone(), gh.clone()))
+    assert torch.allclose(l32, (parts[0][0] + parts[1][0]) / 2, rtol=1e-5), (l32, parts)
+    gcat = torch.cat([parts[0][1], parts[1][1]]) / 2
+    assert torch.allclose(g32, gcat, rtol=1e-5, atol=1e-9), float((g32 - gcat).abs().max())
