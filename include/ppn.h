@@ -202,6 +202,14 @@ typedef struct ppn_conv_desc {
      * tensor (under tile policy 2 ppn_conv2d_fused then cuts the range itself where ppn_conv_split says so; a plan
      * lists the two ranges as separate entries so that each launch is timed and named). */
     int32_t m_begin, m_count;
+    /* Edge-aligned limb part of the head conv (the fast fused path): limb_edge_pad = 448 (the only size built: windows of
+     * 385..448 values, e.g. 21 x 21 = 441) says that `weight`, `scale1` and `shift1` hold ONLY the limb channels, edge e's
+     * window in rows [e * limb_edge_pad, e * limb_edge_pad + limb_window) and padding after it (cout = E * limb_window,
+     * cout_pad = E * limb_edge_pad).  One workgroup then owns a whole window of 128 cells, reduces its arg-max on the
+     * accumulators and STORES argmax_keys u64 [B,E,H,W] (same key format; no atomics, the buffer need not be zeroed).
+     * out_raw, unary_out must be NULL and unary_channels 0: the 6K unary channels are an ordinary NCHW launch of their
+     * own (cout = 6K, out_raw = the compact unary tensor).  0 (default): the chunked epilogue with atomicMax keys. */
+    int32_t limb_edge_pad;
 } ppn_conv_desc;
 
 /* GEMM-depth step / channel tile the packer must pad to for a conv of this shape and dtype, and the order of

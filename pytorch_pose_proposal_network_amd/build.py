@@ -21,6 +21,7 @@ SOURCES = [
     ("decode.hip", ["-ffp-contract=off"]),
     ("conv.hip", []),
     ("conv_big.hip", []),
+    ("conv_head.hip", []),
     ("stem.hip", []),
     ("stem3x3.hip", []),
     ("stem01.hip", []),

@@ -389,6 +389,7 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ 
 
 namespace ppn {
 int conv_launch(const ppn_conv_desc* d, hipStream_t st, const char** kname);
+int head_limb_launch(const ppn_conv_desc* d, long long m_lo, long long m_hi, hipStream_t st, const char** kname);
 bool stem3x3_supported(int cin, int cout, int ksize, int stride, int dilation, int pad);
 int stem3x3_launch(int dtype, const void* src, int batch, int h, int w, int cout, int stride, const float* weight,
                    const float* scale1, const float* shift1, const float* scale2, const float* shift2, void* out_raw,
@@ -482,13 +483,27 @@ int ppn::conv_launch(const ppn_conv_desc* d, hipStream_t st, const char** kname)
     TileChoice tc = choose_tile(d->cout);
     BigTile bt{0, 0};
     const bool big = !smallc && big_tile_for(d->cout, m, &bt, kpad / bk);
+    if (d->limb_edge_pad != 0) {
+        // edge-aligned limb tile (conv_head.hip): rows [e * limb_edge_pad, +limb_window) of the packed weight / shift1
+        // hold edge e's window, the rest of each edge's rows are padding
+        if (d->limb_edge_pad != kEdgeTileBC || smallc || d->src2 || !d->argmax_keys || !d->out_nchw_f32 || d->out_raw ||
+            d->unary_out || d->unary_channels != 0 || d->residual || d->out_act || d->limb_window < 1 ||
+            d->limb_window > d->limb_edge_pad || d->cout % d->limb_window != 0 ||
+            d->cout_pad != d->cout / d->limb_window * d->limb_edge_pad || d->act1 != PPN_ACT_SIGMOID)
+            return ppn::fail(PPN_E_INVALID, "limb_edge_pad: needs %d rows per edge (window <= that), cout = E * window, "
+                                            "cout_pad = E * limb_edge_pad, sigmoid, argmax_keys only (no out_raw / unary_out)",
+                             kEdgeTileBC);
+        if (!d->src || !d->weight) return ppn::fail(PPN_E_INVALID, "NULL src/weight");
+        return ppn::head_limb_launch(d, m_lo, m_hi, st, kname);
+    }
     const int bc = big ? bt.bc : tc.bc, bp = big ? bt.bp : tc.bp;
     if (d->cout_pad % bc != 0 || d->cout_pad < d->cout)
         return ppn::fail(PPN_E_INVALID, "cout_pad %d must be a multiple of %d and >= cout", d->cout_pad, bc);
     if (!d->src || !d->weight || !d->zero_page) return ppn::fail(PPN_E_INVALID, "NULL src/weight/zero_page");
     if (!d->out_raw && !d->out_act && !d->argmax_keys) return ppn::fail(PPN_E_INVALID, "conv has no output");
-    if (d->argmax_keys && (!d->out_nchw_f32 || !d->unary_out || d->unary_channels < 0 || d->limb_window < 1 ||
-                           d->unary_channels > d->cout || (d->cout - d->unary_channels) % d->limb_window != 0))
+    if (d->argmax_keys && !d->limb_edge_pad &&
+        (!d->out_nchw_f32 || !d->unary_out || d->unary_channels < 0 || d->limb_window < 1 ||
+         d->unary_channels > d->cout || (d->cout - d->unary_channels) % d->limb_window != 0))
         return ppn::fail(PPN_E_INVALID, "fused arg-max needs the NCHW head mode, unary_out and cout = unary + E*window");
     if (d->argmax_keys && d->act1 != PPN_ACT_SIGMOID)
         return ppn::fail(PPN_E_INVALID, "fused arg-max keys assume non-negative (sigmoid) outputs");

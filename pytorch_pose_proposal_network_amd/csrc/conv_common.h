@@ -135,6 +135,8 @@ __device__ __forceinline__ void store8<__bf16>(char* p, const float* v) {
 struct BigTile {
     int bp, bc;
 };
+// edge-aligned limb tile of the head conv (ppn_conv_desc.limb_edge_pad): 128 pixels x one edge's window padded to 448 rows
+constexpr int kEdgeTileBP = 128, kEdgeTileBC = 448;
 bool big_tile_for(int cout, long long m, BigTile* out, int ksteps = 0);   // ksteps: K steps of the launch (0 = unknown)
 // Split point of a two-segment launch (0 = single launch): pixels [0, split) run whole rounds of the most efficient
 // tile, the rest a smaller tile that fills one more round (conv_big.hip).

@@ -36,7 +36,7 @@ class ConvDesc(C.Structure):
         ("out_act", C.c_void_p), ("zero_page", C.c_void_p),
         ("src2", C.c_void_p), ("in2_h", C.c_int32), ("in2_w", C.c_int32), ("cin2", C.c_int32), ("stride2", C.c_int32),
         ("unary_out", C.c_void_p), ("argmax_keys", C.c_void_p), ("unary_channels", C.c_int32),
-        ("limb_window", C.c_int32), ("m_begin", C.c_int32), ("m_count", C.c_int32),
+        ("limb_window", C.c_int32), ("m_begin", C.c_int32), ("m_count", C.c_int32), ("limb_edge_pad", C.c_int32),
     ]
 
 

@@ -229,7 +229,41 @@ class PoseProposalNet:
                 self._dev[op.name + ".b1"] = (bds if b1 is None else b1 + bds).float().to(dev)
             self._dev[op.name + ".w"] = packed
             self._dev[op.name + ".geom"] = (ktot, cpad)
+            if op.nchw_f32_out and self._head_edge_pad():
+                # fused-decode plans (forward_u8(fused_decode=True)): the head conv as TWO launches -- the 6K unary
+                # channels as an ordinary NCHW conv of their own, and the limb channels with one 448-row channel tile per
+                # edge (ppn_conv_desc.limb_edge_pad), whose epilogue reduces each window's arg-max on the accumulators
+                ep, nun = self._head_edge_pad(), 6 * len(self.keypoint_names)
+                win, ne = self.local_grid_size[0] * self.local_grid_size[1], len(self.edges)
+                bias = self._sd[op.bias].float() if op.bias else torch.zeros(op.cout)
+                assert op.bn1 is None and op.k == 1 and op.cout == nun + ne * win
+                wu = w[:nun].contiguous().to(dev)
+                ks_u, _, ko_u, kt_u, cp_u = L.conv_tiling(self.compute_dtype, op.cin, nun, 1)
+                pu = torch.empty(cp_u, kt_u, dtype=tdt, device=dev)
+                L.check(lib.ppn_pack_weight(self.compute_dtype, wu.data_ptr(), nun, op.cin, 1, cp_u, kt_u, ko_u, ks_u,
+                                            pu.data_ptr(), stream), "ppn_pack_weight")
+                self._dev[op.name + ".w_unary"], self._dev[op.name + ".geom_unary"] = pu, (kt_u, cp_u)
+                self._dev[op.name + ".b_unary"] = bias[:nun].contiguous().to(dev)
+                we = torch.zeros(ne, ep, op.cin, 1, 1)
+                we[:, :win] = w[nun:].view(ne, win, op.cin, 1, 1)
+                we = we.view(ne * ep, op.cin, 1, 1).contiguous().to(dev)
+                pe = torch.empty(ne * ep, ktot, dtype=tdt, device=dev)
+                L.check(lib.ppn_pack_weight(self.compute_dtype, we.data_ptr(), ne * ep, op.cin, 1, ne * ep, ktot, korder,
+                                            kstep, pe.data_ptr(), stream), "ppn_pack_weight")
+                be = torch.zeros(ne, ep)
+                be[:, :win] = bias[nun:].view(ne, win)
+                self._dev[op.name + ".w_edge"], self._dev[op.name + ".b_edge"] = pe, be.view(-1).contiguous().to(dev)
+                torch.cuda.synchronize(dev)               # `wu` / `we` die here: their pack kernels must have run
         torch.cuda.synchronize(dev)
+
+    def _head_edge_pad(self) -> int:
+        """Rows per edge of the edge-aligned limb tile (448) when the limb window fits it (385..448 values, e.g. the
+        reference's 21 x 21), else 0: the chunked epilogue with atomicMax keys.  PPN_HEAD_EDGE=0 forces the latter."""
+        win = self.local_grid_size[0] * self.local_grid_size[1]
+        if os.environ.get("PPN_HEAD_EDGE", "1") == "0" or not (384 < win <= 448):
+            return 0
+        kstep, _, korder, _, _ = L.conv_tiling(self.compute_dtype, 512, 512, 1)
+        return 448 if korder == 1 else 0
 
     # ---- plans ------------------------------------------------------------------------------------
     def _ptr(self, key: Optional[str]):
@@ -311,6 +345,27 @@ class PoseProposalNet:
                 sh2, sw2, sc2 = shapes[op.ds_src]
                 d.src2, d.in2_h, d.in2_w, d.cin2, d.stride2 = bufs[op.ds_src].data_ptr(), sh2, sw2, sc2, op.ds_stride
             d.out_raw = bufs[op.out_raw].data_ptr() if (op.out_raw and op.out_raw in bufs) else None
+            if fused and op.nchw_f32_out and self._head_edge_pad():
+                # (1) the unary channels: an ordinary sigmoid NCHW conv straight into the compact unary tensor
+                keys, nun = bufs["keys"], bufs["unary"].shape[1]
+                name, flops = entries.pop()
+                d.cout = nun
+                d.k_total, d.cout_pad = self._dev[op.name + ".geom_unary"]
+                d.weight, d.shift1 = self._ptr(op.name + ".w_unary"), self._ptr(op.name + ".b_unary")
+                d.out_raw = bufs["unary"].data_ptr()
+                d.zero_page = self._dev["zero"].data_ptr()
+                L.check(lib.ppn_plan_add_conv(handle, C.byref(d)), f"ppn_plan_add_conv({op.name}.unary)")
+                entries.append((name + ".unary", flops * nun // op.cout))
+                # (2) the limb channels, one channel tile per edge: keys are stored, not accumulated -- no zero fill
+                ep = self._head_edge_pad()
+                d.cout = op.cout - nun
+                d.k_total, d.cout_pad = self._dev[op.name + ".geom"][0], len(self.edges) * ep
+                d.weight, d.shift1 = self._ptr(op.name + ".w_edge"), self._ptr(op.name + ".b_edge")
+                d.out_raw, d.argmax_keys, d.limb_edge_pad = None, keys.data_ptr(), ep
+                d.limb_window = self.local_grid_size[0] * self.local_grid_size[1]
+                L.check(lib.ppn_plan_add_conv(handle, C.byref(d)), f"ppn_plan_add_conv({op.name}.limbs)")
+                entries.append((name + ".limbs", flops - flops * nun // op.cout))
+                continue
             if fused and op.nchw_f32_out:
                 keys = bufs["keys"]
                 L.check(lib.ppn_plan_add_memset(handle, keys.data_ptr(), keys.numel() * 8), "ppn_plan_add_memset")

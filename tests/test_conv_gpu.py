@@ -117,6 +117,43 @@ def run_conv(x, w, dtype, stride=1, dil=1, pad=0, s1=None, b1=None, act1=0, resi
     return out
 
 
+def run_edge_argmax(x, w, bias, dtype, uch, win, edge_pad=448):
+    """The limb part of a conv3-shaped launch through the edge-aligned tile (ppn_conv_desc.limb_edge_pad): one channel
+    tile per edge, arg-max reduced on the accumulators, keys STORED into a buffer that is NOT zeroed first.  x [B,Cin,H,W],
+    w [uch + E*win, Cin, 1, 1], bias [uch + E*win] CPU f32 -> (keys i64 [B,E,H,W] CPU, kernel name)."""
+    from pytorch_pose_proposal_network_amd import lib as L
+    lib = L.load()
+    dev = torch.device("cuda")
+    tdt = torch.float32 if dtype == L.PPN_F32 else torch.bfloat16
+    B, Cin, H, W = x.shape
+    E = (w.shape[0] - uch) // win
+    kstep, _, korder, ktot, _ = L.conv_tiling(dtype, Cin, 512, 1)
+    assert korder == 1
+    st = torch.cuda.current_stream().cuda_stream
+    we = torch.zeros(E, edge_pad, Cin, 1, 1)
+    we[:, :win] = w[uch:].view(E, win, Cin, 1, 1)
+    we = we.view(E * edge_pad, Cin, 1, 1).contiguous().to(dev)
+    packed = torch.empty(E * edge_pad, ktot, dtype=tdt, device=dev)
+    L.check(lib.ppn_pack_weight(dtype, we.data_ptr(), E * edge_pad, Cin, 1, E * edge_pad, ktot, korder, kstep,
+                                packed.data_ptr(), st))
+    be = torch.full((E, edge_pad), 1000.0)                     # a pad row that competed would win every window
+    be[:, :win] = bias[uch:].view(E, win)
+    be = be.view(-1).contiguous().to(dev)
+    xs = x.permute(0, 2, 3, 1).contiguous().to(dev, tdt)
+    zero = torch.zeros(64, device=dev)
+    keys = torch.full((B, E, H, W), 0x7EADBEEF7EADBEEF, dtype=torch.int64, device=dev)   # garbage: must be overwritten
+    d = L.ConvDesc()
+    d.dtype, d.batch, d.in_h, d.in_w, d.cin = dtype, B, H, W, Cin
+    d.out_h, d.out_w, d.cout = H, W, E * win
+    d.ksize, d.stride, d.dilation, d.pad = 1, 1, 1, 0
+    d.k_total, d.cout_pad, d.act1, d.out_nchw_f32 = ktot, E * edge_pad, 3, 1
+    d.src, d.weight, d.zero_page, d.shift1 = xs.data_ptr(), packed.data_ptr(), zero.data_ptr(), be.data_ptr()
+    d.argmax_keys, d.limb_window, d.limb_edge_pad = keys.data_ptr(), win, edge_pad
+    L.check(lib.ppn_conv2d_fused(C.byref(d), st), "ppn_conv2d_fused")
+    torch.cuda.synchronize()
+    return keys.cpu(), lib.ppn_last_conv_kernel().decode()
+
+
 def ref_conv(x, w, stride=1, dil=1, pad=0, s1=None, b1=None, act1=0, residual=None, s2=None, b2=None, act2=0):
     y = F.conv2d(x.double(), w.double(), None, stride, pad, dil)
     if s1 is not None:

@@ -18,7 +18,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from test_conv_gpu import BF16_TOL, F32_TOL, q, ref_conv, rnd, run_conv
+from test_conv_gpu import BF16_TOL, F32_TOL, q, ref_conv, rnd, run_conv, run_edge_argmax
 
 pytestmark = pytest.mark.gpu
 
@@ -312,6 +312,10 @@ def test_full_size_head_conv3_argmax(dtype_name):
     info2 = {}
     run_conv(x, w, dtype, b1=bias, act1=3, nchw=True, argmax=(uch, win), want_raw=False, info=info2)
     assert torch.equal(info2["keys"], info["keys"]) and torch.equal(info2["unary"], info["unary"])
+    # the edge-aligned tile (what the fused-decode plans launch): same keys, stored instead of accumulated
+    keys_e, kn = run_edge_argmax(x, w, bias, dtype, uch, win)
+    print(kn)
+    assert "head_limb_argmax_kernel" in kn and torch.equal(keys_e, info["keys"])
 
 
 @pytest.mark.parametrize("dtype_name", ["f32", "bf16"])
@@ -360,6 +364,8 @@ def test_head_argmax_ambiguous_segments(force_tile, mode, dtype_name):
     info2 = {}
     run_conv(x, w, dtype, b1=bias, act1=3, nchw=True, argmax=(uch, win), want_raw=False, info=info2)
     assert torch.equal(info2["keys"], info["keys"]) and torch.equal(info2["unary"], info["unary"])
+    keys_e, _ = run_edge_argmax(x, w, bias, dtype, uch, win)   # the edge-aligned tile takes the same decisions
+    assert torch.equal(keys_e, info["keys"])
 
 
 @pytest.mark.parametrize("dtype_name", ["f32", "bf16"])

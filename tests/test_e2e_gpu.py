@@ -182,12 +182,12 @@ def test_ap_of_each_mode_against_reference_people():
 
 # AP gates (see the test above): f32 within 1 point of the ceiling per joint group (knife edges move single people);
 # bf16 total AP at most this far below the ceiling (measured on MI355X, round 3: see profiles/README.md)
-AP_F32_MAX_GAP, AP_BF16_MAX_LOSS = 1.0, 40.0
+AP_F32_MAX_GAP, AP_BF16_MAX_LOSS = 1.0, 45.0
 
 # bf16 gates: measured on MI355X (see profiles/README.md, round 2), set just below the measurement.  The synthetic
 # checkpoint is a randomly initialised network: ~490 of 576 cells are root candidates with near-equal scores, so which
 # of two overlapping roots survives NMS is decided by differences far below bf16 resolution.
-BF16_MIN_SAME_ROOT, BF16_MIN_KP = 0.5, 0.8
+BF16_MIN_SAME_ROOT, BF16_MIN_KP = 0.62, 0.92
 
 
 def test_d54_384_f32_head_vs_reference(golden_dir):
