@@ -372,8 +372,44 @@ def extra_sections(args, dev, net, frames, dec):
             del n_
         return res
 
+    def f16_mode():
+        # the same fused path with IEEE-half operands (v_mfma_f32_16x16x32_f16: the bf16 MFMA rate, 11 significant bits
+        # instead of 8): throughput (one lane and `lanes` lanes) and agreement with the reference pipeline's people
+        n16 = model.PoseProposalNet(getattr(drn, args.arch)(), insize=(S, S), outsize=(S // 16, S // 16),
+                                    compute_dtype="float16").cuda(dev)
+        n16.load_state_dict(net.state_dict())
+        d16 = decode.Decoder(B, (S // 16, S // 16), (S, S), device=dev)
+
+        def step():
+            u, k = n16.forward_u8(frames, fused_decode=True)
+            d16.decode_fused(u, k)
+        dt1 = _time_steps(step, dev, 10, warmup=3)
+        lanes = max(1, args.lanes)
+        pipe16 = rt.MultiLaneInference(n16, B, (S, S), device=dev, lanes=lanes)
+        for _ in range(3 * lanes):
+            pipe16.submit(frames)
+        dtl = _time_steps(lambda: pipe16.submit(frames), dev, 20, warmup=3)
+        pipe16.close()
+        res = {"what": f"the fused path with f16 storage / MFMA operands (not BASELINE's dtype: reported beside it), batch {B}",
+               "images_per_sec": round(B / dtl, 1), "ms_per_step": round(dtl * 1e3, 3), "lanes": lanes,
+               "images_per_sec_one_lane": round(B / dt1, 1)}
+        g = np.load(os.path.join(ROOT, "tests", "golden", "e2e_d22_384.npz"))
+        nb, sz = int(g["batch"]), int(g["size"])
+        if args.arch == str(g["arch"]) and S == sz:
+            fr = torch.from_numpy(prng.u8_frames(int(g["seed_in"]), nb, (sz, sz))).to(dev)
+            got = rt.inference_batch(fr, n16).to_host()
+            tot = np.zeros(5, np.int64)
+            for i in range(nb):
+                tot += np.array(decode.people_agreement({k: g[f"{i}/{k}"] for k in ("n", "kp_cell", "limb_arg")}, got[i]))
+            n, exact, same, kp_eq, kp_all = (int(v) for v in tot)
+            res["f16_agreement"] = {"reference_people": n, "reproduced_exactly": exact, "same_root": same,
+                                    "same_root_frac": round(same / max(n, 1), 4),
+                                    "keypoint_cell_agreement": round(kp_eq / max(kp_all, 1), 4)}
+        return res
+
     section("bf16_agreement", bf16_agreement)
     section("ap_vs_reference", ap_vs_reference)
+    section("f16_mode", f16_mode)
     section("materialized_head", materialized)
     section("decode_stress", decode_stress)
     section("f32_parity_mode", f32_mode)

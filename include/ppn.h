@@ -159,10 +159,13 @@ int ppn_loss_unary_bwd(const ppn_loss_cfg* cfg, const float* head, int32_t batch
  *   out_act = act2(v * scale2 + shift2)             (optional) pre-activation of the consumer block
  * ---------------------------------------------------------------------------------------- */
 enum { PPN_ACT_NONE = 0, PPN_ACT_RELU = 1, PPN_ACT_LRELU = 2, PPN_ACT_SIGMOID = 3 };
-enum { PPN_F32 = 0, PPN_BF16 = 1 };
+/* PPN_F16: IEEE half operands (v_mfma_f32_16x16x32_f16: the bf16 MFMA rate, 3 more mantissa bits), f32 accumulation,
+ * f32 head -- inference only (the conv stack, ppn_plan_add_stem012, ppn_pack_weight); the training entry points take
+ * PPN_F32 / PPN_BF16. */
+enum { PPN_F32 = 0, PPN_BF16 = 1, PPN_F16 = 2 };
 
 typedef struct ppn_conv_desc {
-    int32_t dtype;               /* PPN_F32 (exact-f32 MFMA, parity mode) or PPN_BF16 (bf16 MFMA, f32 accumulate) */
+    int32_t dtype;               /* PPN_F32 (exact-f32 MFMA, parity mode), PPN_BF16 or PPN_F16 (16-bit MFMA, f32 accumulate) */
     int32_t batch, in_h, in_w, cin;
     int32_t out_h, out_w, cout;
     int32_t ksize, stride, dilation, pad;
@@ -310,6 +313,17 @@ int ppn_plan_add_stem012(ppn_plan* p, int32_t src_is_u8, const void* src, int32_
                          const float* w0, const float* scale0, const float* shift0, const float* mean, const float* std_,
                          const float* w1, const float* scale1, const float* shift1, const float* w2, const float* scale2,
                          const float* shift2, const float* scale3, const float* shift3, void* out_raw, void* out_act);
+/* The same with the 16-bit type as an argument: dtype = PPN_BF16 (== the two entry points above) or PPN_F16 (IEEE half
+ * storage and MFMA operands, outputs NHWC f16). */
+int ppn_stem012_dt(int32_t dtype, int32_t src_is_u8, const void* src, int32_t batch, int32_t h, int32_t w, const float* w0,
+                   const float* scale0, const float* shift0, const float* mean, const float* std_, const float* w1,
+                   const float* scale1, const float* shift1, const float* w2, const float* scale2, const float* shift2,
+                   const float* scale3, const float* shift3, void* out_raw, void* out_act, void* stream);
+int ppn_plan_add_stem012_dt(ppn_plan* p, int32_t dtype, int32_t src_is_u8, const void* src, int32_t batch, int32_t h,
+                            int32_t w, const float* w0, const float* scale0, const float* shift0, const float* mean,
+                            const float* std_, const float* w1, const float* scale1, const float* shift1, const float* w2,
+                            const float* scale2, const float* shift2, const float* scale3, const float* shift3,
+                            void* out_raw, void* out_act);
 /* Re-point the first layer's input (same shape/dtype as at ppn_plan_add_stem) before a run. */
 int ppn_plan_set_input(ppn_plan* p, const void* src);
 /* Issue every launch of the plan on `stream`.  After two launch-by-launch runs the sequence is captured into a

@@ -43,10 +43,13 @@ def _bf16(t):
 
 
 def fused_forward_ref(sd, x: torch.Tensor, arch: str = "drn_d_22", emulate_bf16: bool = False, taps=None,
-                      fuse_stem=False):
-    """x f32 [B,3,H,W] (normalised) -> head f32 [B,C,H/16,W/16], walking the fused program."""
+                      fuse_stem=False, emulate_dtype=None):
+    """x f32 [B,3,H,W] (normalised) -> head f32 [B,C,H/16,W/16], walking the fused program.
+    emulate_dtype=torch.float16 emulates the PPN_F16 mode's storage roundings the way emulate_bf16 does bf16's."""
     ops = A.build_program(arch, fuse_stem=fuse_stem)
-    q = _bf16 if emulate_bf16 else (lambda t: t)
+    if emulate_dtype is None and emulate_bf16:
+        emulate_dtype = torch.bfloat16
+    q = (lambda t: t.to(emulate_dtype).float()) if emulate_dtype is not None else (lambda t: t)
     tensors = {"input": x.float()}
     with torch.no_grad():
         for op in ops:

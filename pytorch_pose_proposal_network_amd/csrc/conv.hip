@@ -318,7 +318,7 @@ int launch_tile(const ConvKArgs& a, bool smallc, hipStream_t st, const char** kn
     if (!names[0][0]) {
         for (int i = 0; i < 2; ++i)
             snprintf(names[i], sizeof(names[i]), "conv_igemm_kernel<%s, %d, %d, %d, %d, %s>",
-                     sizeof(T) == 4 ? "float" : "__bf16", BP, BC, WP, WC, i ? "true" : "false");
+                     elem_name<T>(), BP, BC, WP, WC, i ? "true" : "false");
     }
     if (smallc) {
         auto k = conv_igemm_kernel<T, BP, BC, WP, WC, true>;
@@ -398,7 +398,7 @@ int stem3x3_launch(int dtype, const void* src, int batch, int h, int w, int cout
 
 extern "C" int ppn_conv_tiling(int32_t dtype, int32_t cin, int32_t cout, int32_t ksize, int32_t* k_step,
                                int32_t* cout_tile, int32_t* k_order) {
-    if (dtype != PPN_F32 && dtype != PPN_BF16) return ppn::fail(PPN_E_INVALID, "bad dtype %d", dtype);
+    if (dtype != PPN_F32 && dtype != PPN_BF16 && dtype != PPN_F16) return ppn::fail(PPN_E_INVALID, "bad dtype %d", dtype);
     if (cin < 1 || cout < 1 || ksize < 1) return ppn::fail(PPN_E_INVALID, "bad conv shape");
     const int bk = dtype == PPN_F32 ? 32 : 64;
     if (cin == 16 && (cout == 16 || cout == 32) && ksize == 3) {
@@ -419,7 +419,7 @@ extern "C" int ppn_conv_tiling(int32_t dtype, int32_t cin, int32_t cout, int32_t
 
 int ppn::conv_launch(const ppn_conv_desc* d, hipStream_t st, const char** kname) {
     if (!d) return ppn::fail(PPN_E_INVALID, "conv desc is NULL");
-    if (d->dtype != PPN_F32 && d->dtype != PPN_BF16) return ppn::fail(PPN_E_INVALID, "bad dtype %d", d->dtype);
+    if (d->dtype != PPN_F32 && d->dtype != PPN_BF16 && d->dtype != PPN_F16) return ppn::fail(PPN_E_INVALID, "bad dtype %d", d->dtype);
     const int bk = d->dtype == PPN_F32 ? 32 : 64, epc = d->dtype == PPN_F32 ? 4 : 8;
     if (d->batch < 1 || d->in_h < 1 || d->in_w < 1 || d->cin < 1 || d->cout < 1)
         return ppn::fail(PPN_E_INVALID, "bad conv geometry");
@@ -550,11 +550,12 @@ int ppn::conv_launch(const ppn_conv_desc* d, hipStream_t st, const char** kname)
     if (d->argmax_keys) return ppn::fail(PPN_E_UNSUPPORTED, "fused arg-max is implemented by the large-tile kernel only");
     if (d->src2) return ppn::fail(PPN_E_UNSUPPORTED, "the fused shortcut is implemented by the large-tile kernel only");
     if (d->dtype == PPN_F32) return launch_dtype<float>(a, smallc, tc, st, kname);
+    if (d->dtype == PPN_F16) return launch_dtype<_Float16>(a, smallc, tc, st, kname);
     return launch_dtype<__bf16>(a, smallc, tc, st, kname);
 }
 
 extern "C" int ppn_conv_split(int32_t dtype, int32_t cin, int32_t cout, int64_t m, int64_t* m_split) {
-    if (dtype != PPN_F32 && dtype != PPN_BF16) return ppn::fail(PPN_E_INVALID, "bad dtype %d", dtype);
+    if (dtype != PPN_F32 && dtype != PPN_BF16 && dtype != PPN_F16) return ppn::fail(PPN_E_INVALID, "bad dtype %d", dtype);
     if (cin < 1 || cout < 1 || m < 1 || !m_split) return ppn::fail(PPN_E_INVALID, "ppn_conv_split: bad arguments");
     const int bk = dtype == PPN_F32 ? 32 : 64;
     const long long cut = (cin % bk == 0) ? big_split_for(cout, m) : 0;
@@ -602,6 +603,9 @@ static int pack_weight_impl(int32_t dtype, const float* w, int32_t cout, int32_t
                            cin, ksize, cout_pad, k_total, k_order, k_step, transposed);
     else if (dtype == PPN_BF16)
         hipLaunchKernelGGL(pack_weight_kernel<__bf16>, dim3(blocks), dim3(256), 0, st, w, static_cast<__bf16*>(out),
+                           cout, cin, ksize, cout_pad, k_total, k_order, k_step, transposed);
+    else if (dtype == PPN_F16)
+        hipLaunchKernelGGL(pack_weight_kernel<_Float16>, dim3(blocks), dim3(256), 0, st, w, static_cast<_Float16*>(out),
                            cout, cin, ksize, cout_pad, k_total, k_order, k_step, transposed);
     else
         return ppn::fail(PPN_E_INVALID, "bad dtype %d", dtype);

@@ -62,6 +62,13 @@ __device__ __forceinline__ void load4<__bf16>(const char* p, float* v) {
     v[0] = __uint_as_float(a.x << 16); v[1] = __uint_as_float(a.x & 0xffff0000u);
     v[2] = __uint_as_float(a.y << 16); v[3] = __uint_as_float(a.y & 0xffff0000u);
 }
+template <>
+__device__ __forceinline__ void load4<_Float16>(const char* p, float* v) {
+    typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+    const f16x4 a = *reinterpret_cast<const f16x4*>(p);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = (float)a[i];
+}
 template <typename T>
 __device__ __forceinline__ void store4(char* p, const float* v);
 template <>
@@ -75,6 +82,15 @@ __device__ __forceinline__ void store4<__bf16>(char* p, const float* v) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) o[i] = (__bf16)v[i];
     *reinterpret_cast<bf16x4*>(p) = o;
+}
+
+template <>
+__device__ __forceinline__ void store4<_Float16>(char* p, const float* v) {
+    typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+    f16x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = (_Float16)v[i];
+    *reinterpret_cast<f16x4*>(p) = o;
 }
 
 __device__ __forceinline__ void bufload_lds16(__amdgpu_buffer_rsrc_t rsrc, char* lds_wave_base, unsigned voff,
@@ -400,7 +416,7 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
 #ifdef PPN_NO_FAST_EPI
     constexpr bool kFastFits = false;
 #else
-    constexpr bool kFastFits = std::is_same<T, __bf16>::value && BC >= 128 && (size_t)BP * RS16 <= 2 * (size_t)STAGE;
+    constexpr bool kFastFits = sizeof(T) == 2 && BC >= 128 && (size_t)BP * RS16 <= 2 * (size_t)STAGE;
 #endif
     bool fast = false;
     if constexpr (kFastFits) fast = !a.nchw && !a.residual && !a.out_act && a.out_raw && (a.Cout & 7) == 0;
@@ -731,7 +747,7 @@ int launch_sc(const ConvKArgs& a, hipStream_t st, const char** kname) {
     constexpr size_t lds = 2 * (size_t)(BP + BC) * 128;
     static char name[96];
     if (!name[0])
-        snprintf(name, sizeof(name), "conv_igemm_big_kernel<%s, %d, %d, %d, %s>", sizeof(T) == 4 ? "float" : "__bf16",
+        snprintf(name, sizeof(name), "conv_igemm_big_kernel<%s, %d, %d, %d, %s>", elem_name<T>(),
                  BP, BC, NW, SC ? "true" : "false");
     if (kname) *kname = name;
     const size_t src_bytes = (size_t)a.B * a.H * a.W * a.Cin * sizeof(T);
@@ -891,6 +907,7 @@ int launch_big(const ConvKArgs& a, int dtype, BigTile t, hipStream_t st, const c
     if ((size_t)a.B * a.H * a.W * a.Cin * es >= 0x7fffff00ull || (size_t)a.n_ctiles * t.bc * a.Ktot * es >= 0x7fffff00ull)
         return ppn::fail(PPN_E_UNSUPPORTED, "tensor too large for the buffer-addressed conv kernel");
     if (dtype == PPN_F32) return launch_T<float>(a, t, st, kname);
+    if (dtype == PPN_F16) return launch_T<_Float16>(a, t, st, kname);
     return launch_T<__bf16>(a, t, st, kname);
 }
 

@@ -9,6 +9,7 @@ namespace ppnconv {
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 
 // Division by a launch-invariant divisor (Granlund-Montgomery, round-up variant): exact for every 32-bit unsigned
 // dividend, 4 VALU instructions instead of the ~35 of an emulated integer division.  The index arithmetic at the
@@ -68,6 +69,13 @@ template <>
 struct Elem<__bf16> {
     static constexpr int EPC = 8;
 };
+template <>
+struct Elem<_Float16> {
+    static constexpr int EPC = 8;
+};
+// kernel-name spelling of the element type (as rocprofv3 demangles it) and the 16-bit test
+template <typename T> constexpr const char* elem_name() { return sizeof(T) == 4 ? "float" : "__bf16"; }
+template <> constexpr const char* elem_name<_Float16>() { return "_Float16"; }
 
 // sigmoid as exp + reciprocal instructions (v_exp_f32, v_rcp_f32: ~1 ulp each, far inside the 1e-4 head tolerance);
 // every head value -- materialised or folded into arg-max keys -- goes through this one function.
@@ -99,6 +107,10 @@ __device__ __forceinline__ void mma_step(f32x4& acc, const f32x4& wf, const f32x
                                                   acc, 0, 0, 0);
 }
 
+__device__ __forceinline__ void mma_step(f32x4& acc, const f32x4& wf, const f32x4& xf, _Float16*) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wf), __builtin_bit_cast(f16x8, xf), acc, 0, 0, 0);
+}
+
 template <typename T>
 __device__ __forceinline__ void load8(const char* p, float* v);
 template <>
@@ -116,6 +128,12 @@ __device__ __forceinline__ void load8<__bf16>(const char* p, float* v) {
         v[2 * i + 1] = __uint_as_float(u[i] & 0xffff0000u);
     }
 }
+template <>
+__device__ __forceinline__ void load8<_Float16>(const char* p, float* v) {
+    const f16x8 a = *reinterpret_cast<const f16x8*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)a[i];
+}
 template <typename T>
 __device__ __forceinline__ void store8(char* p, const float* v);
 template <>
@@ -129,6 +147,14 @@ __device__ __forceinline__ void store8<__bf16>(char* p, const float* v) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) o[i] = (__bf16)v[i];                 // RNE, v_cvt_pk_bf16_f32
     *reinterpret_cast<bf16x8*>(p) = o;
+}
+
+template <>
+__device__ __forceinline__ void store8<_Float16>(char* p, const float* v) {
+    f16x8 o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (_Float16)v[i];               // RNE, v_cvt_f16_f32 (saturates to +-inf past 65504)
+    *reinterpret_cast<f16x8*>(p) = o;
 }
 
 // conv_big.hip: 512-thread, (BP x BC) = ({128,192,256} x {128,256}) tiles for Cin % K-step == 0 layers

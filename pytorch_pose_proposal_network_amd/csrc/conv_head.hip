@@ -414,7 +414,7 @@ template <typename T>
 int launch_T(const HeadArgs& a, int batch, hipStream_t st, const char** kname) {
     constexpr size_t lds = 2 * (size_t)STAGE + SCRATCH;
     static char name[80];
-    if (!name[0]) snprintf(name, sizeof(name), "head_limb_argmax_kernel<%s>", sizeof(T) == 4 ? "float" : "__bf16");
+    if (!name[0]) snprintf(name, sizeof(name), "head_limb_argmax_kernel<%s>", elem_name<T>());
     if (kname) *kname = name;
     auto k = head_limb_argmax_kernel<T>;
     {
@@ -474,6 +474,7 @@ int head_limb_launch(const ppn_conv_desc* d, long long m_lo, long long m_hi, hip
 #endif
     // M is the END of the range in the whole tensor; the source descriptor must cover every row below it
     if (d->dtype == PPN_F32) return launch_T<float>(a, d->batch, st, kname);
+    if (d->dtype == PPN_F16) return launch_T<_Float16>(a, d->batch, st, kname);
     return launch_T<__bf16>(a, d->batch, st, kname);
 }
 

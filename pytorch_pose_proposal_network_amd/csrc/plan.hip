@@ -14,7 +14,7 @@ int stem_launch(int dtype, int src_is_u8, const void* src, int batch, int h, int
 int stem01_launch(int dtype, int src_is_u8, const void* src, int batch, int h, int w, const float* w0,
                   const float* s0, const float* b0, const float* mean, const float* stdv, const float* w1,
                   const float* s1, const float* b1, void* out, hipStream_t st);
-int stem012_launch(int src_is_u8, const void* src, int batch, int h, int w, const float* w0, const float* s0,
+int stem012_launch(int dtype, int src_is_u8, const void* src, int batch, int h, int w, const float* w0, const float* s0,
                    const float* b0, const float* mean, const float* stdv, const float* w1, const float* s1,
                    const float* b1, const float* w2, const float* s2, const float* b2, const float* s3, const float* b3,
                    void* out_raw, void* out_act, hipStream_t st);
@@ -83,7 +83,7 @@ static int run_op(ppn_plan::Op& op, hipStream_t st) {
     }
     if (op.kind == 4) {
         if (op.kname.empty()) op.kname = "stem012_kernel";
-        return ppn::stem012_launch(op.src_is_u8, op.src, op.batch, op.h, op.w, op.weight, op.scale, op.shift, op.mean,
+        return ppn::stem012_launch(op.dtype, op.src_is_u8, op.src, op.batch, op.h, op.w, op.weight, op.scale, op.shift, op.mean,
                                    op.stdv, op.w1, op.scale1, op.shift1, op.w2, op.scale2, op.shift2, op.scale3,
                                    op.shift3, op.out, op.out2, st);
     }
@@ -154,21 +154,31 @@ extern "C" int ppn_plan_add_stem01(ppn_plan* p, int32_t dtype, int32_t src_is_u8
     return PPN_OK;
 }
 
-extern "C" int ppn_plan_add_stem012(ppn_plan* p, int32_t src_is_u8, const void* src, int32_t batch, int32_t h,
+extern "C" int ppn_plan_add_stem012_dt(ppn_plan* p, int32_t dtype, int32_t src_is_u8, const void* src, int32_t batch, int32_t h,
                                     int32_t w, const float* w0, const float* scale0, const float* shift0,
                                     const float* mean, const float* std_, const float* w1, const float* scale1,
                                     const float* shift1, const float* w2, const float* scale2, const float* shift2,
                                     const float* scale3, const float* shift3, void* out_raw, void* out_act) {
     if (!p) return ppn::fail(PPN_E_INVALID, "ppn_plan_add_stem012: NULL plan");
+    if (dtype != PPN_BF16 && dtype != PPN_F16) return ppn::fail(PPN_E_INVALID, "ppn_plan_add_stem012: dtype must be PPN_BF16 or PPN_F16");
     ppn_plan::Op op{};
     op.kind = 4;
-    op.dtype = PPN_BF16; op.src_is_u8 = src_is_u8; op.src = src; op.batch = batch; op.h = h; op.w = w;
+    op.dtype = dtype; op.src_is_u8 = src_is_u8; op.src = src; op.batch = batch; op.h = h; op.w = w;
     op.weight = w0; op.scale = scale0; op.shift = shift0; op.w1 = w1; op.scale1 = scale1; op.shift1 = shift1;
     op.w2 = w2; op.scale2 = scale2; op.shift2 = shift2; op.scale3 = scale3; op.shift3 = shift3;
     op.out = out_raw; op.out2 = out_act;
     for (int i = 0; i < 3; ++i) { op.mean[i] = mean ? mean[i] : 0.f; op.stdv[i] = std_ ? std_[i] : 1.f; }
     p->ops.push_back(op);
     return PPN_OK;
+}
+
+extern "C" int ppn_plan_add_stem012(ppn_plan* p, int32_t src_is_u8, const void* src, int32_t batch, int32_t h,
+                                    int32_t w, const float* w0, const float* scale0, const float* shift0,
+                                    const float* mean, const float* std_, const float* w1, const float* scale1,
+                                    const float* shift1, const float* w2, const float* scale2, const float* shift2,
+                                    const float* scale3, const float* shift3, void* out_raw, void* out_act) {
+    return ppn_plan_add_stem012_dt(p, PPN_BF16, src_is_u8, src, batch, h, w, w0, scale0, shift0, mean, std_, w1, scale1,
+                                   shift1, w2, scale2, shift2, scale3, shift3, out_raw, out_act);
 }
 
 extern "C" int ppn_plan_set_input(ppn_plan* p, const void* src) {

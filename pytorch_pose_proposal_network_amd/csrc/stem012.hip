@@ -42,6 +42,7 @@ namespace {
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
@@ -95,13 +96,18 @@ __device__ __forceinline__ u32x2 lds_read64(unsigned addr) {
     return v;
 }
 
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c, int, int, int) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c, int, int, int) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+
 // BN + ReLU of one accumulator tile -> 4 packed bf16 channels (zero when `inside` is false)
+template <typename H>
 __device__ __forceinline__ u32x2 bn_relu_pack(const f32x4& acc, const float (&sc)[4], const float (&sh)[4], bool inside) {
-    bf16x4 o;
+    typedef __attribute__((ext_vector_type(4))) H hx4;
+    hx4 o;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const float t = acc[r] * sc[r] + sh[r];
-        o[r] = (__bf16)(t > 0.f ? t : 0.f);
+        o[r] = (H)(t > 0.f ? t : 0.f);
     }
     u32x2 p = __builtin_bit_cast(u32x2, o);
     p.x = inside ? p.x : 0u;
@@ -109,8 +115,11 @@ __device__ __forceinline__ u32x2 bn_relu_pack(const f32x4& acc, const float (&sc
     return p;
 }
 
-template <bool U8>
+// H: the 16-bit storage / MFMA operand type (__bf16, or _Float16 for the PPN_F16 mode: same schedule, same rate)
+template <bool U8, typename H>
 __global__ void __launch_bounds__(256, 2) stem012_kernel(Stem012Args a) {
+    typedef __attribute__((ext_vector_type(8))) H hx8;
+    typedef __attribute__((ext_vector_type(4))) H hx4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* in_p = smem;                                  // [RI][WI][4] bf16
     char* l0_p = smem + LDS_IN;                         // [R0][W0][16] bf16
@@ -122,9 +131,9 @@ __global__ void __launch_bounds__(256, 2) stem012_kernel(Stem012Args a) {
     const int ch = lane & 15, g = lane >> 4, col = lane & 15;
 
     // ---- weights as MFMA A fragments (rows = output channels), same k layout as stem.hip / stem3x3.hip ----------
-    bf16x8 wa0[7];           // per dy: k = (dx = 2g + (i>>2), c = i&3)
-    bf16x8 wa1[5];           // k-step kk: k = 8g+i -> tap 2kk + (g>>1), ci = (g&1)*8 + i
-    bf16x8 wa2[2][5];
+    hx8 wa0[7];           // per dy: k = (dx = 2g + (i>>2), c = i&3)
+    hx8 wa1[5];           // k-step kk: k = 8g+i -> tap 2kk + (g>>1), ci = (g&1)*8 + i
+    hx8 wa2[2][5];
     {
         const float* wc = a.w0 + (size_t)ch * 3 * 49;
 #pragma unroll
@@ -132,14 +141,14 @@ __global__ void __launch_bounds__(256, 2) stem012_kernel(Stem012Args a) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int dx = 2 * g + (i >> 2), c = i & 3;
-                wa0[dy][i] = (__bf16)((dx < 7 && c < 3) ? wc[(c * 7 + dy) * 7 + dx] : 0.f);
+                wa0[dy][i] = (H)((dx < 7 && c < 3) ? wc[(c * 7 + dy) * 7 + dx] : 0.f);
             }
         const float* wd = a.w1 + (size_t)ch * 16 * 9;
 #pragma unroll
         for (int kk = 0; kk < 5; ++kk) {
             const int tap = 2 * kk + (g >> 1);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) wa1[kk][i] = (__bf16)(tap < 9 ? wd[((g & 1) * 8 + i) * 9 + tap] : 0.f);
+            for (int i = 0; i < 8; ++i) wa1[kk][i] = (H)(tap < 9 ? wd[((g & 1) * 8 + i) * 9 + tap] : 0.f);
         }
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
@@ -148,7 +157,7 @@ __global__ void __launch_bounds__(256, 2) stem012_kernel(Stem012Args a) {
             for (int kk = 0; kk < 5; ++kk) {
                 const int tap = 2 * kk + (g >> 1);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) wa2[ct][kk][i] = (__bf16)(tap < 9 ? we[((g & 1) * 8 + i) * 9 + tap] : 0.f);
+                for (int i = 0; i < 8; ++i) wa2[ct][kk][i] = (H)(tap < 9 ? we[((g & 1) * 8 + i) * 9 + tap] : 0.f);
             }
         }
     }
@@ -169,7 +178,7 @@ __global__ void __launch_bounds__(256, 2) stem012_kernel(Stem012Args a) {
         // bf16 as the patch stores it -- the same expression stem.hip evaluates per pixel
         for (int i = tid; i < 3 * 256; i += 256) {
             const int c = i >> 8;
-            const __bf16 v = (__bf16)(((float)(i & 255) - a.mean[c]) / a.stdv[c]);
+            const H v = (H)(((float)(i & 255) - a.mean[c]) / a.stdv[c]);
             lut_p[i] = __builtin_bit_cast(unsigned short, v);
         }
     }
@@ -242,8 +251,8 @@ __global__ void __launch_bounds__(256, 2) stem012_kernel(Stem012Args a) {
                     } else {
                         const float* s = static_cast<const float*>(a.src) + ((size_t)b * 3 * a.H + gy) * a.W + gx;
                         const size_t plane = (size_t)a.H * a.W;
-                        bf16x4 t;
-                        t[0] = (__bf16)s[0]; t[1] = (__bf16)s[plane]; t[2] = (__bf16)s[2 * plane]; t[3] = (__bf16)0.f;
+                        hx4 t;
+                        t[0] = (H)s[0]; t[1] = (H)s[plane]; t[2] = (H)s[2 * plane]; t[3] = (H)0.f;
                         o = __builtin_bit_cast(u32x2, t);
                     }
                 }
@@ -276,11 +285,11 @@ __global__ void __launch_bounds__(256, 2) stem012_kernel(Stem012Args a) {
 #pragma unroll
                 for (int dy = 0; dy < 7; ++dy) {
                     const u32x4 xb = {lo[dy].x, lo[dy].y, hi[dy].x, hi[dy].y};
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa0[dy], __builtin_bit_cast(bf16x8, xb), acc, 0, 0, 0);
+                    acc = mfma16(wa0[dy], __builtin_bit_cast(hx8, xb), acc, 0, 0, 0);
                 }
                 const int gx = x0b + sg * 16 + col;
                 // BN + ReLU (drn.py:126-127); zero outside the image: layer1 pads layer0's output with 0
-                *reinterpret_cast<u32x2*>(wr + sg * 128) = bn_relu_pack(acc, sc0, sh0, rowok && gx >= 0 && gx < a.W);
+                *reinterpret_cast<u32x2*>(wr + sg * 128) = bn_relu_pack<H>(acc, sc0, sh0, rowok && gx >= 0 && gx < a.W);
             });
         };
         // layer-1 rows y .. y+nrows-1 from layer-0 rows y-1 .. y+nrows -> ring; wave w computes row y + w
@@ -312,10 +321,10 @@ __global__ void __launch_bounds__(256, 2) stem012_kernel(Stem012Args a) {
 #pragma unroll
                 for (int kk = 0; kk < 5; ++kk) {
                     const u32x4 xb = {lo[kk].x, lo[kk].y, hi[kk].x, hi[kk].y};
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa1[kk], __builtin_bit_cast(bf16x8, xb), acc, 0, 0, 0);
+                    acc = mfma16(wa1[kk], __builtin_bit_cast(hx8, xb), acc, 0, 0, 0);
                 }
                 const int gx = x1b + sg * 16 + col;
-                *reinterpret_cast<u32x2*>(wr + sg * 128) = bn_relu_pack(acc, sc1, sh1, rowok && gx >= 0 && gx < a.W);
+                *reinterpret_cast<u32x2*>(wr + sg * 128) = bn_relu_pack<H>(acc, sc1, sh1, rowok && gx >= 0 && gx < a.W);
             });
         };
         // layer-2 rows oy0 .. oy0+nrows-1 (stride 2) from layer-1 rows 2oy-1 .. -> HBM; waves 0,1 take row 0, waves 2,3
@@ -348,27 +357,27 @@ __global__ void __launch_bounds__(256, 2) stem012_kernel(Stem012Args a) {
 #pragma unroll
                 for (int kk = 0; kk < 5; ++kk) {
                     const u32x4 xw = {lo[kk].x, lo[kk].y, hi[kk].x, hi[kk].y};
-                    const bf16x8 xb = __builtin_bit_cast(bf16x8, xw);
+                    const hx8 xb = __builtin_bit_cast(hx8, xw);
 #pragma unroll
                     for (int ct = 0; ct < 2; ++ct)
-                        acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa2[ct][kk], xb, acc[ct], 0, 0, 0);
+                        acc[ct] = mfma16(wa2[ct][kk], xb, acc[ct], 0, 0, 0);
                 }
                 if (oy < a.Ho && ox < a.Wo) {
                     const size_t pix = ((size_t)b * a.Ho + oy) * a.Wo + ox;
 #pragma unroll
                     for (int ct = 0; ct < 2; ++ct) {
-                        bf16x4 ov, ou;
+                        hx4 ov, ou;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const float t = acc[ct][r] * sc2[ct][r] + sh2[ct][r];
                             const float v = t > 0.f ? t : 0.f;               // BN + ReLU (drn.py:198-200)
                             const float w2 = v * sc3[ct][r] + sh3[ct][r];
-                            ov[r] = (__bf16)v;
-                            ou[r] = (__bf16)(w2 > 0.f ? w2 : 0.f);           // next block's relu(bn1(x)) (drn.py:45-46)
+                            ov[r] = (H)v;
+                            ou[r] = (H)(w2 > 0.f ? w2 : 0.f);           // next block's relu(bn1(x)) (drn.py:45-46)
                         }
                         const size_t o = pix * 32 + ct * 16 + 4 * g;
-                        if (a.out_raw) *reinterpret_cast<bf16x4*>(static_cast<__bf16*>(a.out_raw) + o) = ov;
-                        if (a.out_act) *reinterpret_cast<bf16x4*>(static_cast<__bf16*>(a.out_act) + o) = ou;
+                        if (a.out_raw) *reinterpret_cast<hx4*>(static_cast<H*>(a.out_raw) + o) = ov;
+                        if (a.out_act) *reinterpret_cast<hx4*>(static_cast<H*>(a.out_act) + o) = ou;
                     }
                 }
             }
@@ -405,7 +414,16 @@ __global__ void __launch_bounds__(256, 2) stem012_kernel(Stem012Args a) {
 }  // namespace
 
 namespace ppn {
-int stem012_launch(int src_is_u8, const void* src, int batch, int h, int w, const float* w0, const float* s0,
+template <bool U8, typename H>
+static int stem012_launch_T(const Stem012Args& a, unsigned grid, hipStream_t st) {
+    static int max_lds_set = 0;
+    PPN_LDS_ONCE(max_lds_set, reinterpret_cast<const void*>(stem012_kernel<U8, H>),
+                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    hipLaunchKernelGGL((stem012_kernel<U8, H>), dim3(grid), dim3(256), LDS_BYTES, st, a);
+    return PPN_OK;
+}
+
+int stem012_launch(int dtype, int src_is_u8, const void* src, int batch, int h, int w, const float* w0, const float* s0,
                    const float* b0, const float* mean, const float* stdv, const float* w1, const float* s1,
                    const float* b1, const float* w2, const float* s2, const float* b2, const float* s3, const float* b3,
                    void* out_raw, void* out_act, hipStream_t st) {
@@ -425,17 +443,13 @@ int stem012_launch(int src_is_u8, const void* src, int batch, int h, int w, cons
     if ((long long)batch * h * w * 3 > 0xffffffffLL) return fail(PPN_E_UNSUPPORTED, "frames too large for 32-bit byte offsets");
     static const int per_cu = getenv("PPN_S012_WGS") ? atoi(getenv("PPN_S012_WGS")) : 2;   // tuning knob
     const unsigned grid = (unsigned)(units < 256 * per_cu ? units : 256 * per_cu);   // persistent: 2 workgroups per CU
-    if (src_is_u8) {
-        static int max_lds_set = 0;
-        PPN_LDS_ONCE(max_lds_set, reinterpret_cast<const void*>(stem012_kernel<true>),
-                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        hipLaunchKernelGGL(stem012_kernel<true>, dim3(grid), dim3(256), LDS_BYTES, st, a);
-    } else {
-        static int max_lds_set = 0;
-        PPN_LDS_ONCE(max_lds_set, reinterpret_cast<const void*>(stem012_kernel<false>),
-                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        hipLaunchKernelGGL(stem012_kernel<false>, dim3(grid), dim3(256), LDS_BYTES, st, a);
-    }
+    if (dtype != PPN_BF16 && dtype != PPN_F16) return fail(PPN_E_INVALID, "ppn_stem012: dtype must be PPN_BF16 or PPN_F16");
+    int rc;
+    if (dtype == PPN_F16)
+        rc = src_is_u8 ? stem012_launch_T<true, _Float16>(a, grid, st) : stem012_launch_T<false, _Float16>(a, grid, st);
+    else
+        rc = src_is_u8 ? stem012_launch_T<true, __bf16>(a, grid, st) : stem012_launch_T<false, __bf16>(a, grid, st);
+    if (rc != PPN_OK) return rc;
     PPN_LAUNCH_CHECK();
     return PPN_OK;
 }
@@ -446,6 +460,15 @@ extern "C" int ppn_stem012(int32_t src_is_u8, const void* src, int32_t batch, in
                            const float* w1, const float* scale1, const float* shift1, const float* w2,
                            const float* scale2, const float* shift2, const float* scale3, const float* shift3,
                            void* out_raw, void* out_act, void* stream) {
-    return ppn::stem012_launch(src_is_u8, src, batch, h, w, w0, scale0, shift0, mean, std_, w1, scale1, shift1, w2,
+    return ppn::stem012_launch(PPN_BF16, src_is_u8, src, batch, h, w, w0, scale0, shift0, mean, std_, w1, scale1, shift1,
+                               w2, scale2, shift2, scale3, shift3, out_raw, out_act, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int ppn_stem012_dt(int32_t dtype, int32_t src_is_u8, const void* src, int32_t batch, int32_t h, int32_t w,
+                              const float* w0, const float* scale0, const float* shift0, const float* mean,
+                              const float* std_, const float* w1, const float* scale1, const float* shift1,
+                              const float* w2, const float* scale2, const float* shift2, const float* scale3,
+                              const float* shift3, void* out_raw, void* out_act, void* stream) {
+    return ppn::stem012_launch(dtype, src_is_u8, src, batch, h, w, w0, scale0, shift0, mean, std_, w1, scale1, shift1, w2,
                                scale2, shift2, scale3, shift3, out_raw, out_act, static_cast<hipStream_t>(stream));
 }

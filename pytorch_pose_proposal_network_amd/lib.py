@@ -10,7 +10,7 @@ LIB_PATH = os.environ.get("PPN_LIB", os.path.join(_HERE, "csrc", "libppn.so"))  
 
 PPN_MAX_EDGES = 32
 PPN_MAX_KP = 32
-PPN_F32, PPN_BF16 = 0, 1
+PPN_F32, PPN_BF16, PPN_F16 = 0, 1, 2
 PPN_ACT_NONE, PPN_ACT_RELU, PPN_ACT_LRELU, PPN_ACT_SIGMOID = 0, 1, 2, 3
 
 
@@ -98,6 +98,10 @@ _SIGNATURES = {
                     [C.POINTER(C.c_float)] * 2 + [C.c_void_p] * 11),
     "ppn_plan_add_stem012": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32] +
                              [C.c_void_p] * 3 + [C.POINTER(C.c_float)] * 2 + [C.c_void_p] * 10),
+    "ppn_stem012_dt": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 3 +
+                       [C.POINTER(C.c_float)] * 2 + [C.c_void_p] * 11),
+    "ppn_plan_add_stem012_dt": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32] +
+                                [C.c_void_p] * 3 + [C.POINTER(C.c_float)] * 2 + [C.c_void_p] * 10),
     "ppn_plan_create": (C.c_int, [C.POINTER(C.c_void_p)]),
     "ppn_plan_add_conv": (C.c_int, [C.c_void_p, C.POINTER(ConvDesc)]),
     "ppn_plan_add_memset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),

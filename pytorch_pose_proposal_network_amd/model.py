@@ -74,15 +74,18 @@ class PoseProposalNet:
         self.gridsize = (int(inW / outW), int(inH / outH))
         self.lastsize = 6 * len(keypoint_names) + sW * sH * len(edges)          # model.py:64
         self.compute_dtype = {"float32": L.PPN_F32, "fp32": L.PPN_F32, "bfloat16": L.PPN_BF16,
-                              "bf16": L.PPN_BF16}[compute_dtype]
+                              "bf16": L.PPN_BF16, "float16": L.PPN_F16, "fp16": L.PPN_F16, "f16": L.PPN_F16}[compute_dtype]
         self.training = False
         self.device = torch.device("cuda")
         if fuse_stem is None:
             # bf16 mode: the three stem layers share one launch (csrc/stem012.hip; PPN_FUSE_STEM=0 keeps them apart);
             # the exact-f32 parity mode runs them layer by layer
-            fuse_stem = "all" if (self.compute_dtype == L.PPN_BF16 and os.environ.get("PPN_FUSE_STEM", "1") != "0") else False
-        if fuse_stem == "all" and self.compute_dtype != L.PPN_BF16:
-            raise ValueError("fuse_stem='all' (csrc/stem012.hip) is a bf16-mode kernel")
+            fuse_stem = "all" if (self.compute_dtype == L.PPN_F16 or (
+                self.compute_dtype == L.PPN_BF16 and os.environ.get("PPN_FUSE_STEM", "1") != "0")) else False
+        if fuse_stem == "all" and self.compute_dtype == L.PPN_F32:
+            raise ValueError("fuse_stem='all' (csrc/stem012.hip) is a 16-bit-mode kernel")
+        if self.compute_dtype == L.PPN_F16 and fuse_stem != "all":
+            raise ValueError("the float16 mode runs the stem through csrc/stem012.hip only (fuse_stem='all')")
         if fuse_shortcut is None:                             # tuning knob: PPN_FUSE_SHORTCUT=0 keeps the 1x1 shortcuts apart
             fuse_shortcut = os.environ.get("PPN_FUSE_SHORTCUT", "1") != "0"
         self._ops: List[A.ConvOp] = A.build_program(self.arch, self.lastsize, fuse_stem=fuse_stem,
@@ -113,6 +116,8 @@ class PoseProposalNet:
         state_dict; the training loop then calls ``model.trainer.train_step(x, targets)``.
         mode=False: back to the folded-BN inference plan; parameters and running statistics the trainer changed are
         folded again first."""
+        if mode and self.compute_dtype == L.PPN_F16:
+            raise RuntimeError("PoseProposalNet.train(): the float16 mode is inference only (train in bfloat16 / float32)")
         if mode and not self.training:
             if not self._sd:
                 raise RuntimeError("PoseProposalNet.train(): call load_state_dict() first")
@@ -179,7 +184,7 @@ class PoseProposalNet:
         self._plans.clear()
         self._dev["zero"] = torch.zeros(64, dtype=torch.float32, device=dev)
         stream = L.current_stream_ptr()
-        tdt = torch.float32 if self.compute_dtype == L.PPN_F32 else torch.bfloat16
+        tdt = self._tdt()
         for op in self._ops:
             w = self._sd[op.weight].float().contiguous()
             s1 = b1 = None
@@ -256,6 +261,9 @@ class PoseProposalNet:
                 torch.cuda.synchronize(dev)               # `wu` / `we` die here: their pack kernels must have run
         torch.cuda.synchronize(dev)
 
+    def _tdt(self):
+        return {L.PPN_F32: torch.float32, L.PPN_BF16: torch.bfloat16, L.PPN_F16: torch.float16}[self.compute_dtype]
+
     def _head_edge_pad(self) -> int:
         """Rows per edge of the edge-aligned limb tile (448) when the limb window fits it (385..448 values, e.g. the
         reference's 21 x 21), else 0: the chunked epilogue with atomicMax keys.  PPN_HEAD_EDGE=0 forces the latter."""
@@ -276,7 +284,7 @@ class PoseProposalNet:
         # the plan's own input buffer: u8 [B,H,W,3] frames or the f32 [B,3,H,W] normalised image of model.forward
         src = (torch.empty(batch, h, w, 3, dtype=torch.uint8, device=dev) if src_is_u8 else
                torch.empty(batch, 3, h, w, dtype=torch.float32, device=dev))
-        tdt = torch.float32 if self.compute_dtype == L.PPN_F32 else torch.bfloat16
+        tdt = self._tdt()
         shapes = A.tensor_shapes(self._ops, h, w)
         bufs: Dict[str, torch.Tensor] = {}
         for name, (th, tw, tc) in shapes.items():
@@ -301,8 +309,8 @@ class PoseProposalNet:
             oh, ow = A.out_hw(op, ih, iw)
             entries.append((op.name, A.op_flops(op, shapes) * batch))
             if op.k == 7 and op.next_s2 is not None:
-                assert op.src == "input" and self.compute_dtype == L.PPN_BF16
-                L.check(lib.ppn_plan_add_stem012(handle, 1 if src_is_u8 else 0, src.data_ptr(), batch, h, w,
+                assert op.src == "input" and self.compute_dtype in (L.PPN_BF16, L.PPN_F16)
+                L.check(lib.ppn_plan_add_stem012_dt(handle, self.compute_dtype, 1 if src_is_u8 else 0, src.data_ptr(), batch, h, w,
                                                  self._ptr(op.name + ".w"), self._ptr(op.name + ".s1"),
                                                  self._ptr(op.name + ".b1"), self._mean, self._std,
                                                  self._ptr(op.name + ".w1"), self._ptr(op.name + ".s1b"),
@@ -311,7 +319,7 @@ class PoseProposalNet:
                                                  self._ptr(op.name + ".s2"), self._ptr(op.name + ".b2"),
                                                  bufs[op.out_raw].data_ptr() if op.out_raw else None,
                                                  bufs[op.out_act].data_ptr() if op.out_act else None),
-                        "ppn_plan_add_stem012")
+                        "ppn_plan_add_stem012_dt")
                 continue
             if op.k == 7 and op.next3x3 is not None:
                 assert op.src == "input" and op.out_act is None

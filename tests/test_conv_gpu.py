@@ -12,6 +12,7 @@ pytestmark = pytest.mark.gpu
 
 F32_TOL = 2e-5      # relative to the output scale; exact-f32 MFMA vs torch CPU summation order
 BF16_TOL = 2e-2
+F16_TOL = 3e-3      # IEEE half keeps 11 significant bits (bf16: 8)
 
 
 def _act(v, a):
@@ -30,7 +31,7 @@ def run_conv(x, w, dtype, stride=1, dil=1, pad=0, s1=None, b1=None, act1=0, resi
     from pytorch_pose_proposal_network_amd import lib as L
     lib = L.load()
     dev = torch.device("cuda")
-    tdt = torch.float32 if dtype == L.PPN_F32 else torch.bfloat16
+    tdt = {L.PPN_F32: torch.float32, L.PPN_BF16: torch.bfloat16, L.PPN_F16: torch.float16}[dtype]
     B, Cin, H, W = x.shape
     Cout, _, k, _ = w.shape
     eff = dil * (k - 1) + 1
@@ -124,7 +125,7 @@ def run_edge_argmax(x, w, bias, dtype, uch, win, edge_pad=448):
     from pytorch_pose_proposal_network_amd import lib as L
     lib = L.load()
     dev = torch.device("cuda")
-    tdt = torch.float32 if dtype == L.PPN_F32 else torch.bfloat16
+    tdt = {L.PPN_F32: torch.float32, L.PPN_BF16: torch.bfloat16, L.PPN_F16: torch.float16}[dtype]
     B, Cin, H, W = x.shape
     E = (w.shape[0] - uch) // win
     kstep, _, korder, ktot, _ = L.conv_tiling(dtype, Cin, 512, 1)
@@ -176,8 +177,10 @@ def rnd(*shape, seed=0, scale=1.0):
 
 
 def q(t, dtype):
-    """Round inputs to bf16 first in bf16 mode so that only accumulation/epilogue error is measured."""
+    """Round inputs to the storage type first in the 16-bit modes so that only accumulation/epilogue error is measured."""
     from pytorch_pose_proposal_network_amd import lib as L
+    if dtype == L.PPN_F16:
+        return t.to(torch.float16).float()
     return t.to(torch.bfloat16).float() if dtype == L.PPN_BF16 else t
 
 

@@ -18,7 +18,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from test_conv_gpu import BF16_TOL, F32_TOL, q, ref_conv, rnd, run_conv, run_edge_argmax
+from test_conv_gpu import BF16_TOL, F16_TOL, F32_TOL, q, ref_conv, rnd, run_conv, run_edge_argmax
 
 pytestmark = pytest.mark.gpu
 
@@ -39,11 +39,15 @@ def force_tile():
 
 def _dt(name):
     from pytorch_pose_proposal_network_amd import lib as L
-    return L.PPN_F32 if name == "f32" else L.PPN_BF16
+    return {"f32": L.PPN_F32, "bf16": L.PPN_BF16, "f16": L.PPN_F16}[name]
+
+
+def _tol(name):
+    return {"f32": F32_TOL, "bf16": BF16_TOL, "f16": F16_TOL}[name]
 
 
 def _kname(dtype_name, bp, bc, sc=False):
-    return "conv_igemm_big_kernel<%s, %d, %d, 8, %s>" % ("float" if dtype_name == "f32" else "__bf16", bp, bc,
+    return "conv_igemm_big_kernel<%s, %d, %d, 8, %s>" % ({"f32": "float", "bf16": "__bf16", "f16": "_Float16"}[dtype_name], bp, bc,
                                                          "true" if sc else "false")
 
 
@@ -52,7 +56,7 @@ def _cout_for(bc):
     return {256: 320, 128: 200, 64: 200}[bc]
 
 
-@pytest.mark.parametrize("dtype_name", ["f32", "bf16"])
+@pytest.mark.parametrize("dtype_name", ["f32", "bf16", "f16"])
 @pytest.mark.parametrize("tile", TILES, ids=["%dx%d" % t for t in TILES])
 def test_forced_tile_single_output(force_tile, tile, dtype_name):
     """conv + BN + ReLU, one output: bf16 takes the single-pass epilogue where the tile fits it."""
@@ -69,12 +73,12 @@ def test_forced_tile_single_output(force_tile, tile, dtype_name):
     ref, _ = ref_conv(x, w, 1, 2, 2, s1, b1, act1=1)
     print(info["kernel"])
     assert info["kernel"] == _kname(dtype_name, bp, bc)
-    tol = (F32_TOL if dtype_name == "f32" else BF16_TOL) * max(1.0, float(ref.abs().max()))
+    tol = _tol(dtype_name) * max(1.0, float(ref.abs().max()))
     assert not torch.isnan(raw).any()
     assert float((raw - ref).abs().max()) <= tol
 
 
-@pytest.mark.parametrize("dtype_name", ["f32", "bf16"])
+@pytest.mark.parametrize("dtype_name", ["f32", "bf16", "f16"])
 @pytest.mark.parametrize("tile", TILES, ids=["%dx%d" % t for t in TILES])
 def test_forced_tile_residual_dual_output(force_tile, tile, dtype_name):
     """conv2 of a BasicBlock: raw = acc + residual, act = relu(bn_next(raw)) -- the chunked f32 epilogue."""
@@ -91,7 +95,7 @@ def test_forced_tile_residual_dual_output(force_tile, tile, dtype_name):
     rr, ra = ref_conv(x, w, 1, 1, 1, residual=res, s2=s2, b2=b2, act2=1)
     print(info["kernel"])
     assert info["kernel"] == _kname(dtype_name, bp, bc)
-    tol = F32_TOL * 10 if dtype_name == "f32" else BF16_TOL * 2
+    tol = F32_TOL * 10 if dtype_name == "f32" else _tol(dtype_name) * 2
     assert not torch.isnan(raw).any() and not torch.isnan(act).any()
     assert float((raw - rr).abs().max()) <= tol * max(1.0, float(rr.abs().max()))
     assert float((act - ra).abs().max()) <= tol * max(1.0, float(ra.abs().max()))
@@ -105,7 +109,7 @@ def test_forced_tile_residual_dual_output(force_tile, tile, dtype_name):
 SC_TILES = [t for t in TILES if t[1] >= 128]
 
 
-@pytest.mark.parametrize("dtype_name", ["f32", "bf16"])
+@pytest.mark.parametrize("dtype_name", ["f32", "bf16", "f16"])
 @pytest.mark.parametrize("tile", SC_TILES, ids=["%dx%d" % t for t in SC_TILES])
 def test_forced_tile_fused_shortcut(force_tile, tile, dtype_name):
     """conv2 + BasicBlock.downsample as one GEMM (the SC=true instantiations), with the pre-activation output."""
@@ -127,7 +131,7 @@ def test_forced_tile_fused_shortcut(force_tile, tile, dtype_name):
     y = F.conv2d(x.double(), w.double(), None, 1, 1, 1) + F.conv2d(x2.double(), w2.double(), None, s2)
     y = y + b1.double().view(1, -1, 1, 1)
     u = torch.relu(y * sc2.double().view(1, -1, 1, 1) + sh2.double().view(1, -1, 1, 1))
-    tol = 2e-5 if dtype_name == "f32" else 2e-2
+    tol = _tol(dtype_name)
     assert (raw.double() - y).abs().max() <= tol * max(1.0, y.abs().max().item())
     assert (act.double() - u).abs().max() <= tol * max(1.0, u.abs().max().item())
 
@@ -149,7 +153,7 @@ def _check_keys(info, head, uch, win):
 HEAD_TILES = [t for t in TILES if t[1] >= 128]
 
 
-@pytest.mark.parametrize("dtype_name", ["f32", "bf16"])
+@pytest.mark.parametrize("dtype_name", ["f32", "bf16", "f16"])
 @pytest.mark.parametrize("tile", HEAD_TILES, ids=["%dx%d" % t for t in HEAD_TILES])
 def test_forced_tile_head_nchw_argmax(force_tile, tile, dtype_name):
     """conv3-shaped launch (1x1 + bias + sigmoid, f32 NCHW) with the fused arg-max keys, head materialised too."""
@@ -167,8 +171,11 @@ def test_forced_tile_head_nchw_argmax(force_tile, tile, dtype_name):
     print(info["kernel"])
     assert info["kernel"] == _kname(dtype_name, bp, bc)
     ref, _ = ref_conv(x, w, b1=bias, act1=3)
-    assert float((raw - ref).abs().max()) <= (2e-6 if dtype_name == "f32" else 5e-3)
+    assert float((raw - ref).abs().max()) <= {"f32": 2e-6, "bf16": 5e-3, "f16": 8e-4}[dtype_name]
     _check_keys(info, raw, uch, win)
+    if (bp, bc) == (192, 128):                                    # the edge-aligned tile takes the same decisions
+        keys_e, kn = run_edge_argmax(x, w, bias, dtype, uch, win)
+        assert "head_limb_argmax_kernel" in kn and torch.equal(keys_e, info["keys"])
     # keys only (the benchmarked path: the head tensor is not written)
     info2 = {}
     run_conv(x, w, dtype, b1=bias, act1=3, nchw=True, argmax=(uch, win), want_raw=False, info=info2)
@@ -250,7 +257,7 @@ def test_full_size_layer_sampled(case, dtype_name):
 
     got = raw.permute(0, 2, 3, 1).reshape(M, Cout)[rows].double()
     ref = torch.relu(acc * s1.double() + b1.double())
-    tol = (F32_TOL if dtype_name == "f32" else BF16_TOL) * max(1.0, float(ref.abs().max()))
+    tol = _tol(dtype_name) * max(1.0, float(ref.abs().max()))
     assert not torch.isnan(raw).any()
     assert float((got - ref).abs().max()) <= tol
     # residual + second output on the same shape (chunked epilogue of the same instantiation)
