@@ -325,25 +325,44 @@ def extra_sections(args, dev, net, frames, dec):
                 "images_per_sec": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 3),
                 "frac_of_mfma_peak_3x_fwd_flops": round(3 * flops / dt / 1e12 / BF16_DENSE_PEAK_TFLOPS, 4)}
 
-    def bf16_agreement():
-        # the benchmarked dtype against the REFERENCE pipeline's people lists (tests/golden/e2e_d22_384.npz: 8 frames,
-        # forward + get_humans_by_feature of the reference itself); gated in tests/test_e2e_gpu.py
-        g = np.load(os.path.join(ROOT, "tests", "golden", "e2e_d22_384.npz"))
-        nb, sz = int(g["batch"]), int(g["size"])
-        if args.arch != str(g["arch"]) or S != sz or args.dtype != "bf16":
-            return {"skipped": "fixture is drn_d_22 384x384, bf16 mode"}
+    def _fixture(name):
+        g = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
+        over = {k[len("override/"):]: g[k] for k in g.files if k.startswith("override/")}
+        return g, int(g["batch"]), int(g["size"]), over
+
+    def _agreement(model_, name):
+        """`model_`'s people vs the reference pipeline's on fixture `name` (weights = seed 0 + the fixture's overrides)."""
+        g, nb, sz, over = _fixture(name)
+        if over:
+            sd_ = dict(net.state_dict()); sd_.update({k: torch.from_numpy(v) for k, v in over.items()})
+            model_.load_state_dict(sd_)
         fr = torch.from_numpy(prng.u8_frames(int(g["seed_in"]), nb, (sz, sz))).to(dev)
-        got = rt.inference_batch(fr, net).to_host()
+        got = rt.inference_batch(fr, model_).to_host()
         tot = np.zeros(5, np.int64)
         for i in range(nb):
             exp = {k: g[f"{i}/{k}"] for k in ("n", "kp_cell", "limb_arg")}
             tot += np.array(decode.people_agreement(exp, got[i]))
+        if over:
+            model_.load_state_dict(net.state_dict())
         n, exact, same, kp_eq, kp_all = (int(v) for v in tot)
-        return {"what": "bf16 fused path vs the reference pipeline's people on 8 calibrated frames (dense synthetic heads: "
-                        "~490 root candidates per frame with near-equal scores)", "reference_people": n,
-                "reproduced_exactly": exact, "same_root": same, "keypoint_cells_equal": kp_eq,
+        return {"reference_people": n, "reproduced_exactly": exact, "same_root": same, "keypoint_cells_equal": kp_eq,
                 "keypoint_cells_compared": kp_all, "same_root_frac": round(same / max(n, 1), 4),
                 "keypoint_cell_agreement": round(kp_eq / max(kp_all, 1), 4)}
+
+    def bf16_agreement():
+        # the benchmarked dtype against the REFERENCE pipeline's people lists (tests/golden/e2e_d22_384.npz: 8 frames,
+        # forward + get_humans_by_feature of the reference itself); gated in tests/test_e2e_gpu.py
+        g, nb, sz, _ = _fixture("e2e_d22_384")
+        if args.arch != str(g["arch"]) or S != sz or args.dtype != "bf16":
+            return {"skipped": "fixture is drn_d_22 384x384, bf16 mode"}
+        nb_ = model.PoseProposalNet(getattr(drn, args.arch)(), insize=(S, S), outsize=(S // 16, S // 16),
+                                    compute_dtype="bfloat16").cuda(dev)
+        nb_.load_state_dict(net.state_dict())
+        return {"what": "bf16 fused path vs the reference pipeline's people on 8 calibrated frames (dense synthetic heads: "
+                        "~490 root candidates per frame with near-equal scores)", **_agreement(nb_, "e2e_d22_384"),
+                "tuned_checkpoint": {"what": "the same frames on the reference-fine-tuned checkpoint (bn2 / conv3.bias trained "
+                                             "by the reference's PPNLoss + Adam until < 40 root candidates per frame: 76 people)",
+                                     **_agreement(nb_, "e2e_tuned_d22_384")}}
 
     def ap_vs_reference():
         # what the reduced-precision modes cost in the TASK metric: the reference pipeline's people (fixture) taken as
@@ -393,18 +412,9 @@ def extra_sections(args, dev, net, frames, dec):
         res = {"what": f"the fused path with f16 storage / MFMA operands (not BASELINE's dtype: reported beside it), batch {B}",
                "images_per_sec": round(B / dtl, 1), "ms_per_step": round(dtl * 1e3, 3), "lanes": lanes,
                "images_per_sec_one_lane": round(B / dt1, 1)}
-        g = np.load(os.path.join(ROOT, "tests", "golden", "e2e_d22_384.npz"))
-        nb, sz = int(g["batch"]), int(g["size"])
-        if args.arch == str(g["arch"]) and S == sz:
-            fr = torch.from_numpy(prng.u8_frames(int(g["seed_in"]), nb, (sz, sz))).to(dev)
-            got = rt.inference_batch(fr, n16).to_host()
-            tot = np.zeros(5, np.int64)
-            for i in range(nb):
-                tot += np.array(decode.people_agreement({k: g[f"{i}/{k}"] for k in ("n", "kp_cell", "limb_arg")}, got[i]))
-            n, exact, same, kp_eq, kp_all = (int(v) for v in tot)
-            res["f16_agreement"] = {"reference_people": n, "reproduced_exactly": exact, "same_root": same,
-                                    "same_root_frac": round(same / max(n, 1), 4),
-                                    "keypoint_cell_agreement": round(kp_eq / max(kp_all, 1), 4)}
+        if args.arch == "drn_d_22" and S == 384:
+            res["f16_agreement"] = _agreement(n16, "e2e_d22_384")
+            res["f16_agreement_tuned_checkpoint"] = _agreement(n16, "e2e_tuned_d22_384")
         return res
 
     section("bf16_agreement", bf16_agreement)

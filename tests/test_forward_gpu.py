@@ -104,8 +104,8 @@ def test_forward_bf16_d22_384(golden_dir):
 
 # f16 mode (IEEE half weights + stored activations, 11 significant bits instead of bf16's 8; f32 accumulate / epilogue /
 # head): measured on MI355X (round 3) and gated just above -- the head is ~8x closer to the fp32 reference than bf16's
-F16_MAX_TOL, F16_MEAN_TOL = 0.03, 0.003
-F16_EMU_MAX_TOL, F16_EMU_MEAN_TOL = 0.015, 0.0012
+F16_MAX_TOL, F16_MEAN_TOL = 0.02, 0.0025            # measured 0.0130 / 0.00169 (bf16: 0.101 / 0.0128)
+F16_EMU_MAX_TOL, F16_EMU_MEAN_TOL = 0.009, 0.001     # measured 0.0060 / 0.00066 vs the oracle with f16 storage emulated
 
 
 @pytest.mark.parametrize("name", ["forward_d22_96", "forward_d22_384"])
