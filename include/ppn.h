@@ -260,6 +260,11 @@ int ppn_set_conv_tile_policy(int32_t policy);
  * PPN_CONV_TILE="bp,bc" environment knob that supplies its initial value. */
 int ppn_set_conv_tile_override(int32_t bp, int32_t bc);
 
+/* Test and tuning hook: 0 routes the 64 -> 64 3x3 stride-1 convolutions of the 16-bit modes through the generic
+ * implicit-GEMM kernels instead of the register-resident filter-bank kernel (csrc/conv64.hip); results are bit-identical
+ * either way (tests/test_conv_tiles_gpu.py).  Process-wide; initial value 1 unless PPN_CONV64=0 is in the environment. */
+int ppn_set_conv64_enabled(int32_t on);
+
 /* Name of the kernel instantiation the calling thread's last successful ppn_conv2d_fused launched
  * (e.g. "conv_igemm_big_kernel<__bf16, 192, 256, 8, false>"); "" before the first call. */
 const char* ppn_last_conv_kernel(void);

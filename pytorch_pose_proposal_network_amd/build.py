@@ -22,6 +22,7 @@ SOURCES = [
     ("conv.hip", []),
     ("conv_big.hip", []),
     ("conv_head.hip", []),
+    ("conv64.hip", []),
     ("stem.hip", []),
     ("stem3x3.hip", []),
     ("stem01.hip", []),

@@ -390,6 +390,8 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ 
 namespace ppn {
 int conv_launch(const ppn_conv_desc* d, hipStream_t st, const char** kname);
 int head_limb_launch(const ppn_conv_desc* d, long long m_lo, long long m_hi, hipStream_t st, const char** kname);
+bool conv64_supported(const ppn_conv_desc* d);
+int conv64_launch(const ppn_conv_desc* d, hipStream_t st, const char** kname);
 bool stem3x3_supported(int cin, int cout, int ksize, int stride, int dilation, int pad);
 int stem3x3_launch(int dtype, const void* src, int batch, int h, int w, int cout, int stride, const float* weight,
                    const float* scale1, const float* shift1, const float* scale2, const float* shift2, void* out_raw,
@@ -479,6 +481,8 @@ int ppn::conv_launch(const ppn_conv_desc* d, hipStream_t st, const char** kname)
             return ppn::conv_launch(&part, st, nullptr);
         }
     }
+    // 64 -> 64 3x3 stride 1 in the 16-bit modes: the register-resident filter bank kernel (conv64.hip), same results
+    if (ppn::conv64_supported(d) && d->in_h == d->out_h && d->in_w == d->out_w) return ppn::conv64_launch(d, st, kname);
     const long long m = m_hi - m_lo;                                  // pixels of THIS launch: the tile is chosen for them
     TileChoice tc = choose_tile(d->cout);
     BigTile bt{0, 0};

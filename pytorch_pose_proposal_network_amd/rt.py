@@ -182,11 +182,18 @@ class MultiLaneInference:
         from . import lib as L
         self._policy = tile_policy
         L.check(L.load().ppn_set_conv_tile_policy(tile_policy), "ppn_set_conv_tile_policy")
+        # csrc/conv64.hip (64 -> 64 3x3 with the filter bank in registers) shortens layer3's launches by ~7 us each when
+        # one launch is in flight, but its workgroups own a CU's whole LDS and register file, so another lane's kernels
+        # cannot share the CU: with several lanes the generic kernel gives the higher throughput (same-box A/B: 11.04 k
+        # vs 10.96 k images/s with three lanes).  Process-wide, restored by close(); results are bit-identical either way.
+        self._conv64 = lanes <= 1
+        L.check(L.load().ppn_set_conv64_enabled(1 if self._conv64 else 0), "ppn_set_conv64_enabled")
 
     def close(self):
         from . import lib as L
         self.flush()
         L.check(L.load().ppn_set_conv_tile_policy(0), "ppn_set_conv_tile_policy")
+        L.check(L.load().ppn_set_conv64_enabled(1), "ppn_set_conv64_enabled")
 
     def submit(self, frames_u8: torch.Tensor, to_host: bool = False) -> D.DecodeResult:
         """Queue one batch on the next lane.  `frames_u8`: u8 [B,S,S,3] on the device, or in PINNED host memory -- then

@@ -488,3 +488,43 @@ def test_pixel_ranges_nchw_head_need_aligned_cuts():
     whole2, _ = run_conv(x2, w, dtype, **kw)
     parts2, _ = run_conv(x2, w, dtype, ranges=[(0, 61, (128, 128)), (61, 126 - 61, (128, 128))], **kw)
     assert torch.equal(parts2, whole2)
+
+
+@pytest.mark.parametrize("dtype_name", ["bf16", "f16"])
+@pytest.mark.parametrize("shape", [(3, 24, 32), (2, 19, 37), (1, 8, 16), (2, 96, 96)], ids=lambda s: "%dx%dx%d" % s)
+def test_conv64_filter_bank_kernel_equals_generic(dtype_name, shape):
+    """csrc/conv64.hip (64 -> 64 3x3 stride 1, filter bank in registers, persistent 8x16 tiles with a resident input
+    patch) against the generic implicit-GEMM kernel on the same launch: BIT-identical outputs (same K order, same
+    epilogue arithmetic) in the three forms layer3 uses -- single output with BN + ReLU, residual + second output,
+    second output only -- on image sizes that are and are not multiples of the tile; and close to fp64."""
+    from pytorch_pose_proposal_network_amd import lib as L
+    lib = L.load()
+    dtype = _dt(dtype_name)
+    B, H, W = shape
+    x = q(rnd(B, 64, H, W, seed=201), dtype)
+    w = q(rnd(64, 64, 3, 3, seed=202, scale=(2.0 / 576) ** 0.5), dtype)
+    res = q(rnd(B, 64, H, W, seed=203), dtype)
+    s1 = 0.5 + torch.rand(64, generator=torch.Generator().manual_seed(204))
+    b1 = rnd(64, seed=205, scale=0.3)
+    s2 = 0.5 + torch.rand(64, generator=torch.Generator().manual_seed(206))
+    b2 = rnd(64, seed=207, scale=0.3)
+    forms = [dict(s1=s1, b1=b1, act1=1), dict(residual=res, s2=s2, b2=b2, act2=1, want_act=True),
+             dict(s1=s2, b1=b2, residual=res, act2=1, want_raw=False, want_act=True), dict()]
+    for kw in forms:
+        got, names = {}, {}
+        for on in (1, 0):
+            L.check(lib.ppn_set_conv64_enabled(on), "ppn_set_conv64_enabled")
+            try:
+                info = {}
+                got[on] = run_conv(x, w, dtype, 1, 1, 1, info=info, **kw)
+                names[on] = info["kernel"]
+            finally:
+                L.check(lib.ppn_set_conv64_enabled(1), "ppn_set_conv64_enabled")
+        assert names[1].startswith("conv64_kernel<") and not names[0].startswith("conv64_kernel<"), names
+        for a_, b_ in zip(got[1], got[0]):
+            assert (a_ is None) == (b_ is None)
+            if a_ is not None:
+                assert not torch.isnan(a_).any() and torch.equal(a_, b_), (kw.keys(), float((a_ - b_).abs().max()))
+    raw, _ = run_conv(x, w, dtype, 1, 1, 1, s1=s1, b1=b1, act1=1)
+    ref, _ = ref_conv(x, w, 1, 1, 1, s1, b1, act1=1)
+    assert float((raw - ref).abs().max()) <= _tol(dtype_name) * max(1.0, float(ref.abs().max()))
