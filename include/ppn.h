@@ -63,7 +63,7 @@ typedef struct ppn_decode_cfg {
 } ppn_decode_cfg;
 
 /* Bytes of device scratch ppn_decode needs for `batch` images (limb arg-max map + the root-NMS survivor lists that
- * one workgroup per image of the arg-max launch leaves for the parse kernel). */
+ * the first workgroup per image of the arg-max launch leaves for the parse kernel). */
 size_t ppn_decode_workspace_bytes(const ppn_decode_cfg* cfg, int32_t batch);
 
 /*

@@ -42,13 +42,24 @@ struct DecodeParams {
     const int* early;                 // root NMS done inside the arg-max launch (early_root_nms) or nullptr
 };
 
-// Root candidates + NMS of an image do not depend on the limb arg-max: in the stand-alone decode one workgroup per
-// image of the arg-max launch (its first, so the extra ~9 us disappear in the launch's dynamic schedule) runs them
-// BEFORE its arg-max share and leaves the survivors for the parse kernel:  early[b][0] = number kept (or -1: more than
-// kEarlyMax candidates -- a dense random head -- the parse kernel then runs the phases itself), early[b][1..] = their
-// cells in kept order.  Same device functions, same order of operations: results are identical either way.
-constexpr int kEarlyMax = 128;
-constexpr int kEarlyStride = 1 + kEarlyMax;
+// Root candidates + NMS of an image do not depend on the limb arg-max: in the stand-alone decode the FIRST workgroup of
+// every image of the arg-max launch (edge 0, cell group 0: dispatched first, so the extra work disappears in the
+// launch's dynamic schedule) runs them BEFORE its arg-max share and leaves the survivors for the parse kernel:
+// early[b][0] = number kept, early[b][1..] = their cells in kept order.  Any number of candidates (round 3; round 2
+// bounded it to 128 and left dense heads -- ~490 candidates -- to the parse kernel, whose NMS then ran alone for ~100 us).
+// Same device functions, same order of operations: results are identical either way.
+//
+// Round 3 also built and measured the single-launch form the review asked for -- every arg-max workgroup counts itself
+// done on a per-image counter (write-through stores, vmcnt(0), barrier, one agent-scope atomic add), the LAST one
+// acquires, stages the arg-max map (u16) and a hop-acceptance bitmap in LDS and walks the tree in place, no parse launch.
+// Bit-exact, but not faster on the crowd heads: 116.5-117.3 us against 111.6-115.1 us for the two launches (same box).
+// The walk's tail still costs ~11 us after the image's last workgroup (returning atomic, agent-scope acquire, one HBM
+// round trip for the tables -- the write-through stores drop their lines from L2 --, the 17-hop LDS chain, one more
+// round trip for the boxes) and the completion protocol adds ~2 us of exit latency to each of the 1 632 workgroups,
+// which the parse kernel's 15 us + 1.5 us launch boundary do not exceed.  Removed again; what stayed from it is the
+// unbounded early NMS (dense heads: 208 -> ~120 us) and the explicitly batched loads of the arg-max loop.
+// per-image stride of the early lists: whole 128-byte lines
+__host__ __device__ inline int early_stride(int ncell) { return ((1 + ncell + 31) / 32) * 32; }                 // ints
 
 // ------------------------------------------------------------------------------------------
 // Kernel 1: dense limb arg-max.  grid = (E, batch); thread t -> (column group q, row slice r).
@@ -190,19 +201,20 @@ __device__ __forceinline__ void greedy_nms(int n, int nwords, const float4* s_bo
     __syncthreads();
 }
 
-// Phases 1-4 of the parse (candidates, rank sort, greedy NMS) for one image, bounded to kEarlyMax candidates.
-// Called by a whole workgroup with blockDim.x >= ncell; LDS: early_lds_bytes().
+// Phases 1-4 of the parse (candidates, rank sort, greedy NMS) for one image.
+// Called by a whole workgroup with blockDim.x >= ncell; LDS: early_lds_bytes(ncell).
 __device__ __forceinline__ void early_root_nms(const ppn_decode_cfg& c, const float* __restrict__ img, int ncell,
                                                char* smem, int* __restrict__ out) {
     const int t = threadIdx.x, K = c.K, W = c.W, H = c.H;
+    const int nwords = (ncell + 63) >> 6;
     size_t off = 0;
     auto carve = [&](size_t bytes) { char* ptr = smem + off; off += (bytes + 15) & ~size_t(15); return ptr; };
-    float4* s_box = reinterpret_cast<float4*>(carve(sizeof(float4) * kEarlyMax));
-    unsigned long long* s_key = reinterpret_cast<unsigned long long*>(carve(8 * kEarlyMax));
-    unsigned long long* s_mask = reinterpret_cast<unsigned long long*>(carve(8 * kEarlyMax * (kEarlyMax / 64)));
-    float* s_area = reinterpret_cast<float*>(carve(4 * kEarlyMax));
-    int* s_cell = reinterpret_cast<int*>(carve(4 * kEarlyMax));
-    int* s_sel = reinterpret_cast<int*>(carve(4 * kEarlyMax));
+    float4* s_box = reinterpret_cast<float4*>(carve(sizeof(float4) * ncell));
+    unsigned long long* s_key = reinterpret_cast<unsigned long long*>(carve(8 * ncell));
+    unsigned long long* s_mask = reinterpret_cast<unsigned long long*>(carve(8 * (size_t)ncell * nwords));
+    float* s_area = reinterpret_cast<float*>(carve(4 * ncell));
+    int* s_cell = reinterpret_cast<int*>(carve(4 * ncell));
+    int* s_sel = reinterpret_cast<int*>(carve(4 * ncell));
     int* s_misc = reinterpret_cast<int*>(carve(4 * 40));
     float d0 = 0.0f;
     bool is_c = false;
@@ -212,10 +224,6 @@ __device__ __forceinline__ void early_root_nms(const ppn_decode_cfg& c, const fl
     }
     const int pos = block_compact(is_c, s_misc, s_misc + 32);
     const int n = s_misc[32];
-    if (n > kEarlyMax) {                                              // workgroup-uniform
-        if (t == 0) out[0] = -1;
-        return;
-    }
     if (is_c) s_key[pos] = ((unsigned long long)(~__float_as_uint(d0)) << 32) | (unsigned)t;
     __syncthreads();
     if (is_c) {
@@ -235,14 +243,17 @@ __device__ __forceinline__ void early_root_nms(const ppn_decode_cfg& c, const fl
         s_cell[rank] = t;
     }
     __syncthreads();
-    greedy_nms(n, (n + 63) >> 6, s_box, s_area, s_mask, s_sel, s_misc + 33, c.nms_thr, 0);
+    greedy_nms(n, nwords, s_box, s_area, s_mask, s_sel, s_misc + 33, c.nms_thr, 0);
     const int nsel = s_misc[33];
     if (t == 0) out[0] = nsel;
     if (t < nsel) out[1 + t] = s_cell[s_sel[t]];
 }
 
-size_t early_lds_bytes() {
-    return 16 * kEarlyMax + 8 * kEarlyMax + 8 * kEarlyMax * (kEarlyMax / 64) + 3 * 4 * kEarlyMax + 4 * 40 + 7 * 16;
+size_t early_lds_bytes(int ncell) {
+    const size_t nwords = (ncell + 63) / 64;
+    auto r16 = [](size_t x) { return (x + 15) & ~size_t(15); };
+    return r16(16 * (size_t)ncell) + r16(8 * (size_t)ncell) + r16(8 * (size_t)ncell * nwords) + 3 * r16(4 * (size_t)ncell) +
+           r16(4 * 40);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -261,7 +272,7 @@ limb_argmax_kernel(const float* __restrict__ head, int* __restrict__ out_arg, in
     const int edge = blockIdx.x, b = blockIdx.y, cell0 = blockIdx.z * ncl;
     const int t = threadIdx.x;
     if (early && edge == 0 && blockIdx.z == 0) {                   // workgroup-uniform
-        early_root_nms(cfg, head + (size_t)b * C * ncell, ncell, smem, early + (size_t)b * kEarlyStride);
+        early_root_nms(cfg, head + (size_t)b * C * ncell, ncell, smem, early + (size_t)b * early_stride(ncell));
         __syncthreads();                                           // the arg-max phase reuses the LDS
     }
     const int q = t % Q, r = t / Q;
@@ -279,13 +290,24 @@ limb_argmax_kernel(const float* __restrict__ head, int* __restrict__ out_arg, in
 #pragma unroll
             for (int i = 0; i < V; ++i) { best[i] = a[i]; bidx[i] = r; }
         }
-#pragma unroll 8
-        for (int s = r + NS; s < S; s += NS) {
-            float a[V];
-            vec_to_arr<V>(*reinterpret_cast<const vec*>(base + (size_t)s * ncell + V * q), a);
+        // eight rows per trip, all eight loads issued before the first compare (a row index past the window re-reads
+        // this thread's first row and is ignored: no branch between the loads, so they stay batched whatever else
+        // the kernel contains -- with the in-launch decode tail compiled in, hipcc serialised the plain unrolled loop)
+        for (int s0 = r + NS; s0 < S; s0 += 8 * NS) {
+            float a[8][V];
 #pragma unroll
-            for (int i = 0; i < V; ++i) {
-                if (a[i] > best[i]) { best[i] = a[i]; bidx[i] = s; }   // strict: first max within a slice
+            for (int u = 0; u < 8; ++u) {
+                const int s = s0 + u * NS;
+                vec_to_arr<V>(*reinterpret_cast<const vec*>(base + (size_t)(s < S ? s : r) * ncell + V * q), a[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int s = s0 + u * NS;
+                const bool in = s < S;
+#pragma unroll
+                for (int i = 0; i < V; ++i) {
+                    if (in && a[u][i] > best[i]) { best[i] = a[u][i]; bidx[i] = s; }   // strict: first max within a slice
+                }
             }
         }
 #pragma unroll
@@ -381,7 +403,7 @@ parse_kernel(DecodeParams p, const float* __restrict__ head, const int* __restri
 
     PPN_DT(0);
     // phases 1-4 may already have run inside the arg-max launch (early_root_nms): workgroup-uniform
-    const int* early_b = p.early ? p.early + (size_t)b * kEarlyStride : nullptr;
+    const int* early_b = p.early ? p.early + (size_t)b * early_stride(ncell) : nullptr;
     const int early_n = early_b ? early_b[0] : -1;
     int nsel;
     if (early_n < 0) {
@@ -626,10 +648,13 @@ int check_cfg(const ppn_decode_cfg* c) {
 
 }  // namespace
 
+// workspace layout: arg-max map i32 [B][E][ncell] (padded to a 128-byte multiple) | early lists i32 [B][early_stride]
+static size_t ws_argmap_bytes(const ppn_decode_cfg* c, int batch) {
+    return (((size_t)batch * c->E * c->H * c->W * 4) + 127) & ~size_t(127);
+}
 extern "C" size_t ppn_decode_workspace_bytes(const ppn_decode_cfg* cfg, int32_t batch) {
     if (!cfg || batch < 0) return 0;
-    // the arg-max map + the early root-NMS lists (kEarlyStride ints per image)
-    return (size_t)batch * cfg->E * cfg->H * cfg->W * sizeof(int32_t) + (size_t)batch * kEarlyStride * sizeof(int32_t);
+    return ws_argmap_bytes(cfg, batch) + (size_t)batch * early_stride(cfg->H * cfg->W) * 4;
 }
 
 static int launch_limb_argmax(const ppn_decode_cfg* cfg, const float* head, int32_t batch, int32_t* out_arg,
@@ -655,11 +680,13 @@ static int launch_limb_argmax(const ppn_decode_cfg* cfg, const float* head, int3
     if (NS > S) NS = S;
     int threads = ((NS * Q + 63) / 64) * 64;
     if (threads > 1024) { NS = 1024 / Q; threads = ((NS * Q + 63) / 64) * 64; }
-    // the early root-NMS role needs one thread per cell and its own (small) LDS carve
+    // the early root-NMS role needs one thread per cell and its own LDS carve (62 KB at 24x24: two workgroups per CU
+    // instead of three -- measured harmless for this HBM-bound launch: 96.8-97.3 us vs 97.4-97.6 us)
     static const bool early_off = getenv("PPN_DECODE_EARLY_NMS") && atoi(getenv("PPN_DECODE_EARLY_NMS")) == 0;
-    if (early_off || threads < ncell) early = nullptr;
+    size_t lds = (size_t)NS * ncl * 8;
+    if (early_off || threads < ncell || std::max(lds, early_lds_bytes(ncell)) > 96 * 1024) early = nullptr;
+    if (early) lds = std::max(lds, early_lds_bytes(ncell));
     if (early_used) *early_used = early != nullptr;
-    const size_t lds = std::max((size_t)NS * ncl * 8, early ? early_lds_bytes() : (size_t)0);
     if (lds > 160 * 1024) return ppn::fail(PPN_E_UNSUPPORTED, "limb_argmax LDS %zu too large", lds);
     dim3 grid(cfg->E, batch, CS);
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -698,14 +725,14 @@ extern "C" int ppn_decode(const ppn_decode_cfg* cfg, const float* head, int32_t 
     if (!head || !workspace || !out_count || !out_kp_cell || !out_limb_arg || !out_bbox || !out_score)
         return ppn::fail(PPN_E_INVALID, "ppn_decode: NULL pointer");
     if (cfg->max_humans < 1) return ppn::fail(PPN_E_INVALID, "ppn_decode: max_humans < 1");
-    if (reinterpret_cast<uintptr_t>(out_bbox) % 16 != 0)
+    if (reinterpret_cast<uintptr_t>(out_bbox) % 16 != 0 || reinterpret_cast<uintptr_t>(workspace) % 4 != 0)
         return ppn::fail(PPN_E_INVALID, "ppn_decode: out_bbox must be 16-byte aligned");
     const int ncell = cfg->H * cfg->W;
     const size_t lds = parse_lds_bytes(ncell, cfg->K, cfg->E);
     if (ncell > 1024 || lds > 160 * 1024)
         return ppn::fail(PPN_E_UNSUPPORTED, "grid of %d cells needs %zu B of LDS (max 163840)", ncell, lds);
     int32_t* argmap = static_cast<int32_t*>(workspace);
-    int32_t* early = argmap + (size_t)batch * cfg->E * ncell;
+    int32_t* early = reinterpret_cast<int32_t*>(static_cast<char*>(workspace) + ws_argmap_bytes(cfg, batch));
     bool early_used = false;
     if (int rc = launch_limb_argmax(cfg, head, batch, argmap, cfg->E > 0 ? early : nullptr, stream, &early_used)) return rc;
     DecodeParams p;

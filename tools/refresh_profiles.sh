@@ -25,5 +25,10 @@ echo "[7] in-kernel clock and phase stamps of the dominant conv kernel (diagnost
 if [ -f $R/tools/bin/libppn_clock.so ]; then
   (cd $R && python3 tools/clock_conv.py && python3 tools/clock_conv.py --head) 2>&1 | grep -v amdgpu.ids > $O/conv_clock.txt
 fi
+if [ -f $R/tools/bin/libppn_clockhead.so ]; then (cd $R && python3 tools/clock_head.py) 2>&1 | grep -v amdgpu.ids > $O/head_clock.txt; fi
+if [ -f $R/tools/bin/libppn_clock64.so ]; then (cd $R && python3 tools/clock_conv64.py) 2>&1 | grep -v amdgpu.ids > $O/conv64_clock.txt; fi
+echo "[8] full (second-order) training step: kernel stats"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/train_stats_so -o train -- python3 $R/tools/bench_train.py --steps 3 --warmup 1 > $O/train_profiled_so.txt 2>&1
+python3 $R/tools/pmc_traffic_summary.py $O $O/pmc_traffic.json > $O/pmc_traffic.txt 2>&1 || true
 find $O -name "*.csv" -size +3M -delete
 echo done
