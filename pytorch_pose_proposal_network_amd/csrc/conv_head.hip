@@ -51,7 +51,8 @@ struct HeadArgs {
     const float* shift;              // [E * 448] conv bias in the same padded layout, or NULL
     unsigned long long* keys;        // u64 [B][E][HoWo]
     int M, m_base, HoWo, Cin, Ktot, window, n_edges, n_tiles;
-    FastDiv div_howo, div_ne;
+    int pq, pr;                      // pixel tiles per XCD slot: n_ptiles = 8 * pq + pr (slots 0 .. pr-1 take pq + 1)
+    FastDiv div_howo, div_pq, div_pq1;   // by HoWo, by max(pq, 1), by pq + 1
     unsigned long long* dbg;         // -DPPN_CLOCK builds only (tools/clock_head.py): per-workgroup cycle stamps
 };
 
@@ -82,10 +83,20 @@ __global__ void __launch_bounds__(64 * NW, 2) head_limb_argmax_kernel(HeadArgs a
     const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(a.shift ? a.shift : (const float*)a.wgt), 0, a.shift ? (unsigned)(a.n_edges * BC * 4) : 0u, 0x00020000);
 
-    // iteration `it` of this workgroup: the G tiles of a round are dealt so that the workgroups of one XCD (equal
-    // blockIdx % 8) hold G/8 CONSECUTIVE tiles -- speed only, nothing depends on the placement
+    // Tile order.  Workgroups with equal blockIdx % 8 share an XCD (round-robin dealing: speed only, nothing depends on
+    // it) and therefore an L2.  Each such group owns a contiguous EIGHTH of the pixel tiles for ALL edges and walks it
+    // edge-major: its activation rows (18 tiles x 128 KB at batch 32) stay in that L2 for the whole launch and every
+    // edge's 458 KB of weights is fetched once per XCD.  (Dealing consecutive tiles -- one pixel tile, all 17 edges --
+    // to an XCD per round made every XCD stream all 7.8 MB of weights every round: 635 MB of fabric reads per launch
+    // by the FETCH_SIZE counter against 27 MB of operands.)
     const int G = gridDim.x;
-    auto tile_of = [&](int it) { return it * G + (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3); };
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per = G >> 3;
+    const int psize = a.pq + (xcd < a.pr ? 1 : 0);                    // pixel tiles of this XCD slot
+    const int pstart = xcd * a.pq + min(xcd, a.pr);
+    const int ntl = psize * a.n_edges;                               // tiles of this XCD slot
+    const FastDiv div_ps = xcd < a.pr ? a.div_pq1 : a.div_pq;
+    auto tile_of = [&](int it) { return it * per + slot; };          // LOCAL tile index: edge = li / psize
+    auto edge_of = [&](int li) { return fast_div(li, div_ps); };
 
     const int lrow = lane >> 3;
     const int chunk = (lane & 7) ^ (((lane >> 4) & 3) | ((wave & 1) << 2));
@@ -97,7 +108,7 @@ __global__ void __launch_bounds__(64 * NW, 2) head_limb_argmax_kernel(HeadArgs a
     int ld_step = 0;
     bool live = true;
     auto setup_tile = [&](int tile) {
-        const int pt = fast_div(tile, a.div_ne), e = tile - pt * a.n_edges;
+        const int e = edge_of(tile), pt = pstart + tile - e * psize;
         const int m0 = a.m_base + pt * BP;
 #pragma unroll
         for (int j = 0; j < NXI; ++j) {
@@ -164,13 +175,13 @@ __global__ void __launch_bounds__(64 * NW, 2) head_limb_argmax_kernel(HeadArgs a
     // 512 floats (the 448 of the edge + 64 of the next edge / zeros past the end) by two wave-instructions of 1 KiB
     auto issue_shift = [&](int tile_, int par) {
         if (wave < 2) {
-            const int pt_ = fast_div(tile_, a.div_ne), e_ = tile_ - pt_ * a.n_edges;
+            const int e_ = edge_of(tile_);
             bufload_lds16(srs, shifts + par * 2048 + wave * 1024, (unsigned)((e_ * BC + wave * 256 + lane * 4) * 4), 0);
         }
     };
 
     int tile = tile_of(0);
-    if (tile >= a.n_tiles) return;                                   // (workgroup-uniform)
+    if (tile >= ntl) return;                                         // (workgroup-uniform)
     setup_tile(tile);
     issue_shift(tile, 0);
     static_for<NL>([&](auto gc) { issue_one(gc, 0); });
@@ -197,8 +208,8 @@ __global__ void __launch_bounds__(64 * NW, 2) head_limb_argmax_kernel(HeadArgs a
         // ---- stage 0 of this tile is in buffer 0 (requested during the previous tile's LAST K step, waited for and
         // fenced by that step's barrier; first tile: above); stage 1 is in flight -----------------------------------------
         const int next = tile_of(it + 1);
-        const bool more = next < a.n_tiles;                           // workgroup-uniform
-        const int pt_e = fast_div(tile, a.div_ne), edge = tile - pt_e * a.n_edges;
+        const bool more = next < ntl;                                 // workgroup-uniform
+        const int edge = edge_of(tile), pt_e = pstart + tile - edge * psize;
         const int m0 = a.m_base + pt_e * BP;
         HEAD_T(t1_);
         static_for<NRD>([&](auto rc) { read_one(rc, wA, xA, 0, 0); });
@@ -430,7 +441,7 @@ int launch_T(const HeadArgs& a, int batch, hipStream_t st, const char** kname) {
     }
     // one persistent workgroup per CU (144 KB of LDS each), a multiple of 8 so that the XCD slots of a round are equal
     int grid = (n_cu / 8) * 8;
-    const int need = ((a.n_tiles + 7) / 8) * 8;
+    const int need = 8 * (a.pq + (a.pr ? 1 : 0)) * a.n_edges;       // 8 x the tiles of the largest XCD slot
     if (grid > need) grid = need;
     const size_t src_bytes = (size_t)a.M * a.Cin * sizeof(T);
     const size_t wgt_bytes = (size_t)a.n_edges * BC * a.Ktot * sizeof(T);
@@ -465,8 +476,10 @@ int head_limb_launch(const ppn_conv_desc* d, long long m_lo, long long m_hi, hip
     a.n_edges = d->cout / d->limb_window;
     const int n_ptiles = (int)((m_hi - m_lo + BP - 1) / BP);
     a.n_tiles = n_ptiles * a.n_edges;
+    a.pq = n_ptiles / 8; a.pr = n_ptiles % 8;
     a.div_howo = make_fastdiv((unsigned)a.HoWo);
-    a.div_ne = make_fastdiv((unsigned)a.n_edges);
+    a.div_pq = make_fastdiv((unsigned)(a.pq > 0 ? a.pq : 1));
+    a.div_pq1 = make_fastdiv((unsigned)(a.pq + 1));
 #ifdef PPN_CLOCK
     a.dbg = (unsigned long long*)d->shift2;      // diagnostic channel of the stamped build
 #else
