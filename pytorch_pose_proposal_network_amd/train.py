@@ -207,7 +207,7 @@ class GradNormWeights:
         world = 1
         if dist.is_available() and dist.is_initialized():
             world = dist.get_world_size(group)
-            if world > 1:
+            if world > 1 or _force_dp():
                 dist.all_reduce(self.w, op=dist.ReduceOp.SUM, group=group)      # main.py:769-771
         self.renorm(world)
         return self.log
@@ -365,6 +365,11 @@ def _wgrad_ws(nbytes: int, device) -> torch.Tensor:
     return ws
 
 
+def _force_dp() -> bool:
+    import os
+    return os.environ.get("PPN_FORCE_DP", "0") == "1"
+
+
 class BucketedAllReduce:
     """SUM all-reduce of one flat gradient buffer in a few large buckets, each issued (async) as soon as the
     backward pass has produced every gradient in it, so the exchange runs underneath the rest of the backward.
@@ -379,7 +384,9 @@ class BucketedAllReduce:
     def __init__(self, flat: torch.Tensor, bucket_elems: int = 8 * 1024 * 1024, group=None):
         import torch.distributed as dist
         self.flat, self.group = flat, group
-        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        # PPN_FORCE_DP=1: run the exchange even in a one-rank group (a SUM over one rank is the identity) -- how the
+        # RCCL code path (async bucketed all-reduce against side-stream weight gradients) is exercised on a 1-GPU box
+        self.enabled = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or _force_dp())
         self.world = dist.get_world_size(group) if self.enabled else 1
         n = flat.numel()
         self.bounds = list(range(n, 0, -bucket_elems)) + [0]          # n = b0 > b1 > ... > 0

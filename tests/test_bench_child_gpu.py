@@ -54,3 +54,34 @@ def test_a_failing_rank_fails_the_run_without_hanging(workload):
     assert p.returncode != 0
     assert not [l for l in p.stdout.splitlines() if l.lstrip().startswith("{")], p.stdout
     assert "PPN_BENCH_FAIL_RANK" in p.stderr
+
+
+@pytest.mark.parametrize("workload", ["inference", "train"])
+def test_rccl_branch_runs_with_one_rank(workload):
+    """The `nccl` (= RCCL) calls of the N > 1 path -- init_process_group(device_id=...), barrier, the MAX all-reduce of the
+    timing, and in training the bucketed asynchronous gradient all-reduce against side-stream weight gradients plus the
+    task-weight all-reduce -- executed for real on the one GPU of the box: bench.py under torch.distributed.run with ONE
+    process, PPN_BENCH_FORCE_DIST=1 (join the group although world = 1) and PPN_FORCE_DP=1 (run the exchange although a
+    SUM over one rank is the identity).  Two ranks cannot share a GPU under RCCL, so this is as far as one GPU goes."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, PPN_BENCH_FORCE_DIST="1", PPN_FORCE_DP="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("PPN_BENCH_BACKEND", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+           "--windows", "2", "--no-extras", "--no-cpu-baseline", "--workload", workload]
+    if workload == "train":
+        cmd += ["--batch", "8"]
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=420, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.lstrip().startswith("{")]
+    assert len(lines) == 1, p.stdout
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 1 and r["rccl_ranks"] == 1 and r["value"] > 0
+    if workload == "train":
+        assert len(r["losses"]) == 5 and all(v == v for v in r["losses"])
+        assert abs(sum(r["task_weights"]) - 5.0) < 1e-2
+    else:
+        assert r["batch_consistency"]["ok"]

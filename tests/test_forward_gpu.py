@@ -244,7 +244,7 @@ def test_non_square_inputs(golden_dir, hw):
     ref = Fr.forward_ref({k: np.asarray(v) for k, v in sd.items()}, torch.from_numpy(x), "drn_d_22").numpy()
     assert ref.shape[2:] == (H // 16, W // 16)
     heads = {}
-    for dtype in ("float32", "bfloat16"):
+    for dtype in ("float32", "bfloat16", "float16"):
         m = model.PoseProposalNet(drn.drn_d_22(), insize=(W, H), outsize=(W // 16, H // 16), compute_dtype=dtype).cuda()
         m.load_state_dict(sd)
         m.eval()
@@ -259,6 +259,11 @@ def test_non_square_inputs(golden_dir, hw):
             for k in ("kp_cell", "limb_arg", "bbox", "score"):
                 assert np.array_equal(ra[k], rb[k]), (dtype, k)
     from oracle import fused_ref
+    emu16 = fused_ref.fused_forward_ref(sd, Fr.normalize_u8(u8), "drn_d_22", emulate_dtype=torch.float16, fuse_stem="all").numpy()
+    d16, de16 = np.abs(heads["float16"] - ref), np.abs(heads["float16"] - emu16)
+    print(f"{H}x{W}: f16 vs f32 oracle max {d16.max():.4f} mean {d16.mean():.5f}, vs emulated-f16 oracle max {de16.max():.4f} "
+          f"mean {de16.mean():.5f}")
+    assert d16.mean() <= 0.004 and de16.max() <= 0.02 and de16.mean() <= 0.0015
     emu = fused_ref.fused_forward_ref(sd, Fr.normalize_u8(u8), "drn_d_22", emulate_bf16=True, fuse_stem="all").numpy()
     err = np.abs(heads["float32"] - ref).max()
     d, de = np.abs(heads["bfloat16"] - ref), np.abs(heads["bfloat16"] - emu)

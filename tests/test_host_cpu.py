@@ -194,3 +194,35 @@ def test_two_rank_gloo_bucketed_exchange(tmp_path):
     a, b, c, ncalls, scale, total = int(line[1]), int(line[2]), int(line[3]), int(line[4]), float(line[5]), float(line[6])
     assert (a, b, c, ncalls) == (0, 1, 2, 1)
     assert scale == 0.5 and total == 3 * sum(range(1000))
+
+
+def test_ap_against_people_on_the_reference_fixture():
+    """evaluate.ap_against_people (the task-metric account of the 16-bit modes, bench.py::ap_vs_reference): a people list
+    scored against itself gives the metric's ceiling on that list (the same number whatever the order of the people);
+    removing people lowers every AP; on a fixture without overlapping people the ceiling is 100."""
+    import os
+    import numpy as np
+    from pytorch_pose_proposal_network_amd import evaluate as E
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "e2e_tuned_d22_384.npz"))
+    nb = int(g["batch"])
+    exp = [{k: g[f"{i}/{k}"] for k in ("n", "kp_cell", "limb_arg", "bbox", "score")} for i in range(nb)]
+    ceil_ = np.array(E.ap_against_people(exp, exp))
+    assert np.all(ceil_ > 85.0) and np.all(ceil_ <= 100.0)
+    rev = [dict(n=e["n"], kp_cell=e["kp_cell"][::-1], limb_arg=e["limb_arg"][::-1], bbox=e["bbox"][::-1],
+                score=e["score"][::-1]) for e in exp]
+    assert np.allclose(E.ap_against_people(exp, rev), ceil_, atol=3.0)          # (ties in the matcher depend on order)
+    thin = []
+    for e in exp:
+        keep = [i for i in range(int(e["n"])) if i % 2 == 0]
+        thin.append(dict(n=len(keep), kp_cell=e["kp_cell"][keep], limb_arg=e["limb_arg"][keep], bbox=e["bbox"][keep],
+                         score=e["score"][keep]))
+    less = np.array(E.ap_against_people(exp, thin))
+    assert np.all(less < ceil_ - 15.0)
+    # two well separated single-keypoint-complete people: identical lists score 100
+    one = dict(n=2, kp_cell=np.zeros((2, 18), np.int32), limb_arg=np.zeros((2, 17), np.int32),
+               bbox=np.zeros((2, 18, 4), np.float32), score=np.full((2, 18), 0.9, np.float32))
+    for p, (cy, cx) in enumerate(((60.0, 60.0), (300.0, 300.0))):
+        for k in range(18):
+            one["bbox"][p, k] = [cy + k - 10, cx + 2 * k - 10, cy + k + 10, cx + 2 * k + 10]
+        one["bbox"][p, 0] = [cy - 40, cx - 40, cy + 40, cx + 40]
+    assert np.allclose(E.ap_against_people([one], [one]), 100.0)
