@@ -202,3 +202,34 @@ def test_conv_dgrad(dtype, case):
     tol = 2e-2 if dtype == torch.bfloat16 else 3e-5
     assert dx.shape == ref.shape
     assert (dx.cpu().double() - ref).abs().max() <= tol * max(1.0, ref.abs().max().item())
+
+
+FULL_WGRAD = [
+    # (B, Cin, Cout, H, k, stride, dil, pad): D-22 layer shapes at 384x384, batch 32 -- the 8-wave ping-pong kernel
+    (32, 512, 512, 48, 3, 1, 4, 4),
+    (32, 256, 512, 48, 1, 1, 1, 0),
+    (32, 512, 512, 24, 3, 1, 1, 1),
+    (8, 512, 1312, 24, 1, 1, 1, 0),
+    (3, 264, 320, 37, 3, 1, 2, 2),       # ragged everything: channel tiles, 4107 pixels (not a multiple of 32), odd width
+]
+
+
+@pytest.mark.parametrize("case", FULL_WGRAD)
+def test_conv_wgrad_fullsize_bf16_against_f32_kernel(case):
+    """Full-size weight gradients: the bf16 kernel (ping-pong loop, LDS-DMA ring, transposed reads) against the exact-f32
+    kernel (a different loop) on the same bf16-rounded operands -- the products are exact in f32, so only the
+    accumulation order differs -- and against itself run twice (bitwise: no atomics, no races)."""
+    from pytorch_pose_proposal_network_amd import train as T
+    B, ci, co, H, k, s, dil, pad = case
+    dev = torch.device("cuda")
+    g = torch.Generator(device="cpu").manual_seed(9)
+    Ho = (H + 2 * pad - (dil * (k - 1) + 1)) // s + 1
+    x = torch.randn(B, H, H, ci, generator=g).to(torch.bfloat16).to(dev)
+    dy = torch.randn(B, Ho, Ho, co, generator=g).to(torch.bfloat16).to(dev)
+    a = T.conv_wgrad(x, dy, k, s, dil, pad).clone()
+    b = T.conv_wgrad(x, dy, k, s, dil, pad).clone()
+    r = T.conv_wgrad(x.float(), dy.float(), k, s, dil, pad)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    tol = 3e-5 * (B * Ho * Ho) ** 0.5
+    assert float((a - r).abs().max()) <= tol, (float((a - r).abs().max()), tol)

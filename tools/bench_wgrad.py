@@ -21,6 +21,8 @@ CASES = [  # name, B, cin, cout, H (input), k, stride, dil, pad
     ("1x1 256->512 @48", 32, 256, 512, 48, 1, 1, 1, 0),
 ]
 dev = torch.device("cuda")
+if len(sys.argv) > 1:
+    CASES = [c for c in CASES if sys.argv[1] in c[0]]
 for name, B, ci, co, H, k, s, d, p in CASES:
     Ho = (H + 2 * p - (d * (k - 1) + 1)) // s + 1
     x = torch.randn(B, H, H, ci, device=dev).to(torch.bfloat16)
