@@ -124,6 +124,17 @@ int ppn_loss_fwd_bwd(const ppn_loss_cfg* cfg, const float* head, int32_t batch, 
                      const float* coeff, float* losses, float* grad_head, void* workspace, void* stream);
 
 /*
+ * ppn_loss_fwd_bwd with the five coefficients read on the DEVICE when the kernels run: c_i = coeff_dev[i] / coeff_div
+ * (main.py:668 `loss = sum_i w_i l_i / 5` with the task weights optimizerR.step() left on the device, main.py:761-777).
+ * The host passes no value, so it can enqueue an iteration before the previous one has finished.
+ */
+int ppn_loss_fwd_bwd_dev(const ppn_loss_cfg* cfg, const float* head, int32_t batch, const float* delta,
+                         const float* weight, const float* weight_ij, const float* tx_half, const float* ty_half,
+                         const float* tx, const float* ty, const float* tw, const float* th, const float* te,
+                         const float* coeff_dev, float coeff_div, float* losses, float* grad_head, void* workspace,
+                         void* stream);
+
+/*
  * Training-target encoder (dataset.py:96-185) on the device: person lists -> the ten target tensors of
  * ppn_loss_fwd_bwd, bit-exact with the host encoder.  Replaces the per-sample host encoding + 2 x 17.3 MB/sample
  * H2D of main.py:649-661.

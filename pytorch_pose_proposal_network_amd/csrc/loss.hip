@@ -25,9 +25,16 @@ struct LossArgs {
     float* partial;       // workspace: [nblk_unary][4] then [nblk_limb]
     float* losses;        // [5]
     float coeff[5];
+    const float* coeff_dev;   // ppn_loss_fwd_bwd_dev: c_i = coeff_dev[i] / coeff_div, read on the device
+    float coeff_div;
     int B, K, E, S, H, W, C, inW, inH;
     int nblk_unary, nblk_limb;
 };
+
+// coefficient i: by value (host call) or from device memory (a uniform scalar load)
+__device__ __forceinline__ float coef(const LossArgs& a, int i) {
+    return a.coeff_dev ? a.coeff_dev[i] / a.coeff_div : a.coeff[i];
+}
 
 __device__ __forceinline__ float block_sum(float v, float* s_red) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -86,7 +93,7 @@ __global__ void __launch_bounds__(256) unary_kernel(LossArgs a) {
         l_coor = wt * (dx * dx + dy * dy);
         l_size = wt * (dsw * dsw + dsh * dsh);
         if (a.grad) {
-            const float c0 = a.coeff[0] * invB, c1c = a.coeff[1] * invB, c2c = a.coeff[2] * invB, c3c = a.coeff[3] * invB;
+            const float c0 = coef(a, 0) * invB, c1c = coef(a, 1) * invB, c2c = coef(a, 2) * invB, c3c = coef(a, 3) * invB;
             const float g_iou = -2.f * dl * dc * c1c;                        // dL/d(iou)
             const float gI = g_iou * (U + I) / (U * U), gA0 = -g_iou * I / (U * U);
             const float g_wr = wr > 0.f ? gI * hI : 0.f, g_hr = hr > 0.f ? gI * wI : 0.f;
@@ -241,7 +248,7 @@ __global__ void __launch_bounds__(256) limb_kernel(LossArgs a) {
     const size_t per_img = (size_t)a.E * a.S * HW;                      // limb elements per image
     const size_t head_img = (size_t)a.C * HW, head_off = (size_t)6 * a.K * HW;
     const size_t nvec = per_img / V;                                   // V | per_img is checked on the host
-    const float g = 2.f * a.coeff[4] / (float)a.B;
+    const float g = 2.f * coef(a, 4) / (float)a.B;
     float acc = 0.f;
     const size_t total = (size_t)a.B * nvec;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -318,16 +325,18 @@ extern "C" size_t ppn_loss_workspace_bytes(const ppn_loss_cfg* cfg, int32_t batc
     return ((size_t)a.nblk_unary * 4 + a.nblk_limb) * sizeof(float);
 }
 
-extern "C" int ppn_loss_fwd_bwd(const ppn_loss_cfg* cfg, const float* head, int32_t batch, const float* delta,
-                                const float* weight, const float* weight_ij, const float* tx_half, const float* ty_half,
-                                const float* tx, const float* ty, const float* tw, const float* th, const float* te,
-                                const float* coeff, float* losses, float* grad_head, void* workspace, void* stream) {
+static int loss_fwd_bwd(const ppn_loss_cfg* cfg, const float* head, int32_t batch, const float* delta,
+                        const float* weight, const float* weight_ij, const float* tx_half, const float* ty_half,
+                        const float* tx, const float* ty, const float* tw, const float* th, const float* te,
+                        const float* coeff, const float* coeff_dev, float coeff_div, float* losses, float* grad_head,
+                        void* workspace, void* stream) {
     LossArgs a;
     if (int rc = fill(a, cfg, batch)) return rc;
+    a.coeff_dev = coeff_dev; a.coeff_div = coeff_div;
     if (!head || !delta || !weight || !weight_ij || !tx_half || !ty_half || !tx || !ty || !tw || !th || !te || !losses ||
         !workspace)
         return ppn::fail(PPN_E_INVALID, "ppn_loss_fwd_bwd: NULL pointer");
-    if (grad_head && !coeff) return ppn::fail(PPN_E_INVALID, "ppn_loss_fwd_bwd: coeff is required with grad_head");
+    if (grad_head && !coeff && !coeff_dev) return ppn::fail(PPN_E_INVALID, "ppn_loss_fwd_bwd: coeff is required with grad_head");
     a.head = head; a.delta = delta; a.weight = weight; a.weight_ij = weight_ij; a.tx_half = tx_half; a.ty_half = ty_half;
     a.tx = tx; a.ty = ty; a.tw = tw; a.th = th; a.te = te;
     a.grad = grad_head; a.partial = static_cast<float*>(workspace); a.losses = losses;
@@ -352,6 +361,27 @@ extern "C" int ppn_loss_fwd_bwd(const ppn_loss_cfg* cfg, const float* head, int3
     return PPN_OK;
 }
 
+extern "C" int ppn_loss_fwd_bwd(const ppn_loss_cfg* cfg, const float* head, int32_t batch, const float* delta,
+                                const float* weight, const float* weight_ij, const float* tx_half, const float* ty_half,
+                                const float* tx, const float* ty, const float* tw, const float* th, const float* te,
+                                const float* coeff, float* losses, float* grad_head, void* workspace, void* stream) {
+    return loss_fwd_bwd(cfg, head, batch, delta, weight, weight_ij, tx_half, ty_half, tx, ty, tw, th, te, coeff, nullptr,
+                        1.f, losses, grad_head, workspace, stream);
+}
+
+// The same with the coefficients read ON THE DEVICE at kernel time: c_i = coeff_dev[i] / coeff_div (the task weights
+// of the previous iteration's optimizerR.step(), main.py:668 `loss = sum(w_i * l_i) / 5`): the host needs no value, so
+// it can enqueue the next iteration without waiting for the previous one.
+extern "C" int ppn_loss_fwd_bwd_dev(const ppn_loss_cfg* cfg, const float* head, int32_t batch, const float* delta,
+                                    const float* weight, const float* weight_ij, const float* tx_half,
+                                    const float* ty_half, const float* tx, const float* ty, const float* tw,
+                                    const float* th, const float* te, const float* coeff_dev, float coeff_div,
+                                    float* losses, float* grad_head, void* workspace, void* stream) {
+    if (!coeff_dev || !(coeff_div != 0.f)) return ppn::fail(PPN_E_INVALID, "ppn_loss_fwd_bwd_dev: coeff_dev / coeff_div");
+    return loss_fwd_bwd(cfg, head, batch, delta, weight, weight_ij, tx_half, ty_half, tx, ty, tw, th, te, nullptr,
+                        coeff_dev, coeff_div, losses, grad_head, workspace, stream);
+}
+
 // Gradient of the four unary losses only (resp, iou, coor, size): d(sum_i coeff_i L_i)/d(head[:, 0:6K]) written
 // into grad_head (head layout; the limb channels are NOT touched).  This is what a GradNorm probe pass needs for
 // losses 0..3 (main.py:704-707) -- their gradients live in the first 6K of 7605 channels.
@@ -369,6 +399,7 @@ extern "C" int ppn_loss_unary_bwd(const ppn_loss_cfg* cfg, const float* head, in
     a.grad = grad_head; a.partial = static_cast<float*>(workspace); a.losses = nullptr;
     for (int i = 0; i < 4; ++i) a.coeff[i] = coeff4[i];
     a.coeff[4] = 0.f;
+    a.coeff_dev = nullptr; a.coeff_div = 1.f;
     hipLaunchKernelGGL(unary_kernel, dim3(a.nblk_unary), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     PPN_LAUNCH_CHECK();
     return PPN_OK;
@@ -394,6 +425,7 @@ extern "C" int ppn_loss_dual(const ppn_loss_cfg* cfg, const float* head, const f
     a.head = head; a.delta = delta; a.weight = weight; a.weight_ij = weight_ij; a.tx_half = tx_half; a.ty_half = ty_half;
     a.tx = tx; a.ty = ty; a.tw = tw; a.th = th; a.te = te; a.grad = nullptr; a.partial = nullptr; a.losses = nullptr;
     for (int i = 0; i < 5; ++i) a.coeff[i] = coeff[i];
+    a.coeff_dev = nullptr; a.coeff_div = 1.f;
     p.tz = tz; p.zbar = zbar; p.tzbar = tzbar;
     p.Cd = unary_only ? 6 * a.K : a.C;
     hipStream_t st = static_cast<hipStream_t>(stream);

@@ -33,6 +33,7 @@ using namespace ppnconv;
 
 constexpr unsigned kOOB = 0x80000000u;
 constexpr int kWgTableEntries = 8192;   // ping-pong kernel: x row offsets of (steps per split + 3) * 32 pixels, 32 KB of LDS
+constexpr int kWgTableSmall = 4096;     // 4-wave bf16 kernel: (steps per split + 1) * 64 pixels, 16 KB (two workgroups per CU)
 
 struct WgArgs {
     const char* x;
@@ -220,6 +221,19 @@ __global__ void __launch_bounds__(64 * WM * WN) wgrad_kernel(WgArgs a) {
 #else
 #define WG_T(v) do { } while (0)
 #endif
+    // bf16: tbl[e] = byte offset of the x row that pixel step0*BKP + e reads through this tile's tap, or out of range
+    // (entries past the split's last step are out of range: the ring's run-ahead requests are dead there)
+    auto build_table = [&](unsigned* tbl, int n_tbl) {
+        for (int e = tid; e < n_tbl; e += NTHR) {
+            const int pp = step0 * BKP + e;
+            int rem, rx;
+            const int b = fdiv(pp, a.HoWo, a.inv_howo, &rem);
+            const int oy = fdiv(rem, a.Wo, a.inv_wo, &rx);
+            const int iy = oy * a.stride + oy_off, ix = rx * a.stride + ox_off;
+            const bool ok = (e < nsteps * BKP) & (pp < a.P) & ((unsigned)iy < (unsigned)a.H) & ((unsigned)ix < (unsigned)a.W);
+            tbl[e] = ok ? (unsigned)((b * a.H + iy) * a.W + ix) * (unsigned)(a.Cin * ES) : kOOB;
+        }
+    };
     if constexpr (PP) {
         // ---- ping-pong loop -----------------------------------------------------------------------------------------
         // Every wave runs  R(s): 24 transposed reads of stage s  |barrier|  M(s): 32 MFMAs  |barrier|  and group 1 is
@@ -251,16 +265,7 @@ __global__ void __launch_bounds__(64 * WM * WN) wgrad_kernel(WgArgs a) {
             __builtin_amdgcn_sched_barrier(0);
         };
         unsigned* tbl = reinterpret_cast<unsigned*>(smem + 4 * STAGE);
-        const int n_tbl = (nsteps + 3) * BKP;                           // geometry(): <= kWgTableEntries
-        for (int e = tid; e < n_tbl; e += NTHR) {
-            const int pp = step0 * BKP + e;
-            int rem, rx;
-            const int b = fdiv(pp, a.HoWo, a.inv_howo, &rem);
-            const int oy = fdiv(rem, a.Wo, a.inv_wo, &rx);
-            const int iy = oy * a.stride + oy_off, ix = rx * a.stride + ox_off;
-            const bool ok = (e < nsteps * BKP) & (pp < a.P) & ((unsigned)iy < (unsigned)a.H) & ((unsigned)ix < (unsigned)a.W);
-            tbl[e] = ok ? (unsigned)((b * a.H + iy) * a.W + ix) * (unsigned)(a.Cin * ES) : kOOB;
-        }
+        build_table(tbl, (nsteps + 3) * BKP);                           // geometry(): <= kWgTableEntries
 #pragma unroll
         for (int st = 0; st < 3; ++st)
 #pragma unroll
@@ -333,6 +338,20 @@ __global__ void __launch_bounds__(64 * WM * WN) wgrad_kernel(WgArgs a) {
         if (!grp) phase_barrier();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
+    // 4-wave bf16 kernel: the same cheap DMA offsets (dy linear, x from the table) -- recomputed per lane they were ~230 VALU
+    // instructions per wave and step, more SIMD time than the step's 32 MFMAs
+    constexpr int TBL_OFS = 2 * (TILEA + TILEB);
+    static_assert(!BF || (NPA == 4 && NPB == 4 && RSTEPA == 16 && RSTEPB == 16), "piece rows of the 4-wave bf16 kernel");
+    unsigned va0 = 0, tba = 0, b_ch = 0, b_oob = 0;
+    const unsigned a_rstep = (unsigned)RSTEPA * (unsigned)(a.Cout * ES);
+    if (BF) {
+        build_table(reinterpret_cast<unsigned*>(smem + TBL_OFS), (nsteps + 1) * BKP);   // geometry(): <= kWgTableSmall
+        const unsigned a_oob = a_choff == kOOB ? kOOB : 0u;
+        va0 = ((unsigned)((step0 + 1) * BKP + arow0) * (unsigned)(a.Cout * ES) + (a_choff == kOOB ? 0u : a_choff)) | a_oob;
+        tba = lds0 + TBL_OFS + (BKP + brow0) * 4;
+        b_ch = b_choff == kOOB ? 0u : b_choff;
+        b_oob = b_choff == kOOB ? kOOB : 0u;
+    }
     if (nsteps > 0) issue(0, 0);
     for (int s = 0; s < nsteps; ++s) {
         WG_T(t0_);
@@ -341,10 +360,9 @@ __global__ void __launch_bounds__(64 * WM * WN) wgrad_kernel(WgArgs a) {
         __syncthreads();
         WG_T(t2_);
         // bf16: the next stage's DMA instructions are issued BETWEEN the MFMAs of the first 32-pixel substep (one per
-        // PER MFMAs).  Issued in one burst they hold every wave of the workgroup for ~2 500 cycles per step -- as long as
-        // the MFMAs themselves (tools/clock_wgrad.py) -- because the burst is bounded by the CU's LDS-DMA throughput
-        // and nothing else runs meanwhile; spread out, the matrix pipe covers it.  The second substep leaves the
-        // loads a substep's worth of time to land before the vmcnt(0) of the next step.
+        // PER MFMAs); the second substep leaves the loads a substep's worth of time to land before the vmcnt(0) of
+        // the next step.  (On the last step the pieces are dead: table entries out of range, dy rows of the next split
+        // into the stage nobody reads.)
         const bool more = s + 1 < nsteps;
         if (!BF && more) issue(s + 1, (s + 1) & 1);
         WG_T(t3_);
@@ -369,18 +387,18 @@ __global__ void __launch_bounds__(64 * WM * WN) wgrad_kernel(WgArgs a) {
                     const s16x4 b1 = lds_read_tr16<(sub * 32 + 4) * ROWB>(lb ^ (t << 5 | 16));
                     bfr[t] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
                 });
+                unsigned tx[4] = {0, 0, 0, 0};                       // x row offsets of the lane's four pixels, stage s+1
+                if constexpr (sub == 0) {
+                    asm volatile("ds_read_b32 %0, %1" : "=v"(tx[0]) : "v"(tba));
+                    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(tx[1]) : "v"(tba), "n"(RSTEPB * 4));
+                    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(tx[2]) : "v"(tba), "n"(2 * RSTEPB * 4));
+                    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(tx[3]) : "v"(tba), "n"(3 * RSTEPB * 4));
+                }
                 // every fragment is an operand of the wait, so no MFMA can be scheduled in front of it
-                if constexpr (TM == 4 && TN == 8)
-                    asm volatile("s_waitcnt lgkmcnt(0)"
-                                 : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]), "+v"(bfr[0]), "+v"(bfr[1]),
-                                   "+v"(bfr[2]), "+v"(bfr[3]), "+v"(bfr[4]), "+v"(bfr[5]), "+v"(bfr[6]), "+v"(bfr[7]));
-                else
-                    asm volatile("s_waitcnt lgkmcnt(0)"
-                                 : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]), "+v"(bfr[0]), "+v"(bfr[1]),
-                                   "+v"(bfr[2]), "+v"(bfr[3]));
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]), "+v"(bfr[0]), "+v"(bfr[1]),
+                               "+v"(bfr[2]), "+v"(bfr[3]), "+v"(tx[0]), "+v"(tx[1]), "+v"(tx[2]), "+v"(tx[3]));
                 if (sub == 0) {
-                    // (on the last step the pieces are issued dead -- out-of-range offsets, zero fill into the stage
-                    // nobody reads -- so that the step has ONE instruction schedule)
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
@@ -388,11 +406,14 @@ __global__ void __launch_bounds__(64 * WM * WN) wgrad_kernel(WgArgs a) {
                         for (int j = 0; j < TN; ++j) {
                             const int n = i * TN + j;
                             if (n % PER == 0 && n / PER < NPT) {
-                                issue_piece(s + 1, (s + 1) & 1, n / PER, more);
+                                const int pc = n / PER;
+                                piece_dma((s + 1) & 1, pc, pc < NPA ? va0 + pc * a_rstep : (tx[pc < NPA ? 0 : pc - NPA] + b_ch) | b_oob);
                                 __builtin_amdgcn_sched_barrier(0);
                             }
                             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
                         }
+                    va0 += (unsigned)BKP * (unsigned)(a.Cout * ES);
+                    tba += BKP * 4;
                     __builtin_amdgcn_sched_barrier(0);
                 } else {
 #pragma unroll
@@ -512,8 +533,8 @@ int geometry(const ppn_wgrad_desc* d, Geom* g) {
     ns = ns > max_ns ? max_ns : ns;
     ns = ns > 64 ? 64 : ns;
     g->steps_per_split = (g->total_steps + ns - 1) / ns;
-    if (d->dtype != PPN_F32 && g->big) {        // the offset table of the ping-pong kernel bounds a split
-        const int cap = kWgTableEntries / 32 - 3;
+    if (d->dtype != PPN_F32) {                  // the x-row offset table in LDS bounds a split
+        const int cap = g->big ? kWgTableEntries / 32 - 3 : kWgTableSmall / 64 - 1;
         if (g->steps_per_split > cap) g->steps_per_split = cap;
     }
     g->nsplit = (g->total_steps + g->steps_per_split - 1) / g->steps_per_split;
@@ -525,7 +546,8 @@ int launch(const WgArgs& a, dim3 grid, hipStream_t st) {
     static int lds_set = 0;
     constexpr bool pp = sizeof(T) == 2 && WM * WN == 8;
     constexpr int bkp = sizeof(T) == 2 && !pp ? 64 : 32;
-    constexpr int lds = (pp ? 4 : 2) * bkp * (WM * TM + WN * TN) * 16 * (int)sizeof(T) + (pp ? kWgTableEntries * 4 : 0);
+    constexpr int lds = (pp ? 4 : 2) * bkp * (WM * TM + WN * TN) * 16 * (int)sizeof(T) +
+                        (pp ? kWgTableEntries * 4 : sizeof(T) == 2 ? kWgTableSmall * 4 : 0);
     auto k = wgrad_kernel<T, WM, WN, TM, TN>;
     PPN_LDS_ONCE(lds_set, reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     k<<<grid, 64 * WM * WN, lds, st>>>(a);

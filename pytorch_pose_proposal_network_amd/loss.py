@@ -47,8 +47,10 @@ class PPNLoss:
         return t.contiguous()       # the reference's torch ops accept any strides; the kernels need dense tensors
 
     def forward_backward(self, feature_map: torch.Tensor, targets: Dict[str, torch.Tensor],
-                         coeff: Optional[Sequence[float]] = None, want_grad: bool = True):
-        """-> (losses f32[5] on the device, grad like feature_map or None)."""
+                         coeff: Optional[Sequence[float]] = None, want_grad: bool = True, coeff_dev=None):
+        """-> (losses f32[5] on the device, grad like feature_map or None).
+        coeff_dev = (f32[5] device tensor, divisor): the coefficients are read on the device when the kernels run
+        (c_i = tensor[i] / divisor) instead of being passed by value -- no host read-back of the task weights."""
         lib = self._lib = self._lib or L.load()
         c = self._cfg
         B = feature_map.shape[0]
@@ -66,6 +68,17 @@ class PPNLoss:
         losses = torch.empty(5, dtype=torch.float32, device=dev)
         grad = torch.empty_like(feature_map) if want_grad else None
         cf = None
+        if want_grad and coeff_dev is not None:
+            cw, div = coeff_dev
+            if not (cw.is_cuda and cw.dtype == torch.float32 and cw.numel() == 5 and cw.is_contiguous()):
+                raise ValueError("coeff_dev[0] must be a contiguous float32 CUDA tensor of 5 elements")
+            L.check(lib.ppn_loss_fwd_bwd_dev(C.byref(c), feature_map.data_ptr(), B, t["delta"].data_ptr(),
+                                             t["weight"].data_ptr(), t["weight_ij"].data_ptr(), t["tx_half"].data_ptr(),
+                                             t["ty_half"].data_ptr(), t["tx"].data_ptr(), t["ty"].data_ptr(),
+                                             t["tw"].data_ptr(), t["th"].data_ptr(), t["te"].data_ptr(),
+                                             cw.data_ptr(), float(div), losses.data_ptr(), grad.data_ptr(),
+                                             ws.data_ptr(), L.current_stream_ptr()), "ppn_loss_fwd_bwd_dev")
+            return losses, grad
         if want_grad:
             if coeff is None:
                 raise ValueError("coeff (5 floats) is required for the backward pass")

@@ -182,12 +182,25 @@ class GradNormWeights:
         self.lr, self.alpha, self.betas, self.eps = lr, alpha, betas, eps
         self.step_count = 0
         self.log = torch.zeros(20, dtype=torch.float32, device=device)
+        self._pin, self._pin_event, self._pin_version = None, None, -1
+
+    def host_weights(self):
+        """The five weights as Python floats (coefficients of the loss kernel).  renorm() stages them into pinned memory
+        behind an event, so the next iteration reads them WITHOUT draining the queue: a plain w.tolist() at the start
+        of an iteration made the host wait for the whole forward pass it had just enqueued to its own stream and lose
+        its run-ahead -- the loss, the head backward and the GradNorm probes were then enqueued at launch latency while
+        the GPU idled (~1.5 ms per iteration).  Any in-place write to `w` by the caller invalidates the staged copy."""
+        if self._pin_event is not None and self._pin_version == self.w._version:
+            self._pin_event.synchronize()
+            return self._pin.tolist()
+        return self.w.tolist()
 
     def local_step(self, losses: torch.Tensor, gnorm: torch.Tensor, base: torch.Tensor):
         """This rank's optimizerR.step() (main.py:717-768): G_i, C_i, Lgrad, dLgrad/dw, Adam on w -- before the
         all-reduce and the renormalisation.  losses, gnorm, base: f32[5] device tensors."""
         lib = L.load()
         self.step_count += 1
+        self._pin_event = None                               # w changes behind torch's back: staged copy is stale
         L.check(lib.ppn_gradnorm_weight_step(self.w.data_ptr(), _f32(losses, 5, "losses"), _f32(gnorm, 5, "gnorm"),
                                              _f32(base, 5, "base"), self.alpha, self.exp_avg.data_ptr(),
                                              self.exp_avg_sq.data_ptr(), self.lr, self.betas[0], self.betas[1],
@@ -198,6 +211,13 @@ class GradNormWeights:
     def renorm(self, world: int = 1):
         """main.py:769-777 after the SUM all-reduce: w / world, clamp, renormalise to sum 5."""
         L.check(L.load().ppn_gradnorm_renorm(self.w.data_ptr(), world, L.current_stream_ptr()), "ppn_gradnorm_renorm")
+        if self.w.is_cuda:
+            if self._pin is None:
+                self._pin = torch.empty(5, dtype=torch.float32, pin_memory=True)
+            self._pin.copy_(self.w, non_blocking=True)
+            self._pin_event = torch.cuda.Event()
+            self._pin_event.record()
+            self._pin_version = self.w._version
 
     def step(self, losses: torch.Tensor, gnorm: torch.Tensor, base: torch.Tensor, group=None):
         """local_step, SUM all-reduce of the five weights over `group` (main.py:769-771), renorm.

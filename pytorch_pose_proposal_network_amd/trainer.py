@@ -83,7 +83,11 @@ class PPNTrainer:
         import os
         self._side = (torch.cuda.Stream(device=self.device)
                       if os.environ.get("PPN_TRAIN_SIDE_STREAM", "1") != "0" else None)
-        self._probe_stream = torch.cuda.Stream(device=self.device) if self._side is not None else None
+        # (A high-priority probe stream was tried -- PPN_TRAIN_PROBE_PRIORITY=-1 -- because the main stream waits ~0.65 ms
+        # for the four probe passes, which take 0.5 ms each beside the head backward and 0.23 ms alone: no measurable
+        # change, 1.48 vs 1.52 ms from the end of the loss to the fourth probe; tools/host_timeline.py.)
+        pri = int(os.environ.get("PPN_TRAIN_PROBE_PRIORITY", "0"))
+        self._probe_stream = torch.cuda.Stream(device=self.device, priority=pri) if self._side is not None else None
         self._probe_scratch = None
         self._conv1_local = None
         # second_order: add d Lgrad / d theta (main.py:759, the double backward through the probe gradients) to the
@@ -371,6 +375,8 @@ class PPNTrainer:
         if so is not None:
             # GradNorm's Lgrad.backward(): the second-order adjoints at h1 and at the skip tensor join the first-order
             # ones here, so everything upstream is back-propagated once
+            if so.get("launch_probes") is not None:
+                so.pop("launch_probes")()
             h1_bar, r_bar = self._second_order_tail(c, so)
             if h1_bar is not None:
                 dh1 = dh1 + h1_bar
@@ -386,7 +392,8 @@ class PPNTrainer:
         so = dict(head, targets, losses, coeff, unary=[dL_i/dW for i < 4]).  Accumulates into the tail parameters'
         gradients and returns the adjoints (at h1, at the skip tensor R) to be added to the first-order seeds.
         Derivation: DESIGN.md section 7 item 2; building blocks: train.bn_tangent / bn_dual_backward, PPNLoss.dual."""
-        head, targets, coeff = so["head"], so["targets"], so["coeff"]
+        head, targets = so["head"], so["targets"]
+        coeff = so["coeff"] if "coeff" in so else so["coeff_fn"]()
         B, Ch, Ho, Wo = head.shape
         main = torch.cuda.current_stream(self.device)
         if self._side is not None:
@@ -647,11 +654,17 @@ class PPNTrainer:
         (SUM) over `group` while the backward runs -- and the five probe-gradient norms.
         Returns (losses f32[5], gnorm f32[5], scale = 1/world for the optimiser)."""
         head = self.forward(x)
-        w = self.task.w.tolist()                                         # 5 floats D2H (coefficients of the loss kernel)
-        losses, ghead = self.criterion.forward_backward(head, targets, coeff=[v / 5.0 for v in w])
+        if self.second_order:
+            # the loss kernels read w_i / 5 from the device; the host copy (needed by the second-order tail only) is
+            # fetched there, when the previous iteration is long over -- nothing here waits for the GPU
+            losses, ghead = self.criterion.forward_backward(head, targets, coeff_dev=(self.task.w, 5.0))
+            coeff = None
+        else:
+            w = self.task.host_weights()                                 # 5 floats (coefficients of the loss kernel)
+            losses, ghead = self.criterion.forward_backward(head, targets, coeff=[v / 5.0 for v in w])
+            coeff = [v / 5.0 for v in w]
         if self.base is None:
             self._init_base(losses, group)
-        coeff = [v / 5.0 for v in w]
         unary = None
         if self.second_order:
             # the probe gradients themselves (not only their norms) steer the second-order pass inside backward()
@@ -662,16 +675,24 @@ class PPNTrainer:
             pst = self._probe_stream if self._probe_stream is not None else main
             ev = torch.cuda.Event()
             ev.record(main)
-            with torch.cuda.stream(pst):                  # the four cheap probe passes run beside the head backward
-                pst.wait_event(ev)
-                for i in range(4):
-                    self.criterion.unary_backward(head, targets, [1.0 if j == i else 0.0 for j in range(4)],
-                                                  out=self._probe_scratch)
-                    gi = self.probe_grad(self._probe_scratch, channels_used=6 * cfg.K)
-                    gi.record_stream(main)
-                    grads.append(gi)
-            so = dict(head=head, targets=targets, losses=losses, coeff=coeff, unary=grads,
-                      stream=pst if pst is not main else None)
+
+            def launch_probes():
+                # The four cheap probe passes run beside the head backward.  They only need the forward (the event
+                # above), but the HOST enqueues them after the head's first-order backward (_head_backward calls this
+                # just before the second-order tail): their ~66 small launches take the host ~1 ms, during which the
+                # main stream sat idle when they were enqueued first (rocprofv3 kernel trace, round 3).
+                with torch.cuda.stream(pst):
+                    pst.wait_event(ev)
+                    for i in range(4):
+                        self.criterion.unary_backward(head, targets, [1.0 if j == i else 0.0 for j in range(4)],
+                                                      out=self._probe_scratch)
+                        gi = self.probe_grad(self._probe_scratch, channels_used=6 * cfg.K)
+                        gi.record_stream(main)
+                        grads.append(gi)
+
+            so = dict(head=head, targets=targets, losses=losses, unary=grads,
+                      coeff_fn=lambda: [v / 5.0 for v in self.task.host_weights()],
+                      stream=pst if pst is not main else None, launch_probes=launch_probes)
             exchange = T.BucketedAllReduce(self.grad, group=group)
             self.backward(ghead, exchange, so=so)
             scale = exchange.finish()

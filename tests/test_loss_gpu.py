@@ -61,6 +61,23 @@ def test_loss_matches_oracle_full_gradient():
     assert d.max() <= 2e-5 * max(1.0, float(np.abs(ref_g).max())), d.max()
 
 
+def test_loss_device_coefficients_equal_host_coefficients():
+    """ppn_loss_fwd_bwd_dev (coefficients w_i / 5 read on the device, what PPNTrainer uses so that the host never waits
+    for the task weights) against ppn_loss_fwd_bwd with the same values passed by value: same losses, same gradient."""
+    from pytorch_pose_proposal_network_amd import loss
+    tg = {k: torch.from_numpy(v).cuda() for k, v in T.synthetic_batch(77, 3).items()}
+    head = torch.from_numpy(prng.uniform(prng.stream_seed(6, 2), 3 * cfg.lastsize() * 576, 0.01, 0.99)
+                            .reshape(3, cfg.lastsize(), 24, 24)).cuda()
+    w = torch.tensor([1.3, 0.8, 1.1, 0.7, 1.1], dtype=torch.float32).cuda()
+    crit = loss.PPNLoss()
+    l0, g0 = crit.forward_backward(head, tg, coeff=[float(np.float32(v) / np.float32(5.0)) for v in w.tolist()])
+    l1, g1 = crit.forward_backward(head, tg, coeff_dev=(w, 5.0))
+    assert torch.equal(l0, l1)
+    assert torch.equal(g0, g1)
+    with pytest.raises(ValueError):
+        crit.forward_backward(head, tg, coeff_dev=(w.double(), 5.0))
+
+
 def test_loss_argument_validation():
     from pytorch_pose_proposal_network_amd import loss
     crit = loss.PPNLoss()
