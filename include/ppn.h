@@ -473,6 +473,18 @@ int ppn_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
 int ppn_sumsq(const float* x, int64_t n, float* out, void* workspace, void* stream);
 
 /*
+ * The limb loss's probe gradient by linearity of the backward pass (the four unary probe gradients g_0..3 =
+ * dL_i/dW of main.py:704-708 and total = sum_i c_i dL_i/dW from loss.backward(), main.py:677-683) and every norm
+ * the GradNorm step needs of them, in ONE pass:
+ *     gw4 = (total - sum_{i<4} c_i g_i) / c_4                      (f32[n] device, written)
+ *     stats[0..3] = ||g_i||^2,  stats[4] = ||gw4||^2,  stats[5] = ||total - sum c_i g_i||^2,  stats[6] = ||total||^2
+ * coeff: HOST pointer to 5 floats c_i, c_4 != 0.  Every sum equals ppn_sumsq of that tensor (same mapping and
+ * reduction order; deterministic).  workspace >= 1024 * 7 doubles.
+ */
+int ppn_gradnorm_probe_stats(const float* g0, const float* g1, const float* g2, const float* g3, const float* total,
+                             const float* coeff, int64_t n, float* gw4, float* stats, void* workspace, void* stream);
+
+/*
  * A13: the task-weight half of the GradNorm step (main.py:717-765), all on device, one launch:
  *     l_i = w_i*L_i;  G_i = w_i*gnorm_i;  G_avg = mean G;  lhat_i = l_i/base_i;  r_i = lhat_i/mean(lhat)
  *     C_i = G_avg * r_i^alpha (constant);  Lgrad = sum |G_i - C_i|;  dLgrad/dw_i = sign(G_i - C_i)*gnorm_i

@@ -300,6 +300,57 @@ __global__ void sumsq_final_kernel(const double* __restrict__ partial, int nb, f
     out[0] = (float)acc;
 }
 
+// ---- GradNorm probe statistics (main.py:704-717 for the limb loss by linearity; trainer.py _second_order_tail) ----
+// gw4 = (total - sum_{i<4} c_i g_i) / c_4 and seven sums of squares in one pass: ||g_0..3||^2, ||gw4||^2, the unscaled
+// remainder's and the total's (the trust test of the bf16 mode).  Same element -> thread mapping and the same
+// reduction tree as sumsq_partial_kernel, so every sum equals what ppn_sumsq returns for that tensor.
+struct ProbeStatsArgs {
+    const float* g[4];
+    const float* total;
+    float c[5];
+    long long n;
+    float* gw4;
+    double* partial;      // [gridDim.x][7]
+};
+__global__ void __launch_bounds__(kThreads) probe_stats_partial_kernel(ProbeStatsArgs a) {
+    __shared__ double red[kThreads];
+    double acc[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    const long long stride = (long long)gridDim.x * kThreads;
+    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < a.n; i += stride) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float g = a.g[k][i];
+            acc[k] += (double)g * (double)g;
+            s = s + a.c[k] * g;
+        }
+        const float t = a.total[i];
+        const float rest = t - s;
+        const float g4 = rest / a.c[4];
+        a.gw4[i] = g4;
+        acc[4] += (double)g4 * (double)g4;
+        acc[5] += (double)rest * (double)rest;
+        acc[6] += (double)t * (double)t;
+    }
+    for (int k = 0; k < 7; ++k) {
+        __syncthreads();
+        red[threadIdx.x] = acc[k];
+        __syncthreads();
+        for (int o = kThreads / 2; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) a.partial[(size_t)blockIdx.x * 7 + k] = red[0];
+    }
+}
+__global__ void probe_stats_final_kernel(const double* __restrict__ partial, int nb, float* __restrict__ out) {
+    const int k = threadIdx.x;
+    if (k >= 7) return;
+    double acc = 0.0;
+    for (int b = 0; b < nb; ++b) acc += partial[(size_t)b * 7 + k];
+    out[k] = (float)acc;
+}
+
 // ---- GradNorm task weights (5 scalars, one lane) ------------------------------------------------------------
 __global__ void gradnorm_kernel(float* __restrict__ w, const float* __restrict__ L, const float* __restrict__ gn,
                                 const float* __restrict__ base, float alpha, float* __restrict__ m,
@@ -911,6 +962,26 @@ int ppn_sumsq(const float* x, int64_t n, float* out, void* workspace, void* stre
     sumsq_partial_kernel<<<(int)blocks, kThreads, 0, st>>>(x, n, (double*)workspace);
     PPN_LAUNCH_CHECK();
     sumsq_final_kernel<<<1, 1, 0, st>>>((const double*)workspace, (int)blocks, out);
+    PPN_LAUNCH_CHECK();
+    return PPN_OK;
+}
+
+int ppn_gradnorm_probe_stats(const float* g0, const float* g1, const float* g2, const float* g3, const float* total,
+                             const float* coeff, int64_t n, float* gw4, float* stats, void* workspace, void* stream) {
+    if (!g0 || !g1 || !g2 || !g3 || !total || !coeff || !gw4 || !stats || !workspace || n < 0)
+        return ppn::fail(PPN_E_INVALID, "ppn_gradnorm_probe_stats: NULL argument");
+    if (!(coeff[4] != 0.f)) return ppn::fail(PPN_E_INVALID, "ppn_gradnorm_probe_stats: coeff[4] must not be zero");
+    long long blocks = (n + kThreads * 8 - 1) / (kThreads * 8);
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    ProbeStatsArgs a;
+    a.g[0] = g0; a.g[1] = g1; a.g[2] = g2; a.g[3] = g3; a.total = total;
+    for (int i = 0; i < 5; ++i) a.c[i] = coeff[i];
+    a.n = n; a.gw4 = gw4; a.partial = (double*)workspace;
+    hipStream_t st = (hipStream_t)stream;
+    probe_stats_partial_kernel<<<(int)blocks, kThreads, 0, st>>>(a);
+    PPN_LAUNCH_CHECK();
+    probe_stats_final_kernel<<<1, 64, 0, st>>>((const double*)workspace, (int)blocks, stats);
     PPN_LAUNCH_CHECK();
     return PPN_OK;
 }

@@ -130,6 +130,8 @@ _SIGNATURES.update({
     "ppn_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double,
                                 C.c_double, C.c_double, C.c_double, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
     "ppn_sumsq": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ppn_gradnorm_probe_stats": (C.c_int, [C.c_void_p] * 5 + [C.POINTER(C.c_float), C.c_int64, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_void_p]),
     "ppn_gradnorm_weight_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,
                                            C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32,
                                            C.c_void_p, C.c_void_p]),

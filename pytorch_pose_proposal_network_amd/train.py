@@ -157,6 +157,22 @@ def sumsq(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def probe_stats(g4, total: torch.Tensor, coeff):
+    """(gw4, stats f32[7]) of ppn_gradnorm_probe_stats: the limb probe gradient by linearity and the seven sums of squares
+    (||g_0..3||^2, ||gw4||^2, ||unscaled remainder||^2, ||total||^2) in one pass over the five tensors."""
+    n = total.numel()
+    for t in list(g4) + [total]:
+        _f32(t, n, "probe gradient")
+    gw4 = torch.empty_like(total)
+    st = torch.empty(7, dtype=torch.float32, device=total.device)
+    ws = torch.empty(1024 * 7, dtype=torch.float64, device=total.device)
+    cf = (C.c_float * 5)(*[float(v) for v in coeff])
+    L.check(L.load().ppn_gradnorm_probe_stats(g4[0].data_ptr(), g4[1].data_ptr(), g4[2].data_ptr(), g4[3].data_ptr(),
+                                              total.data_ptr(), cf, n, gw4.data_ptr(), st.data_ptr(), ws.data_ptr(),
+                                              L.current_stream_ptr()), "ppn_gradnorm_probe_stats")
+    return gw4, st
+
+
 def allreduce_mean_(flat: torch.Tensor, group=None) -> float:
     """SUM all-reduce of one flat buffer (RCCL when the tensor is on a GPU, gloo on CPU); returns the 1/world
     factor the caller folds into its next kernel (FlatAdam.step(grad_scale=...)) instead of a separate divide --

@@ -400,17 +400,42 @@ class PPNTrainer:
             main.wait_stream(self._side)                 # the first-order tail gradients this pass accumulates into
         if so.get("stream") is not None:
             main.wait_stream(so["stream"])                # the unary probe gradients
-        gw = list(so["unary"])
-        acc = sum(float(coeff[i]) * gw[i] for i in range(4))
-        gw.append(self._limb_probe(self.G["conv1.weight"], acc, coeff, head, targets))
-        gn = torch.stack([T.sumsq(g.contiguous().view(-1)).sqrt().reshape(()) for g in gw])
+        gw = [g.contiguous() for g in so["unary"]]
+        # The limb probe gradient by linearity, the five probe norms, the trust test of the bf16 mode and GradNorm's
+        # C_i / signs: ONE kernel pass over the five weight-sized tensors and ONE host read-back (the 5 x 9.4 MB tensors
+        # went through ~45 tiny torch launches and three read-backs, each draining the queue: 0.8 ms of an idle GPU per
+        # iteration, tools/train_timeline.py).
+        total = self.G["conv1.weight"]
+        trusted = coeff[4] > 1e-3 * max(coeff)
+        if trusted:
+            gw4, st = T.probe_stats(gw, total.contiguous(), coeff)
+            host = torch.cat([st, so["losses"].reshape(5), self.base.reshape(5)]).tolist()
+            if self.compute_dtype != L.PPN_F32:
+                # bf16: `total` and the unary probes come from differently rounded passes (relative noise ~2^-8 each);
+                # a remainder that is not clearly above that noise cannot be trusted (see _limb_probe)
+                trusted = host[5] > (16.0 * 2.0 ** -8) ** 2 * host[6]
+        if trusted:
+            ss = host[:5]
+            gw.append(gw4)
+        else:
+            _, g4 = self.criterion.forward_backward(head, targets, coeff=[0.0, 0.0, 0.0, 0.0, 1.0])
+            gw.append(self.probe_grad(g4))
+            host = torch.cat([torch.cat([T.sumsq(g.contiguous().view(-1)) for g in gw]), so["losses"].reshape(5),
+                              self.base.reshape(5)]).tolist()
+            ss = host[:5]
+            host = ss + [0.0, 0.0] + host[5:]
+        import numpy as _np
+        f32 = _np.float32
+        gn_np = _np.sqrt(_np.asarray(ss, dtype=f32))
+        gn = torch.from_numpy(gn_np).to(self.device, non_blocking=True)
         so["gnorm"] = gn
-        w = self.task.w
-        G = w.abs() * gn                                                          # main.py:717-721
-        lhat = w * so["losses"] / self.base
-        Cc = G.mean() * (lhat / lhat.mean()) ** self.task.alpha                  # main.py:726-753 (constant)
-        kappa = (torch.sign(G - Cc) * torch.sign(w) * w.abs()).tolist()          # d Lgrad / d||g_i||, times w_i
-        gn_h = gn.tolist()
+        w_np = _np.asarray(self.task.host_weights(), dtype=f32)
+        loss_np, base_np = _np.asarray(host[7:12], dtype=f32), _np.asarray(host[12:17], dtype=f32)
+        G = _np.abs(w_np) * gn_np                                                 # main.py:717-721
+        lhat = w_np * loss_np / base_np
+        Cc = G.mean(dtype=f32) * (lhat / lhat.mean(dtype=f32)) ** f32(self.task.alpha)   # main.py:726-753 (constant)
+        kappa = (_np.sign(G - Cc) * _np.sign(w_np) * _np.abs(w_np)).tolist()      # d Lgrad / d||g_i||, times w_i
+        gn_h = gn_np.tolist()
         k6 = 6 * cfg.K
         P, Gd = self.P, self.G
         act = [i for i in range(5) if kappa[i] != 0.0 and gn_h[i] != 0.0]
@@ -423,7 +448,7 @@ class PPNTrainer:
             return [t[j * B:(j + 1) * B] for j in range(n)]
 
         def ssum(t):                                                              # sum over the stacked streams
-            return t.view(n, B, *t.shape[1:]).sum(0)
+            return t if n == 1 else t.view(n, B, *t.shape[1:]).sum(0)
 
         # ---- forward-mode tangents through the tail.  Every stream is linear in its tangent, so the streams are
         # stacked along the batch dimension for the convolutions (one launch for all of them); the BN tangents need
@@ -459,7 +484,8 @@ class PPNTrainer:
             cpad = zb.shape[-1]
             w3p = torch.zeros(cpad, w3u.shape[1], 1, 1, dtype=torch.float32, device=self.device)
             w3p[:used] = w3u
-            dw3 = T.conv_wgrad(c["h3"], zb.view(m, B, Ho, Wo, cpad).sum(0), 1)    # primal stream: same h3 for all
+            zsum = zb if m == 1 else zb.view(m, B, Ho, Wo, cpad).sum(0)          # (m == 1: a 280 MB no-op reduction)
+            dw3 = T.conv_wgrad(c["h3"], zsum, 1)                                  # primal stream: same h3 for all
             T.conv_wgrad(th3, tzb, 1, out=dw3, accumulate=True)                  # tangent stream: stacked batch
             Gd["conv3.weight"][:used] += dw3[:used]
             Gd["conv3.bias"][:used] += zbar.sum((0, 2, 3))
@@ -654,6 +680,8 @@ class PPNTrainer:
         (SUM) over `group` while the backward runs -- and the five probe-gradient norms.
         Returns (losses f32[5], gnorm f32[5], scale = 1/world for the optimiser)."""
         head = self.forward(x)
+        ev_head = torch.cuda.Event()
+        ev_head.record(torch.cuda.current_stream(self.device))        # the probe passes need the head, not the loss
         if self.second_order:
             # the loss kernels read w_i / 5 from the device; the host copy (needed by the second-order tail only) is
             # fetched there, when the previous iteration is long over -- nothing here waits for the GPU
@@ -673,8 +701,7 @@ class PPNTrainer:
             grads = []
             main = torch.cuda.current_stream(self.device)
             pst = self._probe_stream if self._probe_stream is not None else main
-            ev = torch.cuda.Event()
-            ev.record(main)
+            ev = ev_head                                  # probes start beside the loss kernels (0.45 ms of head start)
 
             def launch_probes():
                 # The four cheap probe passes run beside the head backward.  They only need the forward (the event
