@@ -558,6 +558,17 @@ int ppn_loss_dual(const ppn_loss_cfg* cfg, const float* head, const float* tz, i
                   const float* tx, const float* ty, const float* tw, const float* th, const float* te,
                   const float* coeff, int32_t unary_only, float* zbar, float* tzbar, void* stream);
 
+/*
+ * The limb loss's stream of ppn_loss_dual -- coefficient vector (0, 0, 0, 0, c4) -- with the outputs in the layout the
+ * convolutions read: zb, tzb `dtype` [B][H*W][cpad] NHWC (cpad a multiple of 64, >= 6K + E*sH*sW; channels outside the
+ * limb range are zero) and zsum f32 [B][ceil(H*W/64)][cpad], the per-block pixel sums of zbar (summed over the first two
+ * axes they are conv3.bias' second-order gradient).  Same arithmetic as ppn_loss_dual + ppn_nchw_to_nhwc without the two
+ * f32 head-layout intermediates (2 x 17 MB per image written and re-read).
+ */
+int ppn_loss_limb_dual_nhwc(const ppn_loss_cfg* cfg, const float* head, const float* tz, int32_t batch,
+                            const float* weight_ij, const float* te, float c4, int32_t dtype, int32_t cpad, void* zb,
+                            void* tzb, float* zsum, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

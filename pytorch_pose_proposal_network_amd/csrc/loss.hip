@@ -13,6 +13,7 @@
 // per-workgroup partial sums are combined by finalize_kernel in a fixed order, so the five losses are bitwise
 // reproducible from run to run (no float atomics).
 #include "common.h"
+#include "conv_common.h"
 
 namespace {
 
@@ -241,6 +242,58 @@ __global__ void __launch_bounds__(256) limb_dual_kernel(DualArgs p) {
     }
 }
 
+// The limb stream of the second-order pass, fused with the relayout the convolutions want: for the limb channels the same
+// arithmetic as limb_dual_kernel, but zbar / tzbar go straight to NHWC `T` tensors [B][HW][Cpad] (what conv3's weight
+// and input gradients read) through a 64 x 64 LDS transpose instead of to two f32 head-layout tensors that a second pass
+// re-reads (2 x 541 MB written + read at batch 32) -- and the per-channel sums of zbar over a block's pixels (conv3.bias'
+// second-order gradient) leave as partials [B][ceil(HW/64)][Cpad].  Channels outside [6K, C) are zero.
+template <typename T>
+__global__ void __launch_bounds__(256) limb_dual_nhwc_kernel(LossArgs a, const float* __restrict__ tzp, float c4, int Cpad,
+                                                             T* __restrict__ zb, T* __restrict__ tzb,
+                                                             float* __restrict__ zsum) {
+    __shared__ float tz_t[64][65], z_t[64][65];
+    const int HW = a.H * a.W, C6 = 6 * a.K;
+    const int c0 = blockIdx.x * 64, p0 = blockIdx.y * 64, b = blockIdx.z;
+    const int t = threadIdx.x, px = t & 63;
+    const size_t per_img = (size_t)a.E * a.S * HW;
+    const float g2 = 2.f * c4 / (float)a.B;
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {
+        const int cl = (t >> 6) + 4 * i;
+        const int c = c0 + cl, p = p0 + px;
+        float zv = 0.f, tv = 0.f;
+        if (c >= C6 && c < a.C && p < HW) {
+            const size_t ho = ((size_t)b * a.C + c) * HW + p;
+            const size_t li = (size_t)b * per_img + (size_t)(c - C6) * HW + p;
+            const float s = a.head[ho], tz = tzp[ho], wj = a.weight_ij[li];
+            const float sdot = s * (1.f - s) * tz;
+            sigmoid_dual_adjoint(s, tz, g2 * wj * sdot, g2 * wj * (s - a.te[li]), &zv, &tv);
+        }
+        z_t[px][cl] = zv;
+        tz_t[px][cl] = tv;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int item = t + 256 * i;
+        const int pr = item >> 3, ch = item & 7;
+        const int p = p0 + pr;
+        if (p < HW && c0 + ch * 8 < Cpad) {
+            float v[8], w[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { v[j] = z_t[pr][ch * 8 + j]; w[j] = tz_t[pr][ch * 8 + j]; }
+            const size_t o = (((size_t)b * HW + p) * Cpad + c0 + ch * 8) * sizeof(T);
+            ppnconv::store8<T>(reinterpret_cast<char*>(zb) + o, v);
+            ppnconv::store8<T>(reinterpret_cast<char*>(tzb) + o, w);
+        }
+    }
+    if (t < 64 && c0 + t < Cpad) {                                       // fixed order: reproducible
+        float acc = 0.f;
+        for (int q = 0; q < 64; ++q) acc += z_t[q][t];
+        zsum[((size_t)b * gridDim.y + blockIdx.y) * Cpad + c0 + t] = acc;
+    }
+}
+
 template <int V>
 __global__ void __launch_bounds__(256) limb_kernel(LossArgs a) {
     __shared__ float s_red[4];
@@ -435,5 +488,31 @@ extern "C" int ppn_loss_dual(const ppn_loss_cfg* cfg, const float* head, const f
         hipLaunchKernelGGL(limb_dual_kernel, dim3(256 * 16), dim3(256), 0, st, p);
         PPN_LAUNCH_CHECK();
     }
+    return PPN_OK;
+}
+
+// The limb loss's stream of ppn_loss_dual (coefficient vector (0,0,0,0,c4)) with NHWC outputs: zb, tzb `dtype`
+// [B][H*W][cpad] (cpad a multiple of 64 >= 6K + E*S; channels outside the limb range are zero) and
+// zsum f32 [B][ceil(H*W/64)][cpad], the per-block pixel sums of zbar.  Same arithmetic as ppn_loss_dual followed by
+// ppn_nchw_to_nhwc, without the two f32 head-layout intermediates.
+extern "C" int ppn_loss_limb_dual_nhwc(const ppn_loss_cfg* cfg, const float* head, const float* tz, int32_t batch,
+                                       const float* weight_ij, const float* te, float c4, int32_t dtype, int32_t cpad,
+                                       void* zb, void* tzb, float* zsum, void* stream) {
+    LossArgs a;
+    if (int rc = fill(a, cfg, batch)) return rc;
+    if (!head || !tz || !weight_ij || !te || !zb || !tzb || !zsum)
+        return ppn::fail(PPN_E_INVALID, "ppn_loss_limb_dual_nhwc: NULL pointer");
+    if (cpad % 64 || cpad < a.C) return ppn::fail(PPN_E_INVALID, "ppn_loss_limb_dual_nhwc: cpad %d for %d channels", cpad, a.C);
+    if (dtype != PPN_F32 && dtype != PPN_BF16) return ppn::fail(PPN_E_INVALID, "ppn_loss_limb_dual_nhwc: bad dtype %d", dtype);
+    a.head = head; a.weight_ij = weight_ij; a.te = te;
+    a.delta = a.weight = a.tx_half = a.ty_half = a.tx = a.ty = a.tw = a.th = nullptr;
+    a.grad = nullptr; a.partial = nullptr; a.losses = nullptr; a.coeff_dev = nullptr; a.coeff_div = 1.f;
+    for (int i = 0; i < 5; ++i) a.coeff[i] = 0.f;
+    const int HW = a.H * a.W;
+    const dim3 grid(cpad / 64, (HW + 63) / 64, batch);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == PPN_F32) hipLaunchKernelGGL(limb_dual_nhwc_kernel<float>, grid, dim3(256), 0, st, a, tz, c4, cpad, (float*)zb, (float*)tzb, zsum);
+    else hipLaunchKernelGGL(limb_dual_nhwc_kernel<__bf16>, grid, dim3(256), 0, st, a, tz, c4, cpad, (__bf16*)zb, (__bf16*)tzb, zsum);
+    PPN_LAUNCH_CHECK();
     return PPN_OK;
 }

@@ -153,6 +153,9 @@ _SIGNATURES.update({
     "ppn_bn_act_mask": (C.c_int, [C.POINTER(BnBwdDesc), C.c_void_p]),
     "ppn_bn_dual_workspace_bytes": (C.c_size_t, [C.c_int32]),
     "ppn_bn_dual_bwd": (C.c_int, [C.POINTER(BnBwdDesc), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ppn_loss_limb_dual_nhwc": (C.c_int, [C.POINTER(LossCfg), C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                          C.c_float, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_void_p]),
     "ppn_loss_dual": (C.c_int, [C.POINTER(LossCfg), C.c_void_p, C.c_void_p, C.c_int32] + [C.c_void_p] * 10 +
                       [C.POINTER(C.c_float), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ppn_conv_wgrad_workspace_bytes": (C.c_size_t, [C.POINTER(WgradDesc)]),

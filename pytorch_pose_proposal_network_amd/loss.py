@@ -146,6 +146,33 @@ class PPNLoss:
                                   zbar.data_ptr(), tzbar.data_ptr(), L.current_stream_ptr()), "ppn_loss_dual")
         return zbar, tzbar
 
+    def limb_dual_nhwc(self, feature_map: torch.Tensor, tz: torch.Tensor, targets: Dict[str, torch.Tensor], c4: float,
+                       dtype: torch.dtype):
+        """The limb stream of dual() -- coefficients (0,0,0,0,c4) -- with NHWC outputs: (zb, tzb `dtype` [B,H,W,cpad],
+        zsum f32 [B*ceil(HW/64), cpad] whose column sums are the per-channel sums of zbar).  Equals dual() followed by
+        train.nchw_to_nhwc on both results, without the two f32 head-layout intermediates."""
+        lib = self._lib = self._lib or L.load()
+        c = self._cfg
+        B = feature_map.shape[0]
+        C_ = 6 * c.K + c.E * c.sH * c.sW
+        feature_map = self._check("feature_map", feature_map, (B, C_, c.H, c.W))
+        tz = self._check("tz", tz, (B, C_, c.H, c.W))
+        wij = self._check("weight_ij", targets["weight_ij"], (B, c.E, c.sH, c.sW, c.H, c.W))
+        te = self._check("te", targets["te"], (B, c.E, c.sH, c.sW, c.H, c.W))
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("dtype must be float32 or bfloat16")
+        cpad = (C_ + 63) // 64 * 64
+        dev = feature_map.device
+        zb = torch.empty(B, c.H, c.W, cpad, dtype=dtype, device=dev)
+        tzb = torch.empty_like(zb)
+        npy = (c.H * c.W + 63) // 64
+        zsum = torch.empty(B * npy, cpad, dtype=torch.float32, device=dev)
+        L.check(lib.ppn_loss_limb_dual_nhwc(C.byref(c), feature_map.data_ptr(), tz.data_ptr(), B, wij.data_ptr(),
+                                            te.data_ptr(), float(c4), L.PPN_F32 if dtype == torch.float32 else L.PPN_BF16,
+                                            cpad, zb.data_ptr(), tzb.data_ptr(), zsum.data_ptr(),
+                                            L.current_stream_ptr()), "ppn_loss_limb_dual_nhwc")
+        return zb, tzb, zsum
+
     def forward(self, image, feature_map, delta, weight, weight_ij, tx_half, ty_half, tx, ty, tw, th, te):
         """Reference signature (main.py:180); `image` is only used for its batch size there and is ignored here."""
         targets = dict(delta=delta, weight=weight, weight_ij=weight_ij, tx_half=tx_half, ty_half=ty_half, tx=tx, ty=ty,

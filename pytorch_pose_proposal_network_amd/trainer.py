@@ -474,13 +474,20 @@ class PPNTrainer:
             w3u = P["conv3.weight"] if used == Ch else P["conv3.weight"][:used].contiguous()
             th3 = TH3[js[0] * B:(js[-1] + 1) * B]                                 # the group's streams are adjacent
             t_z = T.conv2d_nhwc(th3, w3u, nchw_f32=True)                          # logit tangents [m*B, used, H, W]
-            zbar, tzbar = torch.empty_like(t_z), torch.empty_like(t_z)
-            for q, j in enumerate(js):
-                ci = [0.0] * 5
-                ci[act[j]] = kappa[act[j]]
-                sl = slice(q * B, (q + 1) * B)
-                self.criterion.dual(head, t_z[sl], targets, ci, unary_only=used != Ch, out=(zbar[sl], tzbar[sl]))
-            zb, tzb = T.nchw_to_nhwc(zbar, self.tdt), T.nchw_to_nhwc(tzbar, self.tdt)
+            if used == Ch and self.tdt in (torch.float32, torch.bfloat16):
+                # the limb stream (one stream, the whole head): dual seeds, relayout and the pixel sums of zbar in
+                # one pass -- no f32 head-layout zbar / tzbar (2 x 541 MB written and re-read at batch 32)
+                zb, tzb, zpart = self.criterion.limb_dual_nhwc(head, t_z, targets, kappa[4], self.tdt)
+                zbias = zpart.sum(0)[:used]
+            else:
+                zbar, tzbar = torch.empty_like(t_z), torch.empty_like(t_z)
+                for q, j in enumerate(js):
+                    ci = [0.0] * 5
+                    ci[act[j]] = kappa[act[j]]
+                    sl = slice(q * B, (q + 1) * B)
+                    self.criterion.dual(head, t_z[sl], targets, ci, unary_only=used != Ch, out=(zbar[sl], tzbar[sl]))
+                zb, tzb = T.nchw_to_nhwc(zbar, self.tdt), T.nchw_to_nhwc(tzbar, self.tdt)
+                zbias = zbar.sum((0, 2, 3))
             cpad = zb.shape[-1]
             w3p = torch.zeros(cpad, w3u.shape[1], 1, 1, dtype=torch.float32, device=self.device)
             w3p[:used] = w3u
@@ -488,7 +495,7 @@ class PPNTrainer:
             dw3 = T.conv_wgrad(c["h3"], zsum, 1)                                  # primal stream: same h3 for all
             T.conv_wgrad(th3, tzb, 1, out=dw3, accumulate=True)                  # tangent stream: stacked batch
             Gd["conv3.weight"][:used] += dw3[:used]
-            Gd["conv3.bias"][:used] += zbar.sum((0, 2, 3))
+            Gd["conv3.bias"][:used] += zbias
             H3bar[js[0] * B:(js[-1] + 1) * B] = T.conv_dgrad(zb, w3p, (Ho, Wo))
             TH3bar[js[0] * B:(js[-1] + 1) * B] = T.conv_dgrad(tzb, w3p, (Ho, Wo))
         # ---- reverse pass over the dual tail --------------------------------------------------------------------------

@@ -101,3 +101,30 @@ def test_loss_dual_matches_double_backward(coeff):
     for mine, ref in ((zbar, zbar_ref), (tzbar, tzbar_ref)):
         m, r = mine.cpu().double(), ref[:, sl]
         assert (m - r).abs().max() <= 2e-4 * max(1e-3, r.abs().max().item()), ((m - r).abs().max(), r.abs().max())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_limb_dual_nhwc_equals_dual_plus_relayout(dtype):
+    """ppn_loss_limb_dual_nhwc (what the trainer's limb stream uses) against the pieces it fuses -- PPNLoss.dual with
+    coefficients (0,0,0,0,c4), checked above against torch double backward, then train.nchw_to_nhwc: the same arithmetic,
+    so the NHWC tensors must be EQUAL; the pixel-sum partials against an f64 sum of zbar."""
+    from pytorch_pose_proposal_network_amd import loss, prng, train as T, config as cfg
+    from oracle import targets_ref as Tg
+    B, c4 = 3, -0.37
+    tg = {k: torch.from_numpy(v).cuda() for k, v in Tg.synthetic_batch(51, B).items()}
+    Cn = cfg.lastsize()
+    head = torch.sigmoid(torch.from_numpy(prng.uniform(prng.stream_seed(10, 1), B * Cn * 576, -3.0, 3.0)
+                                          .reshape(B, Cn, 24, 24).astype(np.float32)).cuda())
+    tz = torch.from_numpy(prng.uniform(prng.stream_seed(10, 2), B * Cn * 576, -1.0, 1.0)
+                          .reshape(B, Cn, 24, 24).astype(np.float32)).cuda()
+    crit = loss.PPNLoss()
+    zbar, tzbar = crit.dual(head, tz, tg, [0.0, 0.0, 0.0, 0.0, c4])
+    zb_ref, tzb_ref = T.nchw_to_nhwc(zbar, dtype), T.nchw_to_nhwc(tzbar, dtype)
+    zb, tzb, zsum = crit.limb_dual_nhwc(head, tz, tg, c4, dtype)
+    torch.cuda.synchronize()
+    assert zb.shape == zb_ref.shape and torch.equal(zb, zb_ref) and torch.equal(tzb, tzb_ref)
+    assert float(zbar[:, :6 * cfg.K].abs().max()) == 0.0                 # the limb stream leaves the unary channels alone
+    ref = zbar.double().sum((0, 2, 3)).cpu()
+    got = zsum.double().sum(0)[:Cn].cpu()
+    assert (got - ref).abs().max() <= 1e-5 * max(1e-6, float(ref.abs().max()))
+    assert float(zsum[:, Cn:].abs().max()) == 0.0
