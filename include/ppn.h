@@ -135,6 +135,23 @@ int ppn_loss_fwd_bwd_dev(const ppn_loss_cfg* cfg, const float* head, int32_t bat
                          void* stream);
 
 /*
+ * ppn_loss_fwd_bwd_dev and ppn_head_grad in one pass over the head: the five losses and, instead of d loss / d head in
+ * the head layout, the gradient w.r.t. conv3's LOGITS in the layout the convolutions' backward reads:
+ *   dz     `dtype` (PPN_F32 / PPN_BF16) [B][H*W][cpad] NHWC = g * s(1-s), channels >= 6K + E*sH*sW zero; cpad % 64 == 0
+ *   dbsum  f32 [B][ceil(H*W/64)][cpad]: per-block cell sums of dz; summed over the first two axes = d loss / d conv3.bias
+ *   grad_unary  f32 scratch [B][6K][H*W] (the unary channels' d loss / d head)
+ * workspace >= ppn_loss_dz_workspace_bytes(cfg, batch, cpad).  Saves the f32 head-layout gradient (17 MB per image
+ * written once and read twice).  loss_limb is summed per 64 x 64 block and then in a fixed order (reproducible; it
+ * differs from ppn_loss_fwd_bwd's value in the last bits).
+ */
+size_t ppn_loss_dz_workspace_bytes(const ppn_loss_cfg* cfg, int32_t batch, int32_t cpad);
+int ppn_loss_fwd_bwd_dz(const ppn_loss_cfg* cfg, const float* head, int32_t batch, const float* delta,
+                        const float* weight, const float* weight_ij, const float* tx_half, const float* ty_half,
+                        const float* tx, const float* ty, const float* tw, const float* th, const float* te,
+                        const float* coeff_dev, float coeff_div, float* losses, float* grad_unary, int32_t dtype,
+                        int32_t cpad, void* dz, float* dbsum, void* workspace, void* stream);
+
+/*
  * Training-target encoder (dataset.py:96-185) on the device: person lists -> the ten target tensors of
  * ppn_loss_fwd_bwd, bit-exact with the host encoder.  Replaces the per-sample host encoding + 2 x 17.3 MB/sample
  * H2D of main.py:649-661.

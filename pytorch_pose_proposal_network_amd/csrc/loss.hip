@@ -30,6 +30,7 @@ struct LossArgs {
     float coeff_div;
     int B, K, E, S, H, W, C, inW, inH;
     int nblk_unary, nblk_limb;
+    int Cg;               // channels of the tensor `grad` points at: C (head layout) or 6K (compact: unary channels only)
 };
 
 // coefficient i: by value (host call) or from device memory (a uniform scalar load)
@@ -101,12 +102,13 @@ __global__ void __launch_bounds__(256) unary_kernel(LossArgs a) {
             const float da1 = pick_lt(a1, c1), db1 = pick_gt(b1, d1), da2 = pick_lt(a2, c2), db2 = pick_gt(b2, d2);
             const float g_rx = g_wr * (da1 - db1), g_ry = g_hr * (da2 - db2);
             const float g_rw = g_wr * 0.5f * (da1 + db1) + gA0 * rh, g_rh = g_hr * 0.5f * (da2 + db2) + gA0 * rw;
-            a.grad[hb] = 2.f * dr * c0;
-            a.grad[hb + KS] = 2.f * dl * dc * c1c;
-            a.grad[hb + 2 * KS] = g_rx * gW + 2.f * wt * dx * c2c;
-            a.grad[hb + 3 * KS] = g_ry * gH + 2.f * wt * dy * c2c;
-            a.grad[hb + 4 * KS] = g_rw * inW + wt * dsw / sw * c3c;
-            a.grad[hb + 5 * KS] = g_rh * inH + wt * dsh / sh * c3c;
+            const size_t gb = (size_t)b * a.Cg * HW + (size_t)k * HW + cell;
+            a.grad[gb] = 2.f * dr * c0;
+            a.grad[gb + KS] = 2.f * dl * dc * c1c;
+            a.grad[gb + 2 * KS] = g_rx * gW + 2.f * wt * dx * c2c;
+            a.grad[gb + 3 * KS] = g_ry * gH + 2.f * wt * dy * c2c;
+            a.grad[gb + 4 * KS] = g_rw * inW + wt * dsw / sw * c3c;
+            a.grad[gb + 5 * KS] = g_rh * inH + wt * dsh / sh * c3c;
         }
     }
     float* out = a.partial + (size_t)blockIdx.x * 4;
@@ -294,6 +296,65 @@ __global__ void __launch_bounds__(256) limb_dual_nhwc_kernel(LossArgs a, const f
     }
 }
 
+// Limb loss forward + backward fused with what the head's backward does first (ppn_head_grad): for a 64-channel x 64-cell
+// block the loss terms w_ij (e - te)^2 are summed (one partial per block), the gradient through the sigmoid
+// dz = g * s(1 - s) goes straight to the NHWC `T` tensor conv3's weight / input gradients read (the unary channels' g
+// comes from the compact tensor unary_kernel wrote), and the per-channel sums of dz over the block's cells leave as
+// partials (conv3.bias' gradient).  Saves the f32 head-layout gradient (17 MB per image written, then re-read twice).
+template <typename T>
+__global__ void __launch_bounds__(256) limb_loss_dz_kernel(LossArgs a, const float* __restrict__ ugrad, int Cpad,
+                                                           T* __restrict__ dz, float* __restrict__ dbsum) {
+    __shared__ float d_t[64][65];
+    __shared__ float s_red[4];
+    const int HW = a.H * a.W, C6 = 6 * a.K;
+    const int c0 = blockIdx.x * 64, p0 = blockIdx.y * 64, b = blockIdx.z;
+    const int t = threadIdx.x, px = t & 63;
+    const size_t per_img = (size_t)a.E * a.S * HW;
+    const float g2 = 2.f * coef(a, 4) / (float)a.B;
+    float lsum = 0.f;
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {
+        const int cl = (t >> 6) + 4 * i;
+        const int c = c0 + cl, p = p0 + px;
+        float v = 0.f;
+        if (c < a.C && p < HW) {
+            const float s = a.head[((size_t)b * a.C + c) * HW + p];
+            float g;
+            if (c >= C6) {
+                const size_t li = (size_t)b * per_img + (size_t)(c - C6) * HW + p;
+                const float wj = a.weight_ij[li], d = s - a.te[li];
+                lsum += wj * d * d;
+                g = g2 * wj * d;
+            } else {
+                g = ugrad[((size_t)b * C6 + c) * HW + p];
+            }
+            v = g * (s * (1.f - s));
+        }
+        d_t[px][cl] = v;
+    }
+    const float bs = block_sum(lsum, s_red);                             // (contains the barrier the tile needs)
+    if (t == 0)
+        a.partial[(size_t)a.nblk_unary * 4 + ((size_t)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = bs;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int item = t + 256 * i;
+        const int pr = item >> 3, ch = item & 7;
+        const int p = p0 + pr;
+        if (p < HW && c0 + ch * 8 < Cpad) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = d_t[pr][ch * 8 + j];
+            ppnconv::store8<T>(reinterpret_cast<char*>(dz) + (((size_t)b * HW + p) * Cpad + c0 + ch * 8) * sizeof(T), v);
+        }
+    }
+    if (t < 64 && c0 + t < Cpad) {                                       // fixed order: reproducible
+        float acc = 0.f;
+        for (int q = 0; q < 64; ++q) acc += d_t[q][t];
+        dbsum[((size_t)b * gridDim.y + blockIdx.y) * Cpad + c0 + t] = acc;
+    }
+}
+
 template <int V>
 __global__ void __launch_bounds__(256) limb_kernel(LossArgs a) {
     __shared__ float s_red[4];
@@ -364,6 +425,7 @@ int fill(LossArgs& a, const ppn_loss_cfg* cfg, int batch) {
         return ppn::fail(PPN_E_INVALID, "bad loss geometry");
     a.B = batch; a.K = cfg->K; a.E = cfg->E; a.S = cfg->sH * cfg->sW; a.H = cfg->H; a.W = cfg->W;
     a.C = 6 * cfg->K + cfg->E * a.S; a.inW = cfg->inW; a.inH = cfg->inH;
+    a.Cg = a.C;
     const long long n_unary = (long long)batch * a.K * a.H * a.W;
     a.nblk_unary = (int)((n_unary + 255) / 256);
     a.nblk_limb = 2048;
@@ -513,6 +575,52 @@ extern "C" int ppn_loss_limb_dual_nhwc(const ppn_loss_cfg* cfg, const float* hea
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (dtype == PPN_F32) hipLaunchKernelGGL(limb_dual_nhwc_kernel<float>, grid, dim3(256), 0, st, a, tz, c4, cpad, (float*)zb, (float*)tzb, zsum);
     else hipLaunchKernelGGL(limb_dual_nhwc_kernel<__bf16>, grid, dim3(256), 0, st, a, tz, c4, cpad, (__bf16*)zb, (__bf16*)tzb, zsum);
+    PPN_LAUNCH_CHECK();
+    return PPN_OK;
+}
+
+// ppn_loss_fwd_bwd_dev + ppn_head_grad in one: the five losses, and instead of d loss / d head in the head layout the
+// gradient w.r.t. conv3's LOGITS in the layout its backward reads -- dz `dtype` [B][H*W][cpad] NHWC (channels >= C zero)
+// -- plus dbsum f32 [B][ceil(H*W/64)][cpad], per-block cell sums of dz (summed over the first two axes: d loss / d
+// conv3.bias).  grad_unary: f32 scratch [B][6K][H*W] (the unary channels' d loss / d head, compact).
+extern "C" size_t ppn_loss_dz_workspace_bytes(const ppn_loss_cfg* cfg, int32_t batch, int32_t cpad) {
+    LossArgs a;
+    if (fill(a, cfg, batch) || cpad < 64) return 0;
+    const size_t nb = (size_t)(cpad / 64) * ((a.H * a.W + 63) / 64) * batch;
+    return ((size_t)a.nblk_unary * 4 + nb) * sizeof(float);
+}
+
+extern "C" int ppn_loss_fwd_bwd_dz(const ppn_loss_cfg* cfg, const float* head, int32_t batch, const float* delta,
+                                   const float* weight, const float* weight_ij, const float* tx_half,
+                                   const float* ty_half, const float* tx, const float* ty, const float* tw,
+                                   const float* th, const float* te, const float* coeff_dev, float coeff_div,
+                                   float* losses, float* grad_unary, int32_t dtype, int32_t cpad, void* dz,
+                                   float* dbsum, void* workspace, void* stream) {
+    LossArgs a;
+    if (int rc = fill(a, cfg, batch)) return rc;
+    if (!head || !delta || !weight || !weight_ij || !tx_half || !ty_half || !tx || !ty || !tw || !th || !te ||
+        !coeff_dev || !losses || !grad_unary || !dz || !dbsum || !workspace)
+        return ppn::fail(PPN_E_INVALID, "ppn_loss_fwd_bwd_dz: NULL pointer");
+    if (!(coeff_div != 0.f)) return ppn::fail(PPN_E_INVALID, "ppn_loss_fwd_bwd_dz: coeff_div");
+    if (cpad % 64 || cpad < a.C) return ppn::fail(PPN_E_INVALID, "ppn_loss_fwd_bwd_dz: cpad %d for %d channels", cpad, a.C);
+    if (dtype != PPN_F32 && dtype != PPN_BF16) return ppn::fail(PPN_E_INVALID, "ppn_loss_fwd_bwd_dz: bad dtype %d", dtype);
+    if (a.E < 1) return ppn::fail(PPN_E_UNSUPPORTED, "ppn_loss_fwd_bwd_dz: needs limb channels");
+    a.head = head; a.delta = delta; a.weight = weight; a.weight_ij = weight_ij; a.tx_half = tx_half; a.ty_half = ty_half;
+    a.tx = tx; a.ty = ty; a.tw = tw; a.th = th; a.te = te;
+    a.grad = grad_unary; a.Cg = 6 * a.K;
+    a.partial = static_cast<float*>(workspace); a.losses = losses;
+    for (int i = 0; i < 5; ++i) a.coeff[i] = 0.f;
+    a.coeff_dev = coeff_dev; a.coeff_div = coeff_div;
+    const int HW = a.H * a.W;
+    const dim3 grid(cpad / 64, (HW + 63) / 64, batch);
+    a.nblk_limb = (int)(grid.x * grid.y * grid.z);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(unary_kernel, dim3(a.nblk_unary), dim3(256), 0, st, a);
+    PPN_LAUNCH_CHECK();
+    if (dtype == PPN_F32) hipLaunchKernelGGL(limb_loss_dz_kernel<float>, grid, dim3(256), 0, st, a, grad_unary, cpad, (float*)dz, dbsum);
+    else hipLaunchKernelGGL(limb_loss_dz_kernel<__bf16>, grid, dim3(256), 0, st, a, grad_unary, cpad, (__bf16*)dz, dbsum);
+    PPN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, st, a);
     PPN_LAUNCH_CHECK();
     return PPN_OK;
 }

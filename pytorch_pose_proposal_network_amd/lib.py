@@ -84,6 +84,10 @@ _SIGNATURES = {
     "ppn_loss_workspace_bytes": (C.c_size_t, [C.POINTER(LossCfg), C.c_int32]),
     "ppn_loss_fwd_bwd": (C.c_int, [C.POINTER(LossCfg), C.c_void_p, C.c_int32] + [C.c_void_p] * 10 +
                          [C.POINTER(C.c_float), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ppn_loss_dz_workspace_bytes": (C.c_size_t, [C.POINTER(LossCfg), C.c_int32, C.c_int32]),
+    "ppn_loss_fwd_bwd_dz": (C.c_int, [C.POINTER(LossCfg), C.c_void_p, C.c_int32] + [C.c_void_p] * 10 +
+                            [C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                             C.c_void_p, C.c_void_p]),
     "ppn_loss_fwd_bwd_dev": (C.c_int, [C.POINTER(LossCfg), C.c_void_p, C.c_int32] + [C.c_void_p] * 10 +
                              [C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ppn_conv_tiling": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32),

@@ -146,6 +146,44 @@ class PPNLoss:
                                   zbar.data_ptr(), tzbar.data_ptr(), L.current_stream_ptr()), "ppn_loss_dual")
         return zbar, tzbar
 
+    def forward_backward_dz(self, feature_map: torch.Tensor, targets: Dict[str, torch.Tensor], coeff_dev, dtype: torch.dtype):
+        """Losses + the gradient w.r.t. conv3's logits in NHWC (ppn_loss_fwd_bwd_dz): -> (losses f32[5], dz `dtype`
+        [B,H,W,cpad], dbsum f32 [B*ceil(HW/64), cpad] whose column sums are d loss / d conv3.bias).  Equals
+        forward_backward(coeff_dev=...) followed by ppn_head_grad, without the f32 head-layout gradient."""
+        lib = self._lib = self._lib or L.load()
+        c = self._cfg
+        B = feature_map.shape[0]
+        C_ = 6 * c.K + c.E * c.sH * c.sW
+        feature_map = self._check("feature_map", feature_map, (B, C_, c.H, c.W))
+        t = {}
+        for k in TARGET_KEYS:
+            shape = (B, c.E, c.sH, c.sW, c.H, c.W) if k in ("weight_ij", "te") else (B, c.K, c.H, c.W)
+            t[k] = self._check(k, targets[k], shape)
+        cw, div = coeff_dev
+        if not (cw.is_cuda and cw.dtype == torch.float32 and cw.numel() == 5 and cw.is_contiguous()):
+            raise ValueError("coeff_dev[0] must be a contiguous float32 CUDA tensor of 5 elements")
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("dtype must be float32 or bfloat16")
+        dev = feature_map.device
+        cpad = (C_ + 63) // 64 * 64
+        key = ("dz", B, cpad)
+        ws = self._ws.get(key)
+        if ws is None or ws.device != dev:
+            n = lib.ppn_loss_dz_workspace_bytes(C.byref(c), B, cpad)
+            ws = self._ws[key] = torch.empty(max(n, 16) // 4, dtype=torch.float32, device=dev)
+        losses = torch.empty(5, dtype=torch.float32, device=dev)
+        gu = torch.empty(B, 6 * c.K, c.H, c.W, dtype=torch.float32, device=dev)
+        dz = torch.empty(B, c.H, c.W, cpad, dtype=dtype, device=dev)
+        dbsum = torch.empty(B * ((c.H * c.W + 63) // 64), cpad, dtype=torch.float32, device=dev)
+        L.check(lib.ppn_loss_fwd_bwd_dz(C.byref(c), feature_map.data_ptr(), B, t["delta"].data_ptr(),
+                                        t["weight"].data_ptr(), t["weight_ij"].data_ptr(), t["tx_half"].data_ptr(),
+                                        t["ty_half"].data_ptr(), t["tx"].data_ptr(), t["ty"].data_ptr(),
+                                        t["tw"].data_ptr(), t["th"].data_ptr(), t["te"].data_ptr(), cw.data_ptr(),
+                                        float(div), losses.data_ptr(), gu.data_ptr(),
+                                        L.PPN_F32 if dtype == torch.float32 else L.PPN_BF16, cpad, dz.data_ptr(),
+                                        dbsum.data_ptr(), ws.data_ptr(), L.current_stream_ptr()), "ppn_loss_fwd_bwd_dz")
+        return losses, dz, dbsum
+
     def limb_dual_nhwc(self, feature_map: torch.Tensor, tz: torch.Tensor, targets: Dict[str, torch.Tensor], c4: float,
                        dtype: torch.dtype):
         """The limb stream of dual() -- coefficients (0,0,0,0,c4) -- with NHWC outputs: (zb, tzb `dtype` [B,H,W,cpad],

@@ -341,11 +341,15 @@ class PPNTrainer:
         used = Ch if channels_used is None else channels_used
         assert not keep or used == Ch
         cpad = (used + 63) // 64 * 64
-        dz = torch.empty(B, Ho, Wo, cpad, dtype=self.tdt, device=self.device)
-        dbias3 = self.G["conv3.bias"] if keep else None
-        L.check(lib.ppn_head_grad(self.compute_dtype, head.data_ptr(), grad_head.data_ptr(), B, Ch, Ho * Wo, used,
-                                  cpad, dz.data_ptr(), dbias3.data_ptr() if keep else None, L.current_stream_ptr()),
-                "ppn_head_grad")
+        if keep and so is not None and so.get("dz") is not None:
+            dz, dbsum = so["dz"]                                      # PPNLoss.forward_backward_dz did this step already
+            self.G["conv3.bias"].copy_(dbsum.sum(0)[:Ch])
+        else:
+            dz = torch.empty(B, Ho, Wo, cpad, dtype=self.tdt, device=self.device)
+            dbias3 = self.G["conv3.bias"] if keep else None
+            L.check(lib.ppn_head_grad(self.compute_dtype, head.data_ptr(), grad_head.data_ptr(), B, Ch, Ho * Wo, used,
+                                      cpad, dz.data_ptr(), dbias3.data_ptr() if keep else None, L.current_stream_ptr()),
+                    "ppn_head_grad")
         w3 = self.P["conv3.weight"]
         w3p = torch.zeros(cpad, w3.shape[1], 1, 1, dtype=torch.float32, device=self.device)
         w3p[:used] = w3[:used]
@@ -692,7 +696,14 @@ class PPNTrainer:
         if self.second_order:
             # the loss kernels read w_i / 5 from the device; the host copy (needed by the second-order tail only) is
             # fetched there, when the previous iteration is long over -- nothing here waits for the GPU
-            losses, ghead = self.criterion.forward_backward(head, targets, coeff_dev=(self.task.w, 5.0))
+            if self.tdt in (torch.float32, torch.bfloat16):
+                # ... and hand the gradient over already differentiated through the sigmoid, in the NHWC layout conv3's
+                # backward reads (no f32 head-layout gradient: 17 MB per image written once and read twice)
+                losses, dz_pre, dbsum = self.criterion.forward_backward_dz(head, targets, (self.task.w, 5.0), self.tdt)
+                ghead = None
+            else:
+                losses, ghead = self.criterion.forward_backward(head, targets, coeff_dev=(self.task.w, 5.0))
+                dz_pre = None
             coeff = None
         else:
             w = self.task.host_weights()                                 # 5 floats (coefficients of the loss kernel)
@@ -727,6 +738,8 @@ class PPNTrainer:
             so = dict(head=head, targets=targets, losses=losses, unary=grads,
                       coeff_fn=lambda: [v / 5.0 for v in self.task.host_weights()],
                       stream=pst if pst is not main else None, launch_probes=launch_probes)
+            if dz_pre is not None:
+                so["dz"] = (dz_pre, dbsum)
             exchange = T.BucketedAllReduce(self.grad, group=group)
             self.backward(ghead, exchange, so=so)
             scale = exchange.finish()

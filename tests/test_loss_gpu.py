@@ -116,3 +116,33 @@ def test_target_encoder_equals_reference_fixture(golden_dir):
     for k in targets.TARGET_KEYS:
         exp = np.stack([g[f"case{i}/{k}"] for i in range(n)])
         assert np.array_equal(got[k].cpu().numpy(), exp), k
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_loss_fwd_bwd_dz_equals_loss_then_head_grad(dtype):
+    """ppn_loss_fwd_bwd_dz (losses + gradient w.r.t. conv3's logits as NHWC + bias partial sums, one pass; what the
+    trainer uses) against the two steps it fuses: ppn_loss_fwd_bwd_dev and ppn_head_grad.  Same arithmetic per element, so
+    dz must be EQUAL; loss_limb and the bias gradient are summed in another order (1e-6 / 1e-5 relative)."""
+    import ctypes as C
+    from pytorch_pose_proposal_network_amd import loss, lib as L
+    B = 3
+    tg = {k: torch.from_numpy(v).cuda() for k, v in T.synthetic_batch(78, B).items()}
+    Cn = cfg.lastsize()
+    head = torch.from_numpy(prng.uniform(prng.stream_seed(6, 3), B * Cn * 576, 0.01, 0.99).reshape(B, Cn, 24, 24)).cuda()
+    w = torch.tensor([1.3, 0.8, 1.1, 0.7, 1.1], dtype=torch.float32).cuda()
+    crit = loss.PPNLoss()
+    l0, g0 = crit.forward_backward(head, tg, coeff_dev=(w, 5.0))
+    cpad = (Cn + 63) // 64 * 64
+    dz0 = torch.empty(B, 24, 24, cpad, dtype=dtype, device="cuda")
+    db0 = torch.empty(Cn, dtype=torch.float32, device="cuda")
+    code = L.PPN_F32 if dtype == torch.float32 else L.PPN_BF16
+    L.check(L.load().ppn_head_grad(code, head.data_ptr(), g0.data_ptr(), B, Cn, 576, Cn, cpad, dz0.data_ptr(),
+                                   db0.data_ptr(), L.current_stream_ptr()), "ppn_head_grad")
+    l1, dz1, dbsum = crit.forward_backward_dz(head, tg, (w, 5.0), dtype)
+    torch.cuda.synchronize()
+    assert torch.equal(dz0, dz1)
+    assert torch.equal(l0[:4], l1[:4])
+    assert abs(float(l0[4]) - float(l1[4])) <= 1e-6 * abs(float(l0[4]))
+    db1 = dbsum.sum(0)
+    assert float(db1[Cn:].abs().max()) == 0.0
+    assert float((db1[:Cn] - db0).abs().max()) <= 1e-5 * float(db0.abs().max())
