@@ -25,7 +25,7 @@ def wrap(obj, name, label=None):
     setattr(obj, name, g)
 
 
-wrap(tr, "forward"); wrap(tr.criterion, "forward_backward", "loss"); wrap(tr, "_second_order_tail", "so_tail")
+wrap(tr, "forward"); wrap(tr.criterion, "forward_backward", "loss"); wrap(tr.criterion, "forward_backward_dz", "loss+dz"); wrap(tr, "_second_order_tail", "so_tail")
 wrap(tr, "_limb_probe", "limb_probe(sync)"); wrap(tr, "backward"); wrap(tr.task, "step", "task.step"); wrap(tr.opt, "step", "adam")
 wrap(tr.task, "host_weights", "host_weights(sync)"); wrap(tr, "probe_grad")
 # GPU-side stamps (no profiler): end of the loss on the main stream, first / last probe launch on the probe stream,
@@ -38,6 +38,12 @@ def fb(*a, **k):
         e = torch.cuda.Event(enable_timing=True); e.record(); gpu.setdefault("loss_end", []).append(e)
     return r
 tr.criterion.forward_backward = fb
+_fbz = tr.criterion.forward_backward_dz
+def fbz(*a, **k):
+    r = _fbz(*a, **k)
+    e = torch.cuda.Event(enable_timing=True); e.record(); gpu.setdefault("loss_end", []).append(e)
+    return r
+tr.criterion.forward_backward_dz = fbz
 _ub = tr.criterion.unary_backward
 def ub(*a, **k):
     e = torch.cuda.Event(enable_timing=True); e.record(); gpu.setdefault("probe", []).append(e)

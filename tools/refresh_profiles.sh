@@ -27,8 +27,14 @@ if [ -f $R/tools/bin/libppn_clock.so ]; then
 fi
 if [ -f $R/tools/bin/libppn_clockhead.so ]; then (cd $R && python3 tools/clock_head.py) 2>&1 | grep -v amdgpu.ids > $O/head_clock.txt; fi
 if [ -f $R/tools/bin/libppn_clock64.so ]; then (cd $R && python3 tools/clock_conv64.py) 2>&1 | grep -v amdgpu.ids > $O/conv64_clock.txt; fi
+if [ -f $R/tools/bin/libppn_clockwg.so ]; then (cd $R && python3 tools/clock_wgrad.py) 2>&1 | grep -v amdgpu.ids > $O/wgrad_clock.txt; fi
+echo "[7b] weight-gradient micro-benchmark + its SQ / TCC counters (separate --pmc passes)"
+(cd $R && python3 tools/bench_wgrad.py) 2>&1 | grep -v amdgpu.ids > $O/wgrad_bench.txt
+(cd $R && tools/pmc_wgrad.sh $T/pmc_wgrad > /dev/null 2>&1 && python3 tools/pmc_summary.py gpurun_out/$T/pmc_wgrad wgrad_kernel > $O/wgrad_pmc.txt) || true
 echo "[8] full (second-order) training step: kernel stats"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/train_stats_so -o train -- python3 $R/tools/bench_train.py --steps 3 --warmup 1 > $O/train_profiled_so.txt 2>&1
+(cd $R && python3 tools/train_timeline.py $(find $O/train_stats_so -name "*kernel_trace.csv" | head -1)) > $O/train_timeline.txt 2>&1 || true
+(cd $R && python3 tools/host_timeline.py) 2>&1 | grep -v -i "warn\|amdgpu\|local_pass" > $O/train_host_timeline.txt || true
 python3 $R/tools/pmc_traffic_summary.py $O $O/pmc_traffic.json > $O/pmc_traffic.txt 2>&1 || true
 find $O -name "*.csv" -size +3M -delete
 echo done
