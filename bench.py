@@ -294,6 +294,33 @@ def extra_sections(args, dev, net, frames, dec):
             res[name] = {"us": round(med * 1e3, 1), "gbps": round(heads.nbytes / med / 1e6, 1),
                          "frac_of_hbm_peak": round(heads.nbytes / med / 1e6 / 8000.0, 4)}
         people = int(d(hs[0]).count.sum().item())
+        # the same decode with TWO batches in flight (two Decoders on two streams, batches alternate): the 15 us parse
+        # kernel of one batch -- one workgroup per image, latency-bound, it cannot start before its image's last arg-max
+        # workgroup -- runs under the arg-max launch of the next.  Throughput over 40 batches, not a per-batch latency.
+        sts = [torch.cuda.Stream(device=dev) for _ in range(2)]
+        ds = [d, decode.Decoder(B, device=dev)]
+        torch.cuda.synchronize(dev)
+        def run(n):
+            for i in range(n):
+                with torch.cuda.stream(sts[i & 1]):
+                    ds[i & 1](hs[i % 4])
+        for s_ in sts:
+            s_.wait_stream(torch.cuda.current_stream(dev))
+        run(8)
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for s_ in sts:
+            s_.wait_stream(torch.cuda.current_stream(dev))
+        run(40)
+        for s_ in sts:
+            torch.cuda.current_stream(dev).wait_stream(s_)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        per = e0.elapsed_time(e1) / 40
+        res["decode_two_in_flight"] = {"us_per_batch": round(per * 1e3, 1), "gbps": round(heads.nbytes / per / 1e6, 1),
+                                       "frac_of_hbm_peak": round(heads.nbytes / per / 1e6 / 8000.0, 4),
+                                       "what": "throughput with two batches in flight on two streams (40 batches)"}
         del hs
         return {"what": f"{B} planted-crowd heads f32 [7605,24,24] (seeds 7..{6 + B}): limb arg-max + NMS + limb parse, "
                         "median of 20 over 4 rotating copies", "algorithmic_bytes": int(heads.nbytes),
