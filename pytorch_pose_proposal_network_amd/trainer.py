@@ -86,6 +86,7 @@ class PPNTrainer:
         # (A high-priority probe stream was tried -- PPN_TRAIN_PROBE_PRIORITY=-1 -- because the main stream waits ~0.65 ms
         # for the four probe passes, which take 0.5 ms each beside the head backward and 0.23 ms alone: no measurable
         # change, 1.48 vs 1.52 ms from the end of the loss to the fourth probe; tools/host_timeline.py.)
+        self._stacked_probes = os.environ.get("PPN_TRAIN_STACKED_PROBES", "1") != "0"
         pri = int(os.environ.get("PPN_TRAIN_PROBE_PRIORITY", "0"))
         self._probe_stream = torch.cuda.Stream(device=self.device, priority=pri) if self._side is not None else None
         self._probe_scratch = None
@@ -624,6 +625,40 @@ class PPNTrainer:
         assert kind == "head"
         return self._head_backward(c, grad_head, probe_only=True, channels_used=channels_used)
 
+    def _stacked_unary_probe_grads(self, head, targets, scratch):
+        """[dL_i/dW for i < 4] (W = conv1.weight, the four unary losses): the four probe passes of probe_grad() with their
+        convolutions STACKED along the batch dimension -- one conv3 / conv2 / conv1x1_2 input-gradient launch for all four
+        (they are per-image operations) -- and only the BN backward passes (per-pass batch statistics) and the four weight
+        gradients run pass by pass: 43 launches instead of 68, and three well-filled convolution launches instead of twelve
+        at a quarter of the GPU.  Same arithmetic per element as probe_grad(): the results are bit-identical."""
+        kind, _, c = self._tape[-1]
+        assert kind == "head"
+        lib = L.load()
+        B, Ch, Ho, Wo = head.shape
+        k6 = 6 * cfg.K
+        cpad = (k6 + 63) // 64 * 64
+        dz4 = torch.empty(4 * B, Ho, Wo, cpad, dtype=self.tdt, device=self.device)
+        for i in range(4):
+            self.criterion.unary_backward(head, targets, [1.0 if j == i else 0.0 for j in range(4)], out=scratch)
+            L.check(lib.ppn_head_grad(self.compute_dtype, head.data_ptr(), scratch.data_ptr(), B, Ch, Ho * Wo, k6, cpad,
+                                      dz4[i * B:(i + 1) * B].data_ptr(), None, L.current_stream_ptr()), "ppn_head_grad")
+        w3 = self.P["conv3.weight"]
+        w3p = torch.zeros(cpad, w3.shape[1], 1, 1, dtype=torch.float32, device=self.device)
+        w3p[:k6] = w3[:k6]
+        dh3 = T.conv_dgrad(dz4, w3p, (Ho, Wo))
+        dc2 = torch.empty_like(dh3)
+        for i in range(4):
+            T.bn_train_backward(c["c2"], dh3[i * B:(i + 1) * B], self.P["bn2.weight"], self.P["bn2.bias"], c["s3"],
+                                act="lrelu", out=dc2[i * B:(i + 1) * B])
+        da3 = T.conv_dgrad(dc2, self.P["conv2.weight"], (Ho, Wo), 1, 1, 1)
+        dh2 = T.conv_dgrad(da3, self.P["conv1x1_2.weight"], (Ho, Wo))
+        grads = []
+        for i in range(4):
+            da2, _, _ = T.bn_train_backward(c["a2"], dh2[i * B:(i + 1) * B], self.P["bn0_2.weight"],
+                                            self.P["bn0_2.bias"], c["s2"], act="lrelu")
+            grads.append(T.conv_wgrad(c["h1"], da2, 3, 1, 1, 1))
+        return grads
+
     def _unary_probes(self, head, targets, coeff, scratch):
         """The four cheap probe passes: (gnorm[0:4] f32[4], sum_{i<4} coeff_i dL_i/dW).  Independent of backward()."""
         k6 = 6 * cfg.K
@@ -728,10 +763,15 @@ class PPNTrainer:
                 # main stream sat idle when they were enqueued first (rocprofv3 kernel trace, round 3).
                 with torch.cuda.stream(pst):
                     pst.wait_event(ev)
-                    for i in range(4):
-                        self.criterion.unary_backward(head, targets, [1.0 if j == i else 0.0 for j in range(4)],
-                                                      out=self._probe_scratch)
-                        gi = self.probe_grad(self._probe_scratch, channels_used=6 * cfg.K)
+                    if self._stacked_probes:
+                        gs = self._stacked_unary_probe_grads(head, targets, self._probe_scratch)
+                    else:
+                        gs = []
+                        for i in range(4):
+                            self.criterion.unary_backward(head, targets, [1.0 if j == i else 0.0 for j in range(4)],
+                                                          out=self._probe_scratch)
+                            gs.append(self.probe_grad(self._probe_scratch, channels_used=6 * cfg.K))
+                    for gi in gs:
                         gi.record_stream(main)
                         grads.append(gi)
 

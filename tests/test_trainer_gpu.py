@@ -550,3 +550,27 @@ def test_batch32_step_is_assembled_from_its_halves():
     assert torch.allclose(l32, (parts[0][0] + parts[1][0]) / 2, rtol=1e-5), (l32, parts)
     gcat = torch.cat([parts[0][1], parts[1][1]]) / 2
     assert torch.allclose(g32, gcat, rtol=1e-5, atol=1e-9), float((g32 - gcat).abs().max())
+
+
+@pytest.mark.parametrize("dtype_code", ["f32", "bf16"])
+def test_stacked_probe_grads_equal_the_four_probe_passes(dtype_code):
+    """PPNTrainer._stacked_unary_probe_grads (the four GradNorm probe passes with their convolutions stacked along the
+    batch dimension; what train_step runs) against probe_grad() pass by pass: bit-identical gradients."""
+    from pytorch_pose_proposal_network_amd import lib as L, synth, prng, targets, config as cfg
+    from pytorch_pose_proposal_network_amd.trainer import PPNTrainer
+    dev = torch.device("cuda")
+    size, B = 96, 3
+    dt = L.PPN_F32 if dtype_code == "f32" else L.PPN_BF16
+    tr = PPNTrainer("drn_d_22", synth.make_state_dict("drn_d_22", 5), compute_dtype=dt, insize=(size, size))
+    x = torch.from_numpy(synth.normalized_frames(prng.u8_frames(8, B, (size, size)))).to(dev)
+    tg = targets.synthetic_targets(13, B, (size, size), device=dev)
+    head = tr.forward(x)
+    scratch = torch.empty_like(head)
+    ref = []
+    for i in range(4):
+        tr.criterion.unary_backward(head, tg, [1.0 if j == i else 0.0 for j in range(4)], out=scratch)
+        ref.append(tr.probe_grad(scratch, channels_used=6 * cfg.K).clone())
+    got = tr._stacked_unary_probe_grads(head, tg, scratch)
+    torch.cuda.synchronize()
+    for a, b in zip(got, ref):
+        assert float(b.abs().max()) > 0 and torch.equal(a, b)
