@@ -21,7 +21,10 @@ using namespace ppnconv;
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
-constexpr int TH = 8, TW = 64, kThreads = 256;
+constexpr int TW = 64, kThreads = 256;
+// output rows per tile: 8, except the stride-2 layer (its 17 x 129 x 16-channel input tile alone is 70 KB: 4 rows -> 53 KB
+// of LDS in all, three workgroups per CU hide each other's staging instead of one)
+template <int S> constexpr int tile_rows() { return S == 2 ? 4 : 8; }
 
 struct SwArgs {
     const __bf16* x;      // NHWC [B][H][W][CIP]
@@ -36,7 +39,8 @@ __device__ __forceinline__ s16x4 tr_read(const char* p) {
 }
 
 template <int CO, int CIP, int KS, int S>
-__global__ void __launch_bounds__(kThreads, 1) stem_wgrad_kernel(SwArgs a) {
+__global__ void __launch_bounds__(kThreads, 2) stem_wgrad_kernel(SwArgs a) {
+    constexpr int TH = tile_rows<S>();
     constexpr int PAD = KS / 2;
     constexpr int XH = (TH - 1) * S + KS, XW = (TW - 1) * S + KS;     // x tile incl. halo
     constexpr int XPB = CIP * 2, YPB = CO * 2;                         // bytes per pixel
@@ -120,26 +124,32 @@ __global__ void __launch_bounds__(kThreads, 1) stem_wgrad_kernel(SwArgs a) {
                 }
         }
     }
-    // ---- fold the 4 waves through LDS, write this workgroup's partial [co][ci][tap] ------------------------------------
-    __syncthreads();
-    float* red = reinterpret_cast<float*>(smem);                       // [4][NT][CO][CIP]
-    if (li < CIP) {
+    // ---- fold the 4 waves through LDS, one filter ROW of taps at a time (a [4][NT][CO][CIP] buffer was 100 KB for the 7x7
+    // layer and alone held the kernel to one workgroup per CU; a row is <= 14 KB), write this workgroup's partial
+    // [co][ci][tap].  The sum runs over the waves in the order 0, 1, 2, 3 as before: same bits.
+    constexpr int NOUT = CO * CIP * NT, ROW = KS * CO * CIP;
+    float* red = reinterpret_cast<float*>(smem);                       // [4][KS][CO][CIP]
+    float* out = a.partial + (size_t)blockIdx.x * NOUT;
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+    for (int dy = 0; dy < KS; ++dy) {
+        __syncthreads();
+        if (li < CIP) {
 #pragma unroll
-            for (int c = 0; c < NCB; ++c)
+            for (int dx = 0; dx < KS; ++dx)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    red[((wave * NT + t) * CO + c * 16 + 4 * g + r) * CIP + li] = acc[t][c][r];
-    }
-    __syncthreads();
-    float* out = a.partial + (size_t)blockIdx.x * CO * CIP * NT;
-    for (int o = tid; o < CO * CIP * NT; o += kThreads) {
-        const int t = o % NT, ci = (o / NT) % CIP, co = o / (NT * CIP);
-        float s = 0.f;
+                for (int c = 0; c < NCB; ++c)
 #pragma unroll
-        for (int w = 0; w < 4; ++w) s += red[((w * NT + t) * CO + co) * CIP + ci];
-        out[o] = s;
+                    for (int r = 0; r < 4; ++r)
+                        red[((wave * KS + dx) * CO + c * 16 + 4 * g + r) * CIP + li] = acc[dy * KS + dx][c][r];
+        }
+        __syncthreads();
+        for (int o = tid; o < ROW; o += kThreads) {
+            const int dx = o % KS, ci = (o / KS) % CIP, co = o / (KS * CIP);
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) v += red[((w * KS + dx) * CO + co) * CIP + ci];
+            out[(co * CIP + ci) * NT + dy * KS + dx] = v;
+        }
     }
 }
 
@@ -163,9 +173,10 @@ __global__ void __launch_bounds__(256) stem_wgrad_fold_kernel(const float* __res
 
 template <int CO, int CIP, int KS, int S>
 constexpr int lds_bytes() {
+    constexpr int TH = tile_rows<S>();
     constexpr int XH = (TH - 1) * S + KS, XW = (TW - 1) * S + KS;
     constexpr int tiles = XH * XW * CIP * 2 + TH * TW * CO * 2 + 16;
-    constexpr int red = 4 * KS * KS * CO * CIP * 4;
+    constexpr int red = 4 * KS * CO * CIP * 4;
     return tiles > red ? tiles : red;
 }
 
@@ -196,9 +207,10 @@ bool stem_wgrad_supported(const ppn_wgrad_desc* d) {
 }
 
 static int stem_wgrad_grid(const ppn_wgrad_desc* d) {
+    const int TH = d->stride == 2 ? tile_rows<2>() : tile_rows<1>();
     const long long tiles = (long long)d->batch * ((d->out_h + TH - 1) / TH) * ((d->out_w + TW - 1) / TW);
-    // persistent workgroups: four per CU for the 3x3 layers (37-103 KB of LDS: two to four co-reside and hide each
-    // other's staging latency; 152 -> 124 us on layer1), two for the 7x7 layer (100 KB of LDS: one resident)
+    // persistent workgroups: four per CU for the 3x3 layers (37-53 KB of LDS: three or four co-reside and hide each
+    // other's staging latency; 152 -> 124 us on layer1), two for the 7x7 layer (32 KB of LDS, 256 VGPRs: two resident)
     const long long cap = d->ksize == 7 ? 512 : 1024;
     return (int)(tiles < cap ? tiles : cap);
 }
@@ -214,6 +226,7 @@ int stem_wgrad_launch(const ppn_wgrad_desc* d, hipStream_t st) {
     a.partial = (float*)d->workspace;
     a.B = d->batch; a.H = d->in_h; a.W = d->in_w; a.Ho = d->out_h; a.Wo = d->out_w;
     a.tiles_x = (d->out_w + TW - 1) / TW;
+    const int TH = d->stride == 2 ? tile_rows<2>() : tile_rows<1>();
     a.tiles_y = (d->out_h + TH - 1) / TH;
     a.ntiles = a.tiles_x * a.tiles_y * d->batch;
     const int nwg = stem_wgrad_grid(d);
