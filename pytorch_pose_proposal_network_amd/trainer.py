@@ -87,6 +87,7 @@ class PPNTrainer:
         # for the four probe passes, which take 0.5 ms each beside the head backward and 0.23 ms alone: no measurable
         # change, 1.48 vs 1.52 ms from the end of the loss to the fourth probe; tools/host_timeline.py.)
         self._stacked_probes = os.environ.get("PPN_TRAIN_STACKED_PROBES", "1") != "0"
+        self._tail_wgrad_side = os.environ.get("PPN_TRAIN_TAIL_WGRAD_SIDE", "1") != "0"
         pri = int(os.environ.get("PPN_TRAIN_PROBE_PRIORITY", "0"))
         self._probe_stream = torch.cuda.Stream(device=self.device, priority=pri) if self._side is not None else None
         self._probe_scratch = None
@@ -238,6 +239,12 @@ class PPNTrainer:
         with torch.cuda.stream(self._side):
             self._side.wait_event(ev)
             fn()
+
+    def _tail_side(self, fn, *tensors):
+        """_on_side for the second-order tail's weight gradients (PPN_TRAIN_TAIL_WGRAD_SIDE=0: on the main stream, for A/B)."""
+        if self._tail_wgrad_side:
+            return self._on_side(fn, *tensors)
+        return fn()
 
     def _wgrad(self, name, x, dy, k, stride=1, dil=1, pad=0):
         self._on_side(lambda: T.conv_wgrad(x, dy, k, stride, dil, pad, out=self.G[name]), x, dy)
@@ -497,9 +504,13 @@ class PPNTrainer:
             w3p = torch.zeros(cpad, w3u.shape[1], 1, 1, dtype=torch.float32, device=self.device)
             w3p[:used] = w3u
             zsum = zb if m == 1 else zb.view(m, B, Ho, Wo, cpad).sum(0)          # (m == 1: a 280 MB no-op reduction)
-            dw3 = T.conv_wgrad(c["h3"], zsum, 1)                                  # primal stream: same h3 for all
-            T.conv_wgrad(th3, tzb, 1, out=dw3, accumulate=True)                  # tangent stream: stacked batch
-            Gd["conv3.weight"][:used] += dw3[:used]
+            # Weight gradients are leaves here too: on the side stream (idle during the tail) instead of ~0.9 ms of the
+            # main stream; they accumulate into gradients the side stream wrote, so the order is the stream's own.
+            def wg3(zsum=zsum, th3=th3, tzb=tzb, used=used):
+                dw3 = T.conv_wgrad(c["h3"], zsum, 1)                              # primal stream: same h3 for all
+                T.conv_wgrad(th3, tzb, 1, out=dw3, accumulate=True)              # tangent stream: stacked batch
+                Gd["conv3.weight"][:used] += dw3[:used]
+            self._tail_side(wg3, c["h3"], zsum, th3, tzb)
             Gd["conv3.bias"][:used] += zbias
             H3bar[js[0] * B:(js[-1] + 1) * B] = T.conv_dgrad(zb, w3p, (Ho, Wo))
             TH3bar[js[0] * B:(js[-1] + 1) * B] = T.conv_dgrad(tzb, w3p, (Ho, Wo))
@@ -513,13 +524,17 @@ class PPNTrainer:
             Gd["bn2.bias"] += db
         c2sum = ssum(C2bar)
         Gd["conv2.bias"] += c2sum.float().sum((0, 1, 2))
-        T.conv_wgrad(c["a3"], c2sum, 3, 1, 1, 1, out=Gd["conv2.weight"], accumulate=True)
-        T.conv_wgrad(TA3, TC2bar, 3, 1, 1, 1, out=Gd["conv2.weight"], accumulate=True)
+        def wg2(c2sum=c2sum, TC2bar=TC2bar):
+            T.conv_wgrad(c["a3"], c2sum, 3, 1, 1, 1, out=Gd["conv2.weight"], accumulate=True)
+            T.conv_wgrad(TA3, TC2bar, 3, 1, 1, 1, out=Gd["conv2.weight"], accumulate=True)
+        self._tail_side(wg2, c["a3"], c2sum, TA3, TC2bar)
         both = T.conv_dgrad(both, P["conv2.weight"], (Ho, Wo), 1, 1, 1)
         A3bar, TA3bar = both[:n * B], both[n * B:]
         a3sum = ssum(A3bar)
-        T.conv_wgrad(c["h2"], a3sum, 1, out=Gd["conv1x1_2.weight"], accumulate=True)
-        T.conv_wgrad(TH2, TA3bar, 1, out=Gd["conv1x1_2.weight"], accumulate=True)
+        def wg12(a3sum=a3sum, TA3bar=TA3bar):
+            T.conv_wgrad(c["h2"], a3sum, 1, out=Gd["conv1x1_2.weight"], accumulate=True)
+            T.conv_wgrad(TH2, TA3bar, 1, out=Gd["conv1x1_2.weight"], accumulate=True)
+        self._tail_side(wg12, c["h2"], a3sum, TH2, TA3bar)
         both = T.conv_dgrad(both, P["conv1x1_2.weight"], (Ho, Wo))
         H2bar, TH2bar = both[:n * B], both[n * B:]
         a2sum, h1_bar = None, None
@@ -531,7 +546,8 @@ class PPNTrainer:
             a2sum = x_bar if a2sum is None else a2sum + x_bar
             hb = T.conv_dgrad(u_bar, v, (Ho, Wo), 1, 1, 1)                        # through u = conv(h1, v_i)
             h1_bar = hb if h1_bar is None else h1_bar + hb
-        T.conv_wgrad(c["h1"], a2sum, 3, 1, 1, 1, out=Gd["conv1.weight"], accumulate=True)
+        self._tail_side(lambda: T.conv_wgrad(c["h1"], a2sum, 3, 1, 1, 1, out=Gd["conv1.weight"], accumulate=True),
+                        c["h1"], a2sum)
         h1_bar = h1_bar + T.conv_dgrad(a2sum, P["conv1.weight"], (Ho, Wo), 1, 1, 1)
         r_bar = a3sum
         return h1_bar, r_bar
