@@ -8,13 +8,20 @@
 // operands are fetched with gfx950's transposing LDS read ds_read_b64_tr_b16 (bf16) -- no shuffle, no second image.
 // The f32 parity mode uses v_mfma_f32_16x16x4_f32, whose operands are one scalar per lane (plain ds_read_b32).
 //
-//   workgroup tile (cout x cin, one tap): 256 x 256 with 8 waves (4 x 2, each 64 x 128) for >= 256-wide layers,
-//              128 x 128 with 4 waves (2 x 2, each 64 x 64) otherwise
-//   depth step 64 pixels (bf16) / 32 pixels (f32), 2 LDS stages (128 KB / 64 KB)
+//   workgroup tile (cout x cin, one tap): 256 x 256 with 8 waves (4 x 2, each 64 x 128) for >= 256-wide bf16 layers,
+//              128 x 128 with 4 waves (2 x 2, each 64 x 64) otherwise (and every f32 layer: 256 x 256, 8 waves, old loop)
+//   bf16 256 x 256: ping-pong loop -- the two wave groups (0-3 / 4-7, one wave of each per SIMD) run half a step out of
+//              phase, one reading fragments while the other issues MFMAs -- over a four-stage ring of 32-pixel steps
+//              (4 x 32 KB); bf16 128 x 128: 64-pixel steps, two stages, DMA issued between the MFMAs of the first substep;
+//              f32: 32-pixel steps, two stages
 //   LDS image: pixel rows of 256 or 512 bytes, 16-byte chunk c of row r at slot c ^ (((r&3)<<2) | ((r>>2)&3)) inside
 //              its 256-byte window, applied on the SOURCE side of the DMA (the DMA destination is lane-linear);
-//              conflict-free for the transposed reads
-//   split over pixels: grid.y slices; every slice writes its own f32 partial, a second launch folds them in a fixed
+//              conflict-free for the transposed reads (SQ_LDS_BANK_CONFLICT = 0)
+//   bf16 reads: inline asm (the compiler would drain every pending LDS-DMA in front of a `ds_read_tr` builtin);
+//   bf16 DMA offsets: dy rows linear, x rows from a per-workgroup table in LDS (built once from the two divisions and
+//              four bounds tests a row needs) -- see the comments at the loops
+//   work items: (pixel split, tile) pairs, the k-th contiguous eighth on XCD k (L2 locality)
+//   split over pixels: every split writes its own f32 partial, a second launch folds them in a fixed
 //              order (bitwise reproducible, no atomics) into the reference layout [cout][cin][k][k].
 //
 // Algorithmic work: 2*P*cout*cin*k*k flops; unique bytes: x + dy once each.
