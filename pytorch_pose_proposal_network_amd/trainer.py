@@ -384,7 +384,7 @@ class PPNTrainer:
         self._wgrad("conv1.weight", c["h1"], da2, 3, 1, 1, 1)
         dh1 = T.conv_dgrad(da2, self.P["conv1.weight"], (Ho, Wo), 1, 1, 1)
         skip = da3
-        if so is not None:
+        if so is not None and "head" in so:
             # GradNorm's Lgrad.backward(): the second-order adjoints at h1 and at the skip tensor join the first-order
             # ones here, so everything upstream is back-propagated once
             if so.get("launch_probes") is not None:
@@ -756,10 +756,16 @@ class PPNTrainer:
                 losses, ghead = self.criterion.forward_backward(head, targets, coeff_dev=(self.task.w, 5.0))
                 dz_pre = None
             coeff = None
+        elif self._probe_stream is not None and self.tdt in (torch.float32, torch.bfloat16):
+            # first-order step, same plumbing: device-side coefficients, gradient straight to NHWC; the host values of
+            # the task weights are read after the backward, where nothing waits for them
+            losses, dz_pre, dbsum = self.criterion.forward_backward_dz(head, targets, (self.task.w, 5.0), self.tdt)
+            ghead, coeff = None, None
         else:
             w = self.task.host_weights()                                 # 5 floats (coefficients of the loss kernel)
             losses, ghead = self.criterion.forward_backward(head, targets, coeff=[v / 5.0 for v in w])
             coeff = [v / 5.0 for v in w]
+            dz_pre = None
         if self.base is None:
             self._init_base(losses, group)
         unary = None
@@ -800,6 +806,35 @@ class PPNTrainer:
             self.backward(ghead, exchange, so=so)
             scale = exchange.finish()
             gn = so["gnorm"]
+        elif coeff is None:
+            # first-order step on the fused plumbing: stacked probe passes beside the backward (they need the head only),
+            # then ONE pass over the five probe-sized tensors for the limb probe gradient and all norms
+            main = torch.cuda.current_stream(self.device)
+            if self._probe_scratch is None or self._probe_scratch.shape != head.shape:
+                self._probe_scratch = torch.empty_like(head)
+            with torch.cuda.stream(self._probe_stream):
+                self._probe_stream.wait_event(ev_head)
+                gs = self._stacked_unary_probe_grads(head, targets, self._probe_scratch)
+            exchange = T.BucketedAllReduce(self.grad, group=group)
+            self.backward(None, exchange, so=dict(dz=(dz_pre, dbsum)))
+            scale = exchange.finish()
+            main.wait_stream(self._probe_stream)
+            for t in gs:
+                t.record_stream(main)
+            coeff = [v / 5.0 for v in self.task.host_weights()]
+            local = self._conv1_local if self._conv1_local is not None else self.G["conv1.weight"]
+            trusted = coeff[4] > 1e-3 * max(coeff)
+            if trusted:
+                gw4, st = T.probe_stats([g.contiguous() for g in gs], local.contiguous(), coeff)
+                if self.compute_dtype != L.PPN_F32:
+                    n_rest, n_tot = st[5:7].tolist()                    # the trust test of _limb_probe
+                    trusted = n_rest > (16.0 * 2.0 ** -8) ** 2 * n_tot
+            if trusted:
+                gn = torch.sqrt(st[:5])
+            else:
+                _, g4 = self.criterion.forward_backward(head, targets, coeff=[0.0, 0.0, 0.0, 0.0, 1.0])
+                gn = torch.sqrt(torch.cat([T.sumsq(g.contiguous().view(-1)) for g in gs] +
+                                          [T.sumsq(self.probe_grad(g4).contiguous().view(-1))]))
         else:
             if self._probe_stream is not None:
                 # the four unary probe passes are small launches that depend only on the forward: they run on their
