@@ -536,6 +536,9 @@ typedef struct ppn_wgrad_desc {
     uint64_t workspace_bytes;     /* >= ppn_conv_wgrad_workspace_bytes(desc) */
 } ppn_wgrad_desc;
 
+/* The workspace holds one f32 partial [k*k][cout][cin] per pixel split.  bf16: a split covers at most 8 096 (>= 256-wide
+ * layers) or 4 032 (narrower ones) output pixels -- its x-row offset table lives in LDS -- so the workspace grows with the
+ * pixel count: 132 MB for a 512 -> 512 3x3 layer at 32 x 48 x 48 pixels (14 splits), ~75 splits per 600 k pixels. */
 size_t ppn_conv_wgrad_workspace_bytes(const ppn_wgrad_desc* d);
 int ppn_conv_wgrad(const ppn_wgrad_desc* d, void* stream);
 
