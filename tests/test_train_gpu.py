@@ -211,6 +211,8 @@ FULL_WGRAD = [
     (32, 512, 512, 24, 3, 1, 1, 1),
     (8, 512, 1312, 24, 1, 1, 1, 0),
     (3, 264, 320, 37, 3, 1, 2, 2),       # ragged everything: channel tiles, 4107 pixels (not a multiple of 32), odd width
+    (32, 64, 64, 96, 3, 1, 1, 1),        # layer3: the 4-wave kernel with its split capped by the LDS offset table (74 splits)
+    (32, 512, 512, 128, 1, 1, 1, 0),     # 524 k pixels: the 8-wave kernel's split cap binds too (65 splits instead of 64)
 ]
 
 
