@@ -574,3 +574,30 @@ def test_stacked_probe_grads_equal_the_four_probe_passes(dtype_code):
     torch.cuda.synchronize()
     for a, b in zip(got, ref):
         assert float(b.abs().max()) > 0 and torch.equal(a, b)
+
+
+def test_train_step_bitwise_reproducible_at_full_size():
+    """Two trainers from one checkpoint, six full-size steps on one batch: every loss, task weight and parameter bitwise
+    equal.  Three streams, the ping-pong weight-gradient kernel and the fixed-order folds leave no room for run-to-run
+    differences; a missing event or barrier would (tools/soak_train.py runs the same screen for longer)."""
+    from pytorch_pose_proposal_network_amd import lib as L, synth, prng, targets
+    from pytorch_pose_proposal_network_amd.trainer import PPNTrainer
+    dev = torch.device("cuda")
+    size, B = 384, 32
+    x = torch.from_numpy(synth.normalized_frames(prng.u8_frames(21, B, (size, size)))).to(dev)
+    tg = targets.synthetic_targets(22, B, (size, size), device=dev)
+    runs = []
+    for _ in range(2):
+        tr = PPNTrainer("drn_d_22", synth.make_state_dict("drn_d_22", 7), compute_dtype=L.PPN_BF16, insize=(size, size),
+                        lr=2e-4)
+        hist = []
+        for _it in range(6):
+            losses, w = tr.train_step(x, tg)
+            hist.append(torch.cat([losses, w]).clone())
+        torch.cuda.synchronize()
+        runs.append((torch.stack(hist).cpu(), tr.flat.clone().cpu()))
+        del tr
+    (h0, p0), (h1, p1) = runs
+    assert torch.isfinite(h0).all() and torch.isfinite(p0).all()
+    assert torch.equal(h0, h1) and torch.equal(p0, p1)
+    assert float(h0[-1, 4]) < float(h0[0, 4])                      # and it trains: the limb loss falls
