@@ -448,6 +448,32 @@ def extra_sections(args, dev, net, frames, dec):
             res["f16_agreement_tuned_checkpoint"] = _agreement(n16, "e2e_tuned_d22_384")
         return res
 
+    def tile_policy_1():
+        # the same bf16 path with the conv tiles chosen by efficiency alone (ppn_set_conv_tile_policy(1): 256x256 for every
+        # >= 256-wide layer).  Not the headline configuration: the 256x256 tile makes 576 workgroups = 2.25 rounds on the
+        # 48x48 layers, a last round only the OTHER lanes fill -- measured one launch in flight (what `roofline` reports) it
+        # is slower than 192x256 at three whole rounds.  Reported beside it as what a throughput-only deployment gets.
+        lanes = max(1, args.lanes)
+        if lanes < 2:
+            return {"skipped": "needs several lanes"}
+        n1 = model.PoseProposalNet(getattr(drn, args.arch)(), insize=(S, S), outsize=(S // 16, S // 16),
+                                   compute_dtype="bfloat16").cuda(dev)
+        n1.load_state_dict(net.state_dict())
+        pipe1 = rt.MultiLaneInference(n1, B, (S, S), device=dev, lanes=lanes, tile_policy=1)
+        try:
+            for _ in range(3 * lanes):
+                pipe1.submit(frames)
+            dts = sorted(_time_steps(lambda: pipe1.submit(frames), dev, 20, warmup=3) for _ in range(3))
+            last = pipe1.submit(frames)
+            pipe1.flush()
+            people = int(last.count.sum().item())
+        finally:
+            pipe1.close()
+        return {"what": "bf16, conv tiles by efficiency alone (--tile-policy 1), same lanes; median of three 20-step windows",
+                "images_per_sec": round(B / dts[1], 1), "ms_per_step": round(dts[1] * 1e3, 3), "lanes": lanes,
+                "people_last_step": people}
+
+    section("tile_policy_1", tile_policy_1)
     section("bf16_agreement", bf16_agreement)
     section("ap_vs_reference", ap_vs_reference)
     section("f16_mode", f16_mode)
