@@ -355,12 +355,60 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, in_hw, stride: int = 1, dilati
     cout, cin, k, _ = w.shape
     eff = dilation * (k - 1) + 1
     B, Ho, Wo, _ = dy.shape
+    # measured at batch 32 (tools/bench_dgrad_s2.py, bit-identical results): 1x1 projections 119 -> 51 and 74 -> 37 us,
+    # layer2 (16 -> 32) 402 -> 359 us; the 3x3 layers with >= 32 input channels do not gain (181 -> 187, 106 -> 130 us:
+    # four short-K launches and four strided copies cost what the 2.25x fewer FLOPs save) and keep the zero-upsampled form
+    if (_S2_PARITY and stride == 2 and dilation == 1 and pad == k // 2 and (k == 1 or (k == 3 and cin <= 16)) and
+            Ho == (H + 2 * pad - k) // 2 + 1 and Wo == (W + 2 * pad - k) // 2 + 1):
+        return _dgrad_stride2(dy, w, H, W, add)
     hup, wup = H + 2 * pad - eff + 1, W + 2 * pad - eff + 1
     if stride > 1 or (hup, wup) != (Ho, Wo):
         up = torch.zeros(B, hup, wup, cout, dtype=dy.dtype, device=dy.device)
         up[:, ::stride, ::stride][:, :Ho, :Wo] = dy
         dy = up
     return conv2d_nhwc(dy, w, 1, dilation, eff - 1 - pad, add=add, dgrad_of=True)
+
+
+import os as _os
+_S2_PARITY = _os.environ.get("PPN_DGRAD_S2_PARITY", "1") != "0"
+_S2_IDX = {}
+
+
+def _dgrad_stride2(dy: torch.Tensor, w: torch.Tensor, H: int, W: int, add: Optional[torch.Tensor]) -> torch.Tensor:
+    """Input gradient of a stride-2 convolution (k = 3 pad 1, or k = 1) WITHOUT the zero-upsampled dy: the input pixels of
+    each parity (i mod 2, j mod 2) only ever meet the taps of the matching parity, so dx splits into four stride-1
+    convolutions of dy itself with 2 x 2 kernels (k = 3:  dx[2j] = w[1] dy[j],  dx[2j+1] = w[2] dy[j] + w[0] dy[j+1]  per
+    axis; absent taps are zero) -- 16 tap-pixel products per 2 x 2 input pixels instead of 36, and no 4x larger zero-filled
+    tensor written, scattered into and read back (0.9 ms of the training step's main stream went into the five stride-2
+    input gradients of DRN-D-22 that way).  k = 1: dx[2j] = w^T dy[j], odd positions zero."""
+    B, Ho, Wo, cout = dy.shape
+    cin = w.shape[1]
+    k = w.shape[2]
+    dev = dy.device
+    if k == 1:
+        wt = w[:, :, 0, 0].t().contiguous().view(cin, cout, 1, 1)
+        o = conv2d_nhwc(dy, wt, 1, 1, 0)
+        dx = torch.zeros(B, H, W, cin, dtype=dy.dtype, device=dev)
+        dx[:, ::2, ::2] = o[:, :(H + 1) // 2, :(W + 1) // 2]
+    else:
+        idx = _S2_IDX.get(dev)
+        if idx is None:
+            # tap of the forward filter that kernel position u of parity p multiplies; 3 = the zero tap appended below
+            idx = _S2_IDX[dev] = torch.tensor([[3, 1], [2, 0]], dtype=torch.long, device=dev)
+        w4 = torch.nn.functional.pad(w.permute(1, 0, 2, 3), (0, 1, 0, 1))            # [cin, cout, 4, 4], index 3 = 0
+        wall = w4[:, :, idx[:, :, None, None], idx[None, None, :, :]]                # [cin, cout, py, uy, px, ux]
+        wall = wall.permute(2, 4, 0, 1, 3, 5).contiguous()                           # [py, px, cin, cout, uy, ux]
+        dx = torch.empty(B, H, W, cin, dtype=dy.dtype, device=dev)
+        for py in (0, 1):
+            for px in (0, 1):
+                ny, nx = (H - py + 1) // 2, (W - px + 1) // 2
+                if ny <= 0 or nx <= 0:
+                    continue
+                o = conv2d_nhwc(dy, wall[py, px], 1, 1, 1)                           # [B, Ho + 1, Wo + 1, cin]
+                dx[:, py::2, px::2] = o[:, py:py + ny, px:px + nx]
+    if add is not None:
+        dx += add
+    return dx
 
 
 def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, ksize: int, stride: int = 1, dilation: int = 1, pad: int = 0,

@@ -235,3 +235,35 @@ def test_conv_wgrad_fullsize_bf16_against_f32_kernel(case):
     assert torch.equal(a, b)
     tol = 3e-5 * (B * Ho * Ho) ** 0.5
     assert float((a - r).abs().max()) <= tol, (float((a - r).abs().max()), tol)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", [(2, 16, 32, 20, 3), (1, 64, 64, 11, 3), (2, 32, 64, 13, 1), (1, 64, 128, 12, 1),
+                                  (3, 32, 64, 7, 3)])
+def test_stride2_dgrad_by_parity_equals_zero_upsampled(dtype, case):
+    """train._dgrad_stride2 (four stride-1 sub-convolutions of dy with 2 x 2 kernels, one per input-pixel parity; k = 1: one
+    half-resolution 1 x 1) against the zero-upsampled transposed convolution it replaces and against autograd in f64;
+    even and odd input sizes."""
+    from pytorch_pose_proposal_network_amd import train as T
+    B, ci, co, H, k = case
+    g = torch.Generator().manual_seed(11)
+    pad = k // 2
+    Ho = (H + 2 * pad - k) // 2 + 1
+    dy = torch.randn(B, Ho, Ho, co, generator=g).to(dtype)
+    w = torch.randn(co, ci, k, k, generator=g) * 0.2
+    x = torch.zeros(B, ci, H, H, dtype=torch.float64, requires_grad=True)
+    wq = w.to(dtype).double() if dtype == torch.bfloat16 else w.double()
+    F.conv2d(x, wq, None, 2, pad).backward(dy.double().permute(0, 3, 1, 2))
+    dev = torch.device("cuda")
+    got = T._dgrad_stride2(dy.to(dev), w.to(dev), H, H, None)
+    old = T._S2_PARITY
+    T._S2_PARITY = False
+    try:
+        ref = T.conv_dgrad(dy.to(dev), w.to(dev), (H, H), 2, 1, pad)
+    finally:
+        T._S2_PARITY = old
+    torch.cuda.synchronize()
+    assert torch.equal(got, ref)
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    err = (got.cpu().double() - x.grad.permute(0, 2, 3, 1)).abs().max().item()
+    assert err <= tol * max(1.0, x.grad.abs().max().item()), err
