@@ -59,7 +59,8 @@ def pmc_traffic(kernel_name):
         table = json.load(open(path))
         for k, v in table.items():
             if frag in k:
-                return {"bytes_per_launch": v["hbm_bytes_per_launch"], "source": os.path.basename(path)}
+                return {"bytes_per_launch": v["hbm_bytes_per_launch"], "source": os.path.basename(path),
+                        "date": table.get("_date") or time.strftime("%Y-%m-%d", time.gmtime(os.path.getmtime(path)))}
     return None
 
 
@@ -138,7 +139,16 @@ def main_train(args):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            # the gradient buckets are exchanged on RCCL's own streams while the backward still runs: ask for
+            # high-priority ones, so that a bucket's ring kernel is dispatched ahead of queued conv workgroups
+            kw = {}
+            try:
+                opts = dist.ProcessGroupNCCL.Options()
+                opts.is_high_priority_stream = True
+                kw["pg_options"] = opts
+            except Exception:                                      # noqa: BLE001 -- an older binding: default streams
+                pass
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, **kw)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     _fail_hook(rank)
@@ -161,12 +171,13 @@ def main_train(args):
     t0 = time.perf_counter()
     for _ in range(args.steps):
         losses, w = tr.train_step(x, tg)
+    host_submit = time.perf_counter() - t0
     fence()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        t = torch.tensor([dt, host_submit], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt, host_submit = float(t[0].item()), float(t[1].item())
     if rank == 0:
         flops = 3 * A.conv_flops(A.build_program(args.arch), S, S) * B          # fwd + dgrad + wgrad, SURVEY 8d
         peak = BF16_DENSE_PEAK_TFLOPS if args.dtype == "bf16" else F32_MFMA_PEAK_TFLOPS
@@ -177,13 +188,16 @@ def main_train(args):
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "rccl_ranks": world if (dist is not None and backend == "nccl") else (1 if world == 1 else 0),
+            "host": {"submit_ms_per_step_max_over_ranks": round(host_submit / args.steps * 1e3, 4),
+                     "omp_num_threads": os.environ.get("OMP_NUM_THREADS"), "cpu_count": os.cpu_count()},
             "config": {"workload": f"{args.arch} PPN training step {args.dtype}, batch {B}/GPU synthetic {S}x{S} frames, "
                                    "targets of 1-4 synthetic people per frame encoded on the device "
                                    "(BASELINE configs[3] per-GPU shard; GradNorm "
                                    + ("without" if args.first_order else "with")
                                    + " the second-order term of main.py:759)",
                        "frames_per_gpu": B, "parallelism": f"minibatch sharded over {world} GPU(s), one all-reduce of "
-                                                           "the flat 128.5 MB gradient buffer + 20 B of task weights"},
+                                                           "the flat 128.5 MB gradient buffer in 32 MB buckets under the "
+                                                           "backward; the 5 task weights ride on the last bucket"},
             "roofline": {"bound": "mfma", "kernel": "whole step (3 x forward conv FLOPs / step time)",
                          "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                          "traffic": None},
@@ -327,22 +341,74 @@ def extra_sections(args, dev, net, frames, dec):
                 "people": people, **res}
 
     def d54():
+        # BASELINE configs[4]'s backbone end to end in every mode, with what each 16-bit mode costs in PEOPLE against the
+        # f32 pipeline of the same network (no reference-generated people fixture exists for D-54 at 384x384; the f32 head
+        # is pinned to the reference by tests/golden/forward_d54_384.npz)
         g = load_bn_stats("drn_d_54")
-        n54 = model.PoseProposalNet(drn.drn_d_54(), insize=(S, S), outsize=(S // 16, S // 16),
-                                    compute_dtype="bfloat16").cuda(dev)
-        n54.load_state_dict(synth.make_state_dict("drn_d_54", 0, bn_stats=g))
-        d54_ = decode.Decoder(B, (S // 16, S // 16), (S, S), device=dev)
+        sd54 = synth.make_state_dict("drn_d_54", 0, bn_stats=g)
+        fl = A.conv_flops(A.build_program("drn_d_54"), S, S) * B
+        res = {"what": f"DRN-D-54 (Bottleneck trunk) end to end, batch {B}, fused decode, one lane; people_vs_f32 = this "
+                       "mode's people on the benchmark frames against the f32 pipeline's (same root / reproduced exactly)"}
+        ref_people = None
+        for mode, key, steps in (("float32", "f32", 2), ("float16x3", "f16x3", 3), ("float16", "f16", 5), ("bfloat16", "bf16", 5)):
+            n54 = model.PoseProposalNet(drn.drn_d_54(), insize=(S, S), outsize=(S // 16, S // 16), compute_dtype=mode).cuda(dev)
+            n54.load_state_dict(sd54)
+            d54_ = decode.Decoder(B, (S // 16, S // 16), (S, S), device=dev)
+
+            def step():
+                u, k = n54.forward_u8(frames, fused_decode=True)
+                return d54_.decode_fused(u, k)
+            dt = _time_steps(step, dev, steps, warmup=2)
+            people = step().to_host()
+            people = [{k: (v.copy() if hasattr(v, "copy") else v) for k, v in r.items()} for r in people]
+            if ref_people is None:
+                ref_people = people
+            tot = np.zeros(5, np.int64)
+            for a_, b_ in zip(ref_people, people):
+                tot += np.array(decode.people_agreement(a_, b_))
+            peak = F32_MFMA_PEAK_TFLOPS if mode == "float32" else BF16_DENSE_PEAK_TFLOPS
+            res[key] = {"images_per_sec": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 3),
+                        "tflops": round(fl / dt / 1e12, 1),
+                        "frac_of_mfma_peak": round(fl / dt / 1e12 / peak, 4) if mode != "float16x3" else None,
+                        "people_vs_f32": {"f32_people": int(tot[0]), "reproduced_exactly": int(tot[1]),
+                                          "same_root": int(tot[2])},
+                        "task_equivalent": bool(mode in ("float32", "float16x3") or tot[1] >= 0.85 * tot[0])}
+            del n54, d54_
+            torch.cuda.empty_cache()
+        return res
+
+    def f16x3_mode():
+        # the tolerance-meeting mode above the exact-f32 MFMA rate: half-pair storage, three f16 MFMA
+        # products per operand pair, f32 accumulation (csrc/conv_big.hip X3); stem and the cin < 64 convs stay exact f32
+        nx = model.PoseProposalNet(getattr(drn, args.arch)(), insize=(S, S), outsize=(S // 16, S // 16),
+                                   compute_dtype="float16x3").cuda(dev)
+        nx.load_state_dict(net.state_dict())
+        dx = decode.Decoder(B, (S // 16, S // 16), (S, S), device=dev)
 
         def step():
-            u, k = n54.forward_u8(frames, fused_decode=True)
-            d54_.decode_fused(u, k)
-        dt = _time_steps(step, dev, 5, warmup=3)
-        fl = A.conv_flops(A.build_program("drn_d_54"), S, S) * B
-        return {"what": f"DRN-D-54 (Bottleneck trunk) end to end, bf16, batch {B}, fused decode, one lane (throughput only: on "
-                        "this random checkpoint bf16 D-54 finds other people than f32 D-54, tests/test_fullsize_gpu.py)",
-                "task_equivalent": False,
-                "images_per_sec": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 3),
-                "tflops": round(fl / dt / 1e12, 1), "frac_of_mfma_peak": round(fl / dt / 1e12 / BF16_DENSE_PEAK_TFLOPS, 4)}
+            u, k = nx.forward_u8(frames, fused_decode=True)
+            dx.decode_fused(u, k)
+        dt1 = _time_steps(step, dev, 5, warmup=3)
+        lanes = max(1, args.lanes)
+        pipex = rt.MultiLaneInference(nx, B, (S, S), device=dev, lanes=lanes)
+        for _ in range(3 * lanes):
+            pipex.submit(frames)
+        dtl = _time_steps(lambda: pipex.submit(frames), dev, 10, warmup=3)
+        pipex.close()
+        res = {"what": f"float16x3: every value a half pair (hi, lo), a_hi w_hi + a_hi w_lo + a_lo w_hi on the f16 MFMA, f32 "
+                       f"accumulation; meets north_star's 1e-4 / people tolerance (tests/test_x3_gpu.py), batch {B}",
+               "images_per_sec": round(B / dtl, 1), "ms_per_step": round(dtl * 1e3, 3), "lanes": lanes,
+               "images_per_sec_one_lane": round(B / dt1, 1)}
+        if args.arch == "drn_d_22" and S == 384:
+            res["agreement"] = _agreement(nx, "e2e_d22_384")
+            res["agreement_tuned_checkpoint"] = _agreement(nx, "e2e_tuned_d22_384")
+            g = np.load(os.path.join(ROOT, "tests", "golden", "forward_d22_384.npz"))
+            u8 = torch.from_numpy(prng.u8_frames(int(g["seed_in"]), int(g["batch"]), (384, 384))).to(dev)
+            sdg = synth.make_state_dict("drn_d_22", int(g["seed_w"]), bn_stats={k[3:]: g[k] for k in g.files if k.startswith("bn/")})
+            nx.load_state_dict(sdg)
+            hv = nx.forward_u8(u8).cpu().numpy().reshape(-1)[g["head_idx"]]
+            res["head_max_abs_err_vs_reference"] = float(np.abs(hv - g["head_val"]).max())
+        return res
 
     def train_shard():
         from pytorch_pose_proposal_network_amd.trainer import PPNTrainer
@@ -477,6 +543,7 @@ def extra_sections(args, dev, net, frames, dec):
     section("bf16_agreement", bf16_agreement)
     section("ap_vs_reference", ap_vs_reference)
     section("f16_mode", f16_mode)
+    section("f16x3_mode", f16x3_mode)
     section("materialized_head", materialized)
     section("decode_stress", decode_stress)
     section("f32_parity_mode", f32_mode)
@@ -631,12 +698,13 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
+    host_submit = time.perf_counter() - t0                      # this rank's host time enqueueing the K steps
     fence()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        t = torch.tensor([dt, host_submit], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt, host_submit = float(t[0].item()), float(t[1].item())
     ms_per_step = dt / args.steps * 1e3
     value = world * B * args.steps / dt
     people = int(out.count.sum().item())
@@ -736,6 +804,10 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "lanes": (max(1, args.lanes) if pipe is not None else 1),
+            "host": {"submit_ms_per_step_max_over_ranks": round(host_submit / args.steps * 1e3, 4),
+                     "omp_num_threads": os.environ.get("OMP_NUM_THREADS"), "cpu_count": os.cpu_count(),
+                     "what": "host time one rank spends enqueueing a step (max over ranks): the N ranks of a node share its "
+                             "cores; bench.py's self-launch gives each rank cpu_count // N OpenMP threads"},
             "value_windows": {"what": f"{len(win)} consecutive windows of {args.steps} steps each, same fences; `value` "
                                       "is the first", "n": len(win), "min": round(win_vals[0], 2),
                               "median": round(win_vals[len(win_vals) // 2], 2), "max": round(win_vals[-1], 2)},
@@ -772,6 +844,13 @@ def main():
                                           "frac": round(agg4[dk][1] / (agg4[dk][0] * 1e-3) / 1e12 / peak, 4)},
                          "traffic": (pmc_traffic(dk) or {}).get("bytes_per_launch"),
                          "traffic_source": (pmc_traffic(dk) or {}).get("source"),
+                         "traffic_provenance": ("a COMMITTED constant, not measured by this run: HBM bytes per launch of this "
+                                                "kernel from two separate rocprofv3 --pmc passes (FETCH_SIZE x 2 + WRITE_SIZE, "
+                                                "--lanes 1) of `python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline "
+                                                "--no-extras --no-verify --lanes 1`, tools/pmc_bench.sh -> "
+                                                "tools/pmc_traffic_summary.py -> profiles/" +
+                                                str((pmc_traffic(dk) or {}).get("source")) + " (file date " +
+                                                str((pmc_traffic(dk) or {}).get("date")) + "); bench.py cannot run the profiler on itself"),
                          "avg_launch_us": round(dms / dn * 1e3, 2),
                          "flops_per_launch_avg": round(dfl / dn)},
             "step_tflops": round(fwd_flops / ms_per_step / 1e9, 2),      # conv FLOPs / whole-step time (lanes overlap)

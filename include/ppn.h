@@ -190,7 +190,13 @@ enum { PPN_ACT_NONE = 0, PPN_ACT_RELU = 1, PPN_ACT_LRELU = 2, PPN_ACT_SIGMOID = 
 /* PPN_F16: IEEE half operands (v_mfma_f32_16x16x32_f16: the bf16 MFMA rate, 3 more mantissa bits), f32 accumulation,
  * f32 head -- inference only (the conv stack, ppn_plan_add_stem012, ppn_pack_weight); the training entry points take
  * PPN_F32 / PPN_BF16. */
-enum { PPN_F32 = 0, PPN_BF16 = 1, PPN_F16 = 2 };
+/* PPN_F16X3 (round 4): split-precision inference mode for the convolutions with cin % 64 == 0.  Activations are NHWC
+ * half PAIRS [pixel][hi(C) | lo'(C)] (hi = half(v), lo' = half((v - hi) * 2^11)), weights are packed by
+ * ppn_pack_weight_x3 as three half copies per 64-channel slab, and the K loop accumulates a_hi w_hi + a_hi w_lo + a_lo w_hi
+ * in f32 on v_mfma_f32_16x16x32_f16: 22-bit operands at a third of the f16 MFMA rate.  Meets the 1e-4 head tolerance
+ * (tests/test_x3_gpu.py); the layers with cin < 64 (stem, the first block's stride-2 convs) run as PPN_F32 and their
+ * outputs are converted by ppn_split_f16x3. */
+enum { PPN_F32 = 0, PPN_BF16 = 1, PPN_F16 = 2, PPN_F16X3 = 3 };
 
 typedef struct ppn_conv_desc {
     int32_t dtype;               /* PPN_F32 (exact-f32 MFMA, parity mode), PPN_BF16 or PPN_F16 (16-bit MFMA, f32 accumulate) */
@@ -241,7 +247,14 @@ typedef struct ppn_conv_desc {
      * out_raw, unary_out must be NULL and unary_channels 0: the 6K unary channels are an ordinary NCHW launch of their
      * own (cout = 6K, out_raw = the compact unary tensor).  0 (default): the chunked epilogue with atomicMax keys. */
     int32_t limb_edge_pad;
+    /* PPN_CONV_* bits, 0 by default.  Carried by the descriptor (and therefore by each plan entry), never process-wide:
+     * PPN_CONV_NO_FILTER_BANK routes a 64 -> 64 3x3 stride-1 convolution of the 16-bit modes through the generic
+     * implicit-GEMM kernel instead of the register-resident filter-bank kernel (csrc/conv64.hip), whose workgroups own a
+     * CU's whole LDS and register file -- the choice of a plan that shares the GPU with other lanes' plans
+     * (rt.MultiLaneInference).  Results are bit-identical either way. */
+    int32_t flags;
 } ppn_conv_desc;
+#define PPN_CONV_NO_FILTER_BANK 1
 
 /* GEMM-depth step / channel tile the packer must pad to for a conv of this shape and dtype, and the order of
  * the GEMM depth index in the packed weight rows:
@@ -255,6 +268,15 @@ int ppn_conv_tiling(int32_t dtype, int32_t cin, int32_t cout, int32_t ksize, int
                     int32_t* k_order);
 
 int ppn_conv2d_fused(const ppn_conv_desc* d, void* stream);
+
+/* PPN_F16X3 helpers.
+ * ppn_pack_weight_x3: w f32 [cout][cin][k][k] (device) -> out half [cout_pad][3 * k_pad], k_pad = k*k*cin (cin % 64 == 0),
+ *   row layout per 64-channel slab sl: [half(ws) taps x 64 | half(ws - half(ws)) taps x 64 | half(ws * 2^-11) taps x 64]
+ *   with ws = w * 2^scale_log2; the caller multiplies scale1 by 2^-scale_log2 (ppn_conv_desc.k_total = 3 * k_pad).
+ * ppn_split_f16x3: src f32 NHWC [pixels][channels] -> dst half [pixels][hi(channels) | lo'(channels)]; channels % 8 == 0. */
+int ppn_pack_weight_x3(const float* w, int32_t cout, int32_t cin, int32_t ksize, int32_t cout_pad, int32_t scale_log2,
+                       void* out, void* stream);
+int ppn_split_f16x3(const float* src, int64_t pixels, int32_t channels, void* dst, void* stream);
 
 /* Where the launcher would cut the output pixels [0, m) of a conv with this Cin/Cout into two launches under tile
  * policy 2 (ppn_set_conv_tile_policy): *m_split pixels run whole rounds (256 CUs) of the most efficient large tile, the
@@ -290,7 +312,8 @@ int ppn_set_conv_tile_override(int32_t bp, int32_t bc);
 
 /* Test and tuning hook: 0 routes the 64 -> 64 3x3 stride-1 convolutions of the 16-bit modes through the generic
  * implicit-GEMM kernels instead of the register-resident filter-bank kernel (csrc/conv64.hip); results are bit-identical
- * either way (tests/test_conv_tiles_gpu.py).  Process-wide; initial value 1 unless PPN_CONV64=0 is in the environment. */
+ * either way (tests/test_conv_tiles_gpu.py).  Process-wide; initial value 1 unless PPN_CONV64=0 is in the environment.
+ * Product code uses ppn_conv_desc.flags (PPN_CONV_NO_FILTER_BANK) per descriptor / plan instead. */
 int ppn_set_conv64_enabled(int32_t on);
 
 /* Name of the kernel instantiation the calling thread's last successful ppn_conv2d_fused launched
@@ -327,6 +350,8 @@ int ppn_plan_add_conv(ppn_plan* p, const ppn_conv_desc* d);
 /* Zero `bytes` at `ptr` as a step of the plan (the arg-max keys of the fused head conv); runs as a KERNEL with
  * 16-byte stores, never a memset node of the captured graph: `ptr` must be 16-byte aligned (PPN_E_INVALID else). */
 int ppn_plan_add_memset(ppn_plan* p, void* ptr, size_t bytes);
+/* ppn_split_f16x3 as a step of the plan (PPN_F16X3 plans: behind the PPN_F32 launches whose outputs feed split convs). */
+int ppn_plan_add_split(ppn_plan* p, const float* src, int64_t pixels, int32_t channels, void* dst);
 int ppn_plan_add_stem(ppn_plan* p, int32_t dtype, int32_t src_is_u8, const void* src, int32_t batch, int32_t h,
                       int32_t w, const float* weight, const float* scale, const float* shift, const float* mean,
                       const float* std_, void* out);

@@ -43,13 +43,20 @@ def _bf16(t):
 
 
 def fused_forward_ref(sd, x: torch.Tensor, arch: str = "drn_d_22", emulate_bf16: bool = False, taps=None,
-                      fuse_stem=False, emulate_dtype=None):
+                      fuse_stem=False, emulate_dtype=None, residual_dtype="same", fuse_shortcut: bool = True):
     """x f32 [B,3,H,W] (normalised) -> head f32 [B,C,H/16,W/16], walking the fused program.
-    emulate_dtype=torch.float16 emulates the PPN_F16 mode's storage roundings the way emulate_bf16 does bf16's."""
-    ops = A.build_program(arch, fuse_stem=fuse_stem)
+    emulate_dtype=torch.float16 emulates the PPN_F16 mode's storage roundings the way emulate_bf16 does bf16's.
+    residual_dtype (precision study, tests/precision_study.py): storage type of the tensors that are ONLY ever read as a
+    residual (never as a convolution operand) -- "same" = emulate_dtype, None = f32, or a torch dtype."""
+    ops = A.build_program(arch, fuse_stem=fuse_stem, fuse_shortcut=fuse_shortcut)
     if emulate_dtype is None and emulate_bf16:
         emulate_dtype = torch.bfloat16
     q = (lambda t: t.to(emulate_dtype).float()) if emulate_dtype is not None else (lambda t: t)
+    operands = {o.src for o in ops} | {o.ds_src for o in ops if o.ds_src}
+    if residual_dtype == "same":
+        q_res = q
+    else:
+        q_res = (lambda t: t.to(residual_dtype).float()) if residual_dtype is not None else (lambda t: t)
     tensors = {"input": x.float()}
     with torch.no_grad():
         for op in ops:
@@ -92,7 +99,7 @@ def fused_forward_ref(sd, x: torch.Tensor, arch: str = "drn_d_22", emulate_bf16:
             if op.residual:
                 v = v + tensors[op.residual]
             if op.out_raw:
-                tensors[op.out_raw] = v if op.nchw_f32_out else q(v)
+                tensors[op.out_raw] = v if op.nchw_f32_out else (q(v) if op.out_raw in operands else q_res(v))
             if op.out_act:
                 u = v
                 if op.bn2:

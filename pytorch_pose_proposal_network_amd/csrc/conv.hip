@@ -385,7 +385,68 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ 
     }
 }
 
+// PPN_F16X3 weight packing (ppn_pack_weight_x3): row = [slab][copy 0..2][tap][64 channels], ws = w * 2^s
+__global__ void pack_weight_x3_kernel(const float* __restrict__ w, _Float16* __restrict__ out, int cout, int cin, int ks,
+                                      int cout_pad, float scale) {
+    const int ntaps = ks * ks, kreal = ntaps * cin;
+    const size_t n = (size_t)cout_pad * 3 * kreal;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int co = (int)(i / (3 * (size_t)kreal)), k = (int)(i % (3 * (size_t)kreal));
+        const int blk = k / 64, within = k % 64;                      // blk = (slab * 3 + copy) * ntaps + tap
+        const int tap = blk % ntaps, sc = blk / ntaps, copy = sc % 3, ci = (sc / 3) * 64 + within;
+        float v = 0.f;
+        if (co < cout) {
+            const float ws = w[((size_t)co * cin + ci) * ntaps + tap] * scale;
+            const float hi = (float)(_Float16)ws;
+            v = copy == 0 ? hi : (copy == 1 ? ws - hi : ws * ppnconv::kX3LoInv);
+        }
+        out[i] = (_Float16)v;
+    }
+}
+
+// f32 NHWC -> PPN_F16X3 pairs (ppn_split_f16x3): 8 channels per thread
+__global__ void __launch_bounds__(256) split_x3_kernel(const float* __restrict__ src, char* __restrict__ dst, size_t pixels,
+                                                       int channels) {
+    const int cpr = channels / 8;
+    const size_t n = pixels * cpr;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t px = i / cpr;
+        const int c = (int)(i % cpr) * 8;
+        float v[8];
+        ppnconv::load8<float>(reinterpret_cast<const char*>(src + px * channels + c), v);
+        ppnconv::store8_x3(dst + (px * 2 * channels + c) * 2, (size_t)channels * 2, v);
+    }
+}
+
 }  // namespace
+
+namespace ppn {
+int split_x3_launch(const float* src, long long pixels, int channels, void* dst, hipStream_t st) {
+    if (!src || !dst || pixels < 1 || channels < 8 || channels % 8 != 0)
+        return ppn::fail(PPN_E_INVALID, "ppn_split_f16x3: NULL pointer or channels %% 8 != 0");
+    const size_t n = (size_t)pixels * (channels / 8);
+    const int blocks = (int)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256);
+    hipLaunchKernelGGL(split_x3_kernel, dim3(blocks), dim3(256), 0, st, src, static_cast<char*>(dst), (size_t)pixels, channels);
+    PPN_LAUNCH_CHECK();
+    return PPN_OK;
+}
+}  // namespace ppn
+
+extern "C" int ppn_split_f16x3(const float* src, int64_t pixels, int32_t channels, void* dst, void* stream) {
+    return ppn::split_x3_launch(src, pixels, channels, dst, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int ppn_pack_weight_x3(const float* w, int32_t cout, int32_t cin, int32_t ksize, int32_t cout_pad,
+                                  int32_t scale_log2, void* out, void* stream) {
+    if (!w || !out || cout < 1 || cin < 64 || cin % 64 != 0 || ksize < 1 || cout_pad < cout || scale_log2 < -60 || scale_log2 > 60)
+        return ppn::fail(PPN_E_INVALID, "ppn_pack_weight_x3: bad arguments (cin %% 64 == 0)");
+    const size_t n = (size_t)cout_pad * 3 * ksize * ksize * cin;
+    const int blocks = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    hipLaunchKernelGGL(pack_weight_x3_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), w,
+                       static_cast<_Float16*>(out), cout, cin, ksize, cout_pad, ldexpf(1.f, scale_log2));
+    PPN_LAUNCH_CHECK();
+    return PPN_OK;
+}
 
 namespace ppn {
 int conv_launch(const ppn_conv_desc* d, hipStream_t st, const char** kname);
@@ -400,9 +461,12 @@ int stem3x3_launch(int dtype, const void* src, int batch, int h, int w, int cout
 
 extern "C" int ppn_conv_tiling(int32_t dtype, int32_t cin, int32_t cout, int32_t ksize, int32_t* k_step,
                                int32_t* cout_tile, int32_t* k_order) {
-    if (dtype != PPN_F32 && dtype != PPN_BF16 && dtype != PPN_F16) return ppn::fail(PPN_E_INVALID, "bad dtype %d", dtype);
+    if (dtype != PPN_F32 && dtype != PPN_BF16 && dtype != PPN_F16 && dtype != PPN_F16X3)
+        return ppn::fail(PPN_E_INVALID, "bad dtype %d", dtype);
     if (cin < 1 || cout < 1 || ksize < 1) return ppn::fail(PPN_E_INVALID, "bad conv shape");
     const int bk = dtype == PPN_F32 ? 32 : 64;
+    if (dtype == PPN_F16X3 && (cin % bk != 0 || cout < 64))
+        return ppn::fail(PPN_E_UNSUPPORTED, "PPN_F16X3 needs cin %% 64 == 0 and cout >= 64 (run the layer as PPN_F32)");
     if (cin == 16 && (cout == 16 || cout == 32) && ksize == 3) {
         // direct small-channel kernel (stem3x3.hip): weights stay in the reference layout, f32, unpadded
         if (k_step) *k_step = 144;
@@ -421,7 +485,9 @@ extern "C" int ppn_conv_tiling(int32_t dtype, int32_t cin, int32_t cout, int32_t
 
 int ppn::conv_launch(const ppn_conv_desc* d, hipStream_t st, const char** kname) {
     if (!d) return ppn::fail(PPN_E_INVALID, "conv desc is NULL");
-    if (d->dtype != PPN_F32 && d->dtype != PPN_BF16 && d->dtype != PPN_F16) return ppn::fail(PPN_E_INVALID, "bad dtype %d", d->dtype);
+    if (d->dtype != PPN_F32 && d->dtype != PPN_BF16 && d->dtype != PPN_F16 && d->dtype != PPN_F16X3)
+        return ppn::fail(PPN_E_INVALID, "bad dtype %d", d->dtype);
+    const bool x3 = d->dtype == PPN_F16X3;
     const int bk = d->dtype == PPN_F32 ? 32 : 64, epc = d->dtype == PPN_F32 ? 4 : 8;
     if (d->batch < 1 || d->in_h < 1 || d->in_w < 1 || d->cin < 1 || d->cout < 1)
         return ppn::fail(PPN_E_INVALID, "bad conv geometry");
@@ -447,6 +513,11 @@ int ppn::conv_launch(const ppn_conv_desc* d, hipStream_t st, const char** kname)
     if (smallc && log2c < 0) return ppn::fail(PPN_E_UNSUPPORTED, "cin %d < K step must be a power of two", d->cin);
     const int kreal = d->ksize * d->ksize * d->cin;
     int kpad = ((kreal + bk - 1) / bk) * bk;
+    if (x3) {
+        if (smallc || d->cout < 64 || d->src2 || d->limb_edge_pad)
+            return ppn::fail(PPN_E_UNSUPPORTED, "PPN_F16X3: cin %% 64 == 0, cout >= 64, no fused shortcut, no edge tile");
+        kpad *= 3;                                                    // three virtual slabs per real one
+    }
     const int kmain = kpad;
     if (d->src2) {
         if (d->cin2 < bk || d->cin2 % bk != 0 || d->stride2 < 1 || d->in2_h < 1 || d->in2_w < 1 || d->scale1 ||
@@ -519,7 +590,7 @@ int ppn::conv_launch(const ppn_conv_desc* d, hipStream_t st, const char** kname)
     } else if (d->cout % 8 != 0) {
         return ppn::fail(PPN_E_UNSUPPORTED, "NHWC output needs cout %% 8 == 0 (got %d)", d->cout);
     }
-    const long long in_elems = (long long)d->batch * d->in_h * d->in_w * d->cin;
+    const long long in_elems = (long long)d->batch * d->in_h * d->in_w * d->cin * (x3 ? 2 : 1);
     if (in_elems > 0x7fffffffLL) return ppn::fail(PPN_E_UNSUPPORTED, "tensor too large for 32-bit indexing");
     ConvKArgs a;
     a.src = static_cast<const char*>(d->src);
@@ -530,7 +601,7 @@ int ppn::conv_launch(const ppn_conv_desc* d, hipStream_t st, const char** kname)
     a.scale2 = d->scale2; a.shift2 = d->shift2;
     a.out_act = static_cast<char*>(d->out_act);
     a.zero = static_cast<const char*>(d->zero_page);
-    a.B = d->batch; a.H = d->in_h; a.W = d->in_w; a.Cin = d->cin; a.Ho = d->out_h; a.Wo = d->out_w; a.Cout = d->cout;
+    a.B = d->batch; a.H = d->in_h; a.W = d->in_w; a.Cin = x3 ? 2 * d->cin : d->cin; a.Ho = d->out_h; a.Wo = d->out_w; a.Cout = d->cout;
     a.ks = d->ksize; a.stride = d->stride; a.dil = d->dilation; a.pad = d->pad;
     a.Ktot = d->k_total; a.M = (int)m_hi; a.m_base = (int)m_lo; a.HoWo = d->out_h * d->out_w;
     a.div_howo = make_fastdiv((unsigned)a.HoWo); a.div_wo = make_fastdiv((unsigned)d->out_w);
@@ -550,6 +621,8 @@ int ppn::conv_launch(const ppn_conv_desc* d, hipStream_t st, const char** kname)
     a.amax_keys = reinterpret_cast<unsigned long long*>(d->argmax_keys);
     a.unary_ch = d->unary_channels;
     a.window = d->limb_window;
+    a.lo_off = x3 ? d->cin * 2 : 0;                                   // source pixel = [hi(cin) | lo'(cin)] halves
+    if (x3 && !big) return ppn::fail(PPN_E_UNSUPPORTED, "PPN_F16X3 is implemented by the large-tile kernel only");
     if (big) return launch_big(a, d->dtype, bt, st, kname);
     if (d->argmax_keys) return ppn::fail(PPN_E_UNSUPPORTED, "fused arg-max is implemented by the large-tile kernel only");
     if (d->src2) return ppn::fail(PPN_E_UNSUPPORTED, "the fused shortcut is implemented by the large-tile kernel only");
@@ -559,7 +632,8 @@ int ppn::conv_launch(const ppn_conv_desc* d, hipStream_t st, const char** kname)
 }
 
 extern "C" int ppn_conv_split(int32_t dtype, int32_t cin, int32_t cout, int64_t m, int64_t* m_split) {
-    if (dtype != PPN_F32 && dtype != PPN_BF16 && dtype != PPN_F16) return ppn::fail(PPN_E_INVALID, "bad dtype %d", dtype);
+    if (dtype != PPN_F32 && dtype != PPN_BF16 && dtype != PPN_F16 && dtype != PPN_F16X3)
+        return ppn::fail(PPN_E_INVALID, "bad dtype %d", dtype);
     if (cin < 1 || cout < 1 || m < 1 || !m_split) return ppn::fail(PPN_E_INVALID, "ppn_conv_split: bad arguments");
     const int bk = dtype == PPN_F32 ? 32 : 64;
     const long long cut = (cin % bk == 0) ? big_split_for(cout, m) : 0;

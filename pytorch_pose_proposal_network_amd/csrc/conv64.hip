@@ -298,7 +298,7 @@ static int g_conv64_on = -1;             // -1: not decided yet (PPN_CONV64=0 in
 
 bool conv64_supported(const ppn_conv_desc* d) {
     if (g_conv64_on < 0) g_conv64_on = (getenv("PPN_CONV64") && atoi(getenv("PPN_CONV64")) == 0) ? 0 : 1;
-    if (!g_conv64_on) return false;
+    if (!g_conv64_on || (d->flags & PPN_CONV_NO_FILTER_BANK)) return false;
     return (d->dtype == PPN_BF16 || d->dtype == PPN_F16) && d->cin == 64 && d->cout == 64 && d->ksize == 3 && d->stride == 1 &&
            d->dilation == 1 && d->pad == 1 && !d->src2 && !d->out_nchw_f32 && !d->argmax_keys && d->k_total == 576 &&
            d->cout_pad == 64 && d->m_count == 0 && d->act1 != PPN_ACT_SIGMOID && d->act2 != PPN_ACT_SIGMOID;

@@ -89,7 +89,7 @@ __device__ __forceinline__ void store4<_Float16>(char* p, const float* v) {
     typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
     f16x4 o;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) o[i] = (_Float16)v[i];
+    for (int i = 0; i < 4; ++i) o[i] = (_Float16)clamp_f16(v[i]);
     *reinterpret_cast<f16x4*>(p) = o;
 }
 
@@ -103,9 +103,17 @@ __device__ __forceinline__ void bufload_lds16(__amdgpu_buffer_rsrc_t rsrc, char*
 // NW = 8 -> two waves per SIMD (each hides the other's LDS-DMA issue stalls) with 8 x TP<=4 tiles.
 // SC: the launch carries a fused 1x1 projection shortcut (second activation source, ConvKArgs.src2); compiled out
 // of the plain instantiation -- its extra loader state costs the main loop a few per cent.
-template <typename T, int BP, int BC, int NW, bool SC>
+// X3 (PPN_F16X3, T = _Float16): split-precision operands.  Activation tensors hold every value as an IEEE-half pair,
+// NHWC [pixel][hi(C) | lo'(C)] with hi = half(v), lo' = half((v - hi) * 2^11); the packed weight rows hold, per 64-channel
+// slab, three copies [half(ws) | half(ws - half(ws)) | half(ws * 2^-11)] of the layer's weights ws = w * 2^s (s chosen on
+// the host so that max |ws| <= 32768; 2^-s is folded into scale1).  The K loop walks three virtual slabs per real slab --
+// (a_hi, w_hi), (a_hi, w_lo), (a_lo', w_hi * 2^-11) -- i.e. acc += a_hi w_hi + a_hi w_lo + a_lo w_hi in f32: products of
+// 22-bit operands minus the lo x lo term (2^-22 relative), at a third of the f16 MFMA rate = ~5x the exact-f32 MFMA rate.
+// Same loop, same staging: only the slab bookkeeping of advance() and the epilogue's loads / stores differ.
+template <typename T, int BP, int BC, int NW, bool SC, bool X3 = false>
 __global__ void __launch_bounds__(64 * NW, NW / 4)
 conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
+    static_assert(!X3 || (std::is_same<T, _Float16>::value && !SC), "X3 is the split-f16 mode without a fused shortcut");
     constexpr int EPC = Elem<T>::EPC;
     constexpr int BK = 8 * EPC;
     constexpr int ES = sizeof(T);
@@ -187,7 +195,7 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
     const int dx_bytes = a.dil * a.Cin * ES;                        // one tap to the right
     const int dy_bytes = a.dil * a.W * a.Cin * ES - a.ks * dx_bytes; // next tap row, back to dx = 0
     const int ksz = a.ks;
-    int u_tap = 0, u_dx = 0, u_slab = 0, tapoff = 0;
+    int u_tap = 0, u_dx = 0, u_slab = 0, tapoff = 0, u_ph = 0;
     unsigned tapbit = 1u;                                           // 0 once past the last K step
     unsigned ksoff = 0;
     bool live = true;
@@ -206,8 +214,17 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
             tapoff += wrapx ? dy_bytes : 0;
             const bool wrapt = u_tap == ntaps;
             u_tap = wrapt ? 0 : u_tap;
-            u_slab += wrapt ? BK * ES : 0;
-            tapoff = wrapt ? u_slab : tapoff;
+            if constexpr (X3) {
+                // three virtual slabs per real one: hi, hi, lo' (a.lo_off bytes further in the pixel)
+                u_ph += wrapt ? 1 : 0;
+                const bool wrapp = u_ph == 3;
+                u_ph = wrapp ? 0 : u_ph;
+                u_slab += wrapp ? BK * ES : 0;
+                tapoff = wrapt ? u_slab + (u_ph == 2 ? a.lo_off : 0) : tapoff;
+            } else {
+                u_slab += wrapt ? BK * ES : 0;
+                tapoff = wrapt ? u_slab : tapoff;
+            }
             tapbit = live ? (1u << u_tap) : 0u;
         } else {
             tapoff = phase2 ? tapoff + BK * ES : 0;               // plain channel slabs of the second source
@@ -416,7 +433,7 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
 #ifdef PPN_NO_FAST_EPI
     constexpr bool kFastFits = false;
 #else
-    constexpr bool kFastFits = sizeof(T) == 2 && BC >= 128 && (size_t)BP * RS16 <= 2 * (size_t)STAGE;
+    constexpr bool kFastFits = !X3 && sizeof(T) == 2 && BC >= 128 && (size_t)BP * RS16 <= 2 * (size_t)STAGE;
 #endif
     bool fast = false;
     if constexpr (kFastFits) fast = !a.nchw && !a.residual && !a.out_act && a.out_raw && (a.Cout & 7) == 0;
@@ -519,7 +536,8 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
                 int mrow[NPASS];
                 size_t moff[NPASS];                                  // byte offset of (row, c) in the NHWC tensors
                 float res[NPASS][8];
-                const size_t row_bytes = (size_t)a.Cout * ES;
+                const size_t row_bytes = (size_t)a.Cout * ES * (X3 ? 2 : 1);       // X3: [hi(Cout) | lo'(Cout)] per pixel
+                const size_t lo_bytes = (size_t)a.Cout * ES;
                 // residual rows of ALL passes are requested first: one memory latency per chunk, not per pass
 #pragma unroll
                 for (int pass = 0; pass < NPASS; ++pass) {
@@ -536,7 +554,10 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
                     }
 #pragma unroll
                     for (int i = 0; i < 8; ++i) res[pass][i] = 0.f;
-                    if (a.residual && m < a.M) load8<T>(a.residual + moff[pass], res[pass]);
+                    if (a.residual && m < a.M) {
+                        if constexpr (X3) load8_x3(a.residual + moff[pass], lo_bytes, res[pass]);
+                        else load8<T>(a.residual + moff[pass], res[pass]);
+                    }
                 }
 #pragma unroll
                 for (int pass = 0; pass < NPASS; ++pass) {
@@ -556,7 +577,10 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
 #if PPN_DIAG == 7
                         if (a.out_raw && v[0] == 12345.678f) store8<T>(a.out_raw + off, v);
 #else
-                        if (a.out_raw) store8<T>(a.out_raw + off, v);
+                        if (a.out_raw) {
+                            if constexpr (X3) store8_x3(a.out_raw + off, lo_bytes, v);
+                            else store8<T>(a.out_raw + off, v);
+                        }
 #endif
                         if (a.out_act) {
                             float u[8];
@@ -565,7 +589,8 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
                                 const float t2 = v[i] * s2[i] + b2[i];
                                 u[i] = fmaxf(t2, t2 * slope2);
                             }
-                            store8<T>(a.out_act + off, u);
+                            if constexpr (X3) store8_x3(a.out_act + off, lo_bytes, u);
+                            else store8<T>(a.out_act + off, u);
                         }
                     }
                 }
@@ -742,17 +767,17 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
 #endif
 }
 
-template <typename T, int BP, int BC, int NW, bool SC>
+template <typename T, int BP, int BC, int NW, bool SC, bool X3 = false>
 int launch_sc(const ConvKArgs& a, hipStream_t st, const char** kname) {
     constexpr size_t lds = 2 * (size_t)(BP + BC) * 128;
     static char name[96];
     if (!name[0])
-        snprintf(name, sizeof(name), "conv_igemm_big_kernel<%s, %d, %d, %d, %s>", elem_name<T>(),
-                 BP, BC, NW, SC ? "true" : "false");
+        snprintf(name, sizeof(name), "conv_igemm_big_kernel<%s, %d, %d, %d, %s%s>", elem_name<T>(),
+                 BP, BC, NW, SC ? "true" : "false", X3 ? ", true" : "");
     if (kname) *kname = name;
     const size_t src_bytes = (size_t)a.B * a.H * a.W * a.Cin * sizeof(T);
     const size_t wgt_bytes = (size_t)a.n_ctiles * BC * a.Ktot * sizeof(T);
-    auto k = conv_igemm_big_kernel<T, BP, BC, NW, SC>;
+    auto k = conv_igemm_big_kernel<T, BP, BC, NW, SC, X3>;
     {
         static int max_lds_set = 0;   // the attribute sticks to the function: set it when it grows
         PPN_LDS_ONCE(max_lds_set, reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -799,6 +824,23 @@ int launch_T(const ConvKArgs& a, BigTile t, hipStream_t st, const char** kname) 
     }
     if (t.bp == 256) return launch_one<T, 256, 64, 8>(a, st, kname);
     return launch_one<T, 128, 64, 8>(a, st, kname);
+}
+
+// split-f16 mode (PPN_F16X3): the 8-wave tiles, no fused shortcut
+int launch_X3(const ConvKArgs& a, BigTile t, hipStream_t st, const char** kname) {
+    if (a.src2) return ppn::fail(PPN_E_UNSUPPORTED, "PPN_F16X3: no fused shortcut");
+    if (t.bc == 256) {
+        if (t.bp == 256) return launch_sc<_Float16, 256, 256, 8, false, true>(a, st, kname);
+        if (t.bp == 192) return launch_sc<_Float16, 192, 256, 8, false, true>(a, st, kname);
+        return launch_sc<_Float16, 128, 256, 8, false, true>(a, st, kname);
+    }
+    if (t.bc == 128) {
+        if (t.bp == 256) return launch_sc<_Float16, 256, 128, 8, false, true>(a, st, kname);
+        if (t.bp == 192) return launch_sc<_Float16, 192, 128, 8, false, true>(a, st, kname);
+        return launch_sc<_Float16, 128, 128, 8, false, true>(a, st, kname);
+    }
+    if (t.bp == 256) return launch_sc<_Float16, 256, 64, 8, false, true>(a, st, kname);
+    return launch_sc<_Float16, 128, 64, 8, false, true>(a, st, kname);
 }
 
 }  // namespace
@@ -907,6 +949,7 @@ int launch_big(const ConvKArgs& a, int dtype, BigTile t, hipStream_t st, const c
     if ((size_t)a.B * a.H * a.W * a.Cin * es >= 0x7fffff00ull || (size_t)a.n_ctiles * t.bc * a.Ktot * es >= 0x7fffff00ull)
         return ppn::fail(PPN_E_UNSUPPORTED, "tensor too large for the buffer-addressed conv kernel");
     if (dtype == PPN_F32) return launch_T<float>(a, t, st, kname);
+    if (dtype == PPN_F16X3) return launch_X3(a, t, st, kname);
     if (dtype == PPN_F16) return launch_T<_Float16>(a, t, st, kname);
     return launch_T<__bf16>(a, t, st, kname);
 }

@@ -57,6 +57,7 @@ struct ConvKArgs {
     int H2, W2, Cin2, stride2;
     int nsteps_main;                  // K steps of the main convolution; the rest belong to the shortcut
     unsigned src2_bytes;
+    int lo_off;                       // PPN_F16X3: bytes from a pixel's hi block to its lo' block in the SOURCE tensor
 };
 
 template <typename T>
@@ -134,6 +135,11 @@ __device__ __forceinline__ void load8<_Float16>(const char* p, float* v) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = (float)a[i];
 }
+// IEEE half overflows to +-inf past 65504; the f16 mode stores RAW pre-activation residual streams, and one inf becomes
+// a NaN in the next residual add / BN affine and a garbage decode.  Every f16 store path clamps to the largest finite
+// half instead (one v_med3_f32; a NaN stays a NaN).
+__device__ __forceinline__ float clamp_f16(float v) { return __builtin_amdgcn_fmed3f(v, -65504.f, 65504.f); }
+
 template <typename T>
 __device__ __forceinline__ void store8(char* p, const float* v);
 template <>
@@ -153,8 +159,27 @@ template <>
 __device__ __forceinline__ void store8<_Float16>(char* p, const float* v) {
     f16x8 o;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) o[i] = (_Float16)v[i];               // RNE, v_cvt_f16_f32 (saturates to +-inf past 65504)
+    for (int i = 0; i < 8; ++i) o[i] = (_Float16)clamp_f16(v[i]);    // RNE (v_cvt_f16_f32) on a value held inside the finite range
     *reinterpret_cast<f16x8*>(p) = o;
+}
+
+// PPN_F16X3 storage: a value v as the half pair (hi, lo') = (half(v), half((v - hi) * 2^11)); lo' is kept at hi's
+// magnitude so that it never falls into the half subnormals while hi is normal.  `lo_bytes`: distance hi -> lo' block.
+constexpr float kX3LoScale = 2048.f, kX3LoInv = 1.f / 2048.f;
+__device__ __forceinline__ void store8_x3(char* p, size_t lo_bytes, const float* v) {
+    f16x8 h, l;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        h[i] = (_Float16)clamp_f16(v[i]);
+        l[i] = (_Float16)clamp_f16((v[i] - (float)h[i]) * kX3LoScale);   // the difference is exact in f32; |.| <= ulp(hi)/2 * 2^11
+    }
+    *reinterpret_cast<f16x8*>(p) = h;
+    *reinterpret_cast<f16x8*>(p + lo_bytes) = l;
+}
+__device__ __forceinline__ void load8_x3(const char* p, size_t lo_bytes, float* v) {
+    const f16x8 h = *reinterpret_cast<const f16x8*>(p), l = *reinterpret_cast<const f16x8*>(p + lo_bytes);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)h[i] + (float)l[i] * kX3LoInv;
 }
 
 // conv_big.hip: 512-thread, (BP x BC) = ({128,192,256} x {128,256}) tiles for Cin % K-step == 0 layers

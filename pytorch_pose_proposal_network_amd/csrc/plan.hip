@@ -8,6 +8,7 @@
 
 namespace ppn {
 int conv_launch(const ppn_conv_desc* d, hipStream_t st, const char** kname);
+int split_x3_launch(const float* src, long long pixels, int channels, void* dst, hipStream_t st);
 int stem_launch(int dtype, int src_is_u8, const void* src, int batch, int h, int w, const float* weight,
                 const float* scale, const float* shift, const float* mean, const float* stdv, void* out,
                 hipStream_t st);
@@ -22,7 +23,8 @@ int stem012_launch(int dtype, int src_is_u8, const void* src, int batch, int h, 
 
 struct ppn_plan {
     struct Op {
-        int kind;  // 0 conv, 1 stem, 2 memset, 3 stem01 (layer0 + layer1), 4 stem012 (layer0 + layer1 + layer2, bf16)
+        int kind;  // 0 conv, 1 stem, 2 memset, 3 stem01 (layer0 + layer1), 4 stem012 (layer0 + layer1 + layer2, bf16),
+                   // 5 f32 -> PPN_F16X3 pair conversion (src = f32 tensor, ms_ptr = destination, ms_bytes = pixels, batch = channels)
         const float *w1 = nullptr, *scale1 = nullptr, *shift1 = nullptr;
         const float *w2 = nullptr, *scale2 = nullptr, *shift2 = nullptr, *scale3 = nullptr, *shift3 = nullptr;
         void* out2 = nullptr;
@@ -75,6 +77,10 @@ static int run_op(ppn_plan::Op& op, hipStream_t st) {
         PPN_LAUNCH_CHECK();
         return PPN_OK;
     }
+    if (op.kind == 5) {
+        if (op.kname.empty()) op.kname = "split_x3_kernel";
+        return ppn::split_x3_launch(static_cast<const float*>(op.src), (long long)op.ms_bytes, op.batch, op.ms_ptr, st);
+    }
     if (op.kind == 0) {
         const char* kn = nullptr;
         int rc = ppn::conv_launch(&op.conv, st, &kn);
@@ -108,6 +114,19 @@ extern "C" int ppn_plan_add_conv(ppn_plan* p, const ppn_conv_desc* d) {
     ppn_plan::Op op{};
     op.kind = 0;
     op.conv = *d;
+    p->ops.push_back(op);
+    return PPN_OK;
+}
+
+extern "C" int ppn_plan_add_split(ppn_plan* p, const float* src, int64_t pixels, int32_t channels, void* dst) {
+    if (!p || !src || !dst || pixels < 1 || channels < 8 || channels % 8 != 0)
+        return ppn::fail(PPN_E_INVALID, "ppn_plan_add_split: NULL argument or channels %% 8 != 0");
+    ppn_plan::Op op{};
+    op.kind = 5;
+    op.src = src;
+    op.ms_ptr = dst;
+    op.ms_bytes = (size_t)pixels;
+    op.batch = channels;
     p->ops.push_back(op);
     return PPN_OK;
 }

@@ -99,6 +99,13 @@ __device__ __forceinline__ u32x2 lds_read64(unsigned addr) {
 __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c, int, int, int) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c, int, int, int) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 
+// non-negative float -> storage type; the IEEE-half instantiation stays finite (65504) instead of overflowing to +inf
+template <typename H>
+__device__ __forceinline__ H to_store(float v) {
+    if constexpr (sizeof(H) == 2 && !__is_same(H, __bf16)) return (H)fminf(v, 65504.f);
+    else return (H)v;
+}
+
 // BN + ReLU of one accumulator tile -> 4 packed bf16 channels (zero when `inside` is false)
 template <typename H>
 __device__ __forceinline__ u32x2 bn_relu_pack(const f32x4& acc, const float (&sc)[4], const float (&sh)[4], bool inside) {
@@ -107,7 +114,7 @@ __device__ __forceinline__ u32x2 bn_relu_pack(const f32x4& acc, const float (&sc
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const float t = acc[r] * sc[r] + sh[r];
-        o[r] = (H)(t > 0.f ? t : 0.f);
+        o[r] = to_store<H>(t > 0.f ? t : 0.f);
     }
     u32x2 p = __builtin_bit_cast(u32x2, o);
     p.x = inside ? p.x : 0u;
@@ -372,8 +379,8 @@ __global__ void __launch_bounds__(256, 2) stem012_kernel(Stem012Args a) {
                             const float t = acc[ct][r] * sc2[ct][r] + sh2[ct][r];
                             const float v = t > 0.f ? t : 0.f;               // BN + ReLU (drn.py:198-200)
                             const float w2 = v * sc3[ct][r] + sh3[ct][r];
-                            ov[r] = (H)v;
-                            ou[r] = (H)(w2 > 0.f ? w2 : 0.f);           // next block's relu(bn1(x)) (drn.py:45-46)
+                            ov[r] = to_store<H>(v);
+                            ou[r] = to_store<H>(w2 > 0.f ? w2 : 0.f);           // next block's relu(bn1(x)) (drn.py:45-46)
                         }
                         const size_t o = pix * 32 + ct * 16 + 4 * g;
                         if (a.out_raw) *reinterpret_cast<hx4*>(static_cast<H*>(a.out_raw) + o) = ov;

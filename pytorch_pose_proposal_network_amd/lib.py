@@ -10,7 +10,8 @@ LIB_PATH = os.environ.get("PPN_LIB", os.path.join(_HERE, "csrc", "libppn.so"))  
 
 PPN_MAX_EDGES = 32
 PPN_MAX_KP = 32
-PPN_F32, PPN_BF16, PPN_F16 = 0, 1, 2
+PPN_F32, PPN_BF16, PPN_F16, PPN_F16X3 = 0, 1, 2, 3
+PPN_CONV_NO_FILTER_BANK = 1          # ppn_conv_desc.flags
 PPN_ACT_NONE, PPN_ACT_RELU, PPN_ACT_LRELU, PPN_ACT_SIGMOID = 0, 1, 2, 3
 
 
@@ -37,6 +38,7 @@ class ConvDesc(C.Structure):
         ("src2", C.c_void_p), ("in2_h", C.c_int32), ("in2_w", C.c_int32), ("cin2", C.c_int32), ("stride2", C.c_int32),
         ("unary_out", C.c_void_p), ("argmax_keys", C.c_void_p), ("unary_channels", C.c_int32),
         ("limb_window", C.c_int32), ("m_begin", C.c_int32), ("m_count", C.c_int32), ("limb_edge_pad", C.c_int32),
+        ("flags", C.c_int32),
     ]
 
 
@@ -112,6 +114,10 @@ _SIGNATURES = {
     "ppn_plan_create": (C.c_int, [C.POINTER(C.c_void_p)]),
     "ppn_plan_add_conv": (C.c_int, [C.c_void_p, C.POINTER(ConvDesc)]),
     "ppn_plan_add_memset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "ppn_plan_add_split": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
+    "ppn_pack_weight_x3": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
+                                     C.c_void_p]),
+    "ppn_split_f16x3": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "ppn_plan_add_stem": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32] +
                           [C.c_void_p] * 3 + [C.POINTER(C.c_float)] * 2 + [C.c_void_p]),
     "ppn_plan_set_input": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -74,7 +74,8 @@ class PoseProposalNet:
         self.gridsize = (int(inW / outW), int(inH / outH))
         self.lastsize = 6 * len(keypoint_names) + sW * sH * len(edges)          # model.py:64
         self.compute_dtype = {"float32": L.PPN_F32, "fp32": L.PPN_F32, "bfloat16": L.PPN_BF16,
-                              "bf16": L.PPN_BF16, "float16": L.PPN_F16, "fp16": L.PPN_F16, "f16": L.PPN_F16}[compute_dtype]
+                              "bf16": L.PPN_BF16, "float16": L.PPN_F16, "fp16": L.PPN_F16, "f16": L.PPN_F16,
+                              "float16x3": L.PPN_F16X3, "f16x3": L.PPN_F16X3}[compute_dtype]
         self.training = False
         self.device = torch.device("cuda")
         if fuse_stem is None:
@@ -82,7 +83,13 @@ class PoseProposalNet:
             # the exact-f32 parity mode runs them layer by layer
             fuse_stem = "all" if (self.compute_dtype == L.PPN_F16 or (
                 self.compute_dtype == L.PPN_BF16 and os.environ.get("PPN_FUSE_STEM", "1") != "0")) else False
-        if fuse_stem == "all" and self.compute_dtype == L.PPN_F32:
+        if self.compute_dtype == L.PPN_F16X3:
+            # split-f16 mode: the layers with cin < 64 (stem, first block's stride-2 convs) run as exact f32, launch by
+            # launch; the split kernel has no fused-shortcut instantiation
+            if fuse_stem or fuse_shortcut:
+                raise ValueError("the float16x3 mode runs the stem layer by layer and without fused shortcuts")
+            fuse_stem, fuse_shortcut = False, False
+        if fuse_stem == "all" and self.compute_dtype in (L.PPN_F32, L.PPN_F16X3):
             raise ValueError("fuse_stem='all' (csrc/stem012.hip) is a 16-bit-mode kernel")
         if self.compute_dtype == L.PPN_F16 and fuse_stem != "all":
             raise ValueError("the float16 mode runs the stem through csrc/stem012.hip only (fuse_stem='all')")
@@ -116,8 +123,9 @@ class PoseProposalNet:
         state_dict; the training loop then calls ``model.trainer.train_step(x, targets)``.
         mode=False: back to the folded-BN inference plan; parameters and running statistics the trainer changed are
         folded again first."""
-        if mode and self.compute_dtype == L.PPN_F16:
-            raise RuntimeError("PoseProposalNet.train(): the float16 mode is inference only (train in bfloat16 / float32)")
+        if mode and self.compute_dtype in (L.PPN_F16, L.PPN_F16X3):
+            raise RuntimeError("PoseProposalNet.train(): the float16 / float16x3 modes are inference only (train in "
+                               "bfloat16 / float32)")
         if mode and not self.training:
             if not self._sd:
                 raise RuntimeError("PoseProposalNet.train(): call load_state_dict() first")
@@ -216,10 +224,29 @@ class PoseProposalNet:
                     self._dev[op.name + ".s1c"] = sm.float().to(dev)
                     self._dev[op.name + ".b1c"] = bm.float().to(dev)
                 continue
-            kstep, _, korder, ktot, cpad = L.conv_tiling(self.compute_dtype, op.cin, op.cout, op.k)
+            odt = self._op_dtype(op)
+            if odt == L.PPN_F16X3:
+                # split-f16 weights: three half copies of w * 2^s per 64-channel slab (csrc/conv_big.hip, X3); 2^-s is
+                # folded into scale1 (a power of two: exact)
+                _, _, _, kpad, cpad = L.conv_tiling(odt, op.cin, op.cout, op.k)
+                wmax = float(w.abs().max())
+                sl2 = int(np.floor(np.log2(32768.0 / wmax))) if wmax > 0 else 0
+                sl2 = max(-24, min(24, sl2))
+                wd = w.to(dev)
+                packed = torch.empty(cpad, 3 * kpad, dtype=torch.float16, device=dev)
+                L.check(lib.ppn_pack_weight_x3(wd.data_ptr(), op.cout, op.cin, op.k, cpad, sl2, packed.data_ptr(), stream),
+                        "ppn_pack_weight_x3")
+                base = s1 if s1 is not None else torch.ones(op.cout, dtype=torch.float64)
+                self._dev[op.name + ".s1"] = (base * (2.0 ** -sl2)).float().to(dev)
+                self._dev[op.name + ".w"] = packed
+                self._dev[op.name + ".geom"] = (3 * kpad, cpad)
+                torch.cuda.synchronize(dev)
+                continue
+            kstep, _, korder, ktot, cpad = L.conv_tiling(odt, op.cin, op.cout, op.k)
             wd = w.to(dev)
+            tdt = self._tdt(odt)
             packed = torch.empty(cpad, ktot, dtype=torch.float32 if korder == 2 else tdt, device=dev)
-            L.check(lib.ppn_pack_weight(self.compute_dtype, wd.data_ptr(), op.cout, op.cin, op.k, cpad, ktot,
+            L.check(lib.ppn_pack_weight(odt, wd.data_ptr(), op.cout, op.cin, op.k, cpad, ktot,
                                         korder, kstep, packed.data_ptr(), stream), "ppn_pack_weight")
             if op.ds_src:
                 # fused projection shortcut: [main | 1x1 weights * BN scale] per packed row, BN shift -> shift1
@@ -261,14 +288,22 @@ class PoseProposalNet:
                 torch.cuda.synchronize(dev)               # `wu` / `we` die here: their pack kernels must have run
         torch.cuda.synchronize(dev)
 
-    def _tdt(self):
-        return {L.PPN_F32: torch.float32, L.PPN_BF16: torch.bfloat16, L.PPN_F16: torch.float16}[self.compute_dtype]
+    def _tdt(self, dtype=None):
+        return {L.PPN_F32: torch.float32, L.PPN_BF16: torch.bfloat16, L.PPN_F16: torch.float16,
+                L.PPN_F16X3: torch.float16}[self.compute_dtype if dtype is None else dtype]
+
+    def _op_dtype(self, op) -> int:
+        """The dtype a launch runs in: the model's, except that the float16x3 mode runs the convolutions the split
+        kernel does not cover (cin not a multiple of 64: the stem and the first block's stride-2 convs) as exact f32."""
+        if self.compute_dtype != L.PPN_F16X3:
+            return self.compute_dtype
+        return L.PPN_F16X3 if (op.k != 7 and op.cin % 64 == 0 and op.cout >= 64) else L.PPN_F32
 
     def _head_edge_pad(self) -> int:
         """Rows per edge of the edge-aligned limb tile (448) when the limb window fits it (385..448 values, e.g. the
         reference's 21 x 21), else 0: the chunked epilogue with atomicMax keys.  PPN_HEAD_EDGE=0 forces the latter."""
         win = self.local_grid_size[0] * self.local_grid_size[1]
-        if os.environ.get("PPN_HEAD_EDGE", "1") == "0" or not (384 < win <= 448):
+        if os.environ.get("PPN_HEAD_EDGE", "1") == "0" or not (384 < win <= 448) or self.compute_dtype == L.PPN_F16X3:
             return 0
         kstep, _, korder, _, _ = L.conv_tiling(self.compute_dtype, 512, 512, 1)
         return 448 if korder == 1 else 0
@@ -278,7 +313,7 @@ class PoseProposalNet:
         t = self._dev.get(key) if key else None
         return t.data_ptr() if t is not None else None
 
-    def _build_plan(self, batch: int, h: int, w: int, src_is_u8: bool, fused: bool = False) -> _Plan:
+    def _build_plan(self, batch: int, h: int, w: int, src_is_u8: bool, fused: bool = False, conv_flags: int = 0) -> _Plan:
         lib = self._lib
         dev = self.device
         # the plan's own input buffer: u8 [B,H,W,3] frames or the f32 [B,3,H,W] normalised image of model.forward
@@ -287,13 +322,46 @@ class PoseProposalNet:
         tdt = self._tdt()
         shapes = A.tensor_shapes(self._ops, h, w)
         bufs: Dict[str, torch.Tensor] = {}
+        x3 = self.compute_dtype == L.PPN_F16X3
+        producer = {}                                 # tensor name -> dtype of the launch that writes it
+        for op in self._ops:
+            for name in (op.out_raw, op.out_act):
+                if name:
+                    producer[name] = self._op_dtype(op)
+        need_split = set()                            # f32-produced tensors a split-f16 launch reads (float16x3 mode)
+        if x3:
+            for op in self._ops:
+                if self._op_dtype(op) == L.PPN_F16X3:
+                    for name in (op.src, op.residual):
+                        if name and producer.get(name) == L.PPN_F32:
+                            need_split.add(name)
+                else:
+                    assert op.src == "input" or producer[op.src] == L.PPN_F32, "an f32 launch cannot read a split tensor"
+                    assert not op.residual or producer[op.residual] == L.PPN_F32
         for name, (th, tw, tc) in shapes.items():
             if name == "input":
                 continue
             if name == "head":
                 bufs[name] = torch.empty(batch, tc, th, tw, dtype=torch.float32, device=dev)
+            elif x3 and producer[name] == L.PPN_F16X3:
+                bufs[name] = torch.empty(batch, th, tw, 2 * tc, dtype=torch.float16, device=dev)   # [hi(C) | lo'(C)]
+            elif x3:
+                bufs[name] = torch.empty(batch, th, tw, tc, dtype=torch.float32, device=dev)
+                if name in need_split:
+                    bufs[name + "#x3"] = torch.empty(batch, th, tw, 2 * tc, dtype=torch.float16, device=dev)
             else:
                 bufs[name] = torch.empty(batch, th, tw, tc, dtype=tdt, device=dev)
+
+        def rd(name, odt):                            # the buffer a launch of dtype `odt` reads tensor `name` from
+            return bufs[name + "#x3"] if (odt == L.PPN_F16X3 and producer.get(name) == L.PPN_F32) else bufs[name]
+
+        def add_splits(op):                           # behind an f32 launch: convert the outputs split launches read
+            for name in (op.out_raw, op.out_act):
+                if name and name in need_split:
+                    th_, tw_, tc_ = shapes[name]
+                    L.check(lib.ppn_plan_add_split(handle, bufs[name].data_ptr(), batch * th_ * tw_, tc_,
+                                                   bufs[name + "#x3"].data_ptr()), "ppn_plan_add_split")
+                    entries.append((f"split({name})", 0))
         handle = C.c_void_p()
         L.check(lib.ppn_plan_create(C.byref(handle)), "ppn_plan_create")
         entries = []
@@ -308,6 +376,7 @@ class PoseProposalNet:
             ih, iw, _ = shapes[op.src]
             oh, ow = A.out_hw(op, ih, iw)
             entries.append((op.name, A.op_flops(op, shapes) * batch))
+            odt = self._op_dtype(op)
             if op.k == 7 and op.next_s2 is not None:
                 assert op.src == "input" and self.compute_dtype in (L.PPN_BF16, L.PPN_F16)
                 L.check(lib.ppn_plan_add_stem012_dt(handle, self.compute_dtype, 1 if src_is_u8 else 0, src.data_ptr(), batch, h, w,
@@ -332,23 +401,25 @@ class PoseProposalNet:
                 continue
             if op.k == 7:
                 assert op.src == "input" and op.out_act is None
-                L.check(lib.ppn_plan_add_stem(handle, self.compute_dtype, 1 if src_is_u8 else 0, src.data_ptr(),
+                L.check(lib.ppn_plan_add_stem(handle, odt, 1 if src_is_u8 else 0, src.data_ptr(),
                                               batch, h, w, self._ptr(op.name + ".w"), self._ptr(op.name + ".s1"),
                                               self._ptr(op.name + ".b1"), self._mean, self._std,
                                               bufs[op.out_raw].data_ptr()), "ppn_plan_add_stem")
+                add_splits(op)
                 continue
             d = L.ConvDesc()
-            d.dtype = self.compute_dtype
+            d.dtype = odt
+            d.flags = conv_flags
             d.batch, d.in_h, d.in_w, d.cin = batch, ih, iw, op.cin
             d.out_h, d.out_w, d.cout = oh, ow, op.cout
             d.ksize, d.stride, d.dilation, d.pad = op.k, op.stride, op.dilation, op.pad
             d.k_total, d.cout_pad = self._dev[op.name + ".geom"]
             d.act1, d.act2 = op.act1, op.act2
             d.out_nchw_f32 = 1 if op.nchw_f32_out else 0
-            d.src = bufs[op.src].data_ptr()
+            d.src = rd(op.src, odt).data_ptr()
             d.weight = self._ptr(op.name + ".w")
             d.scale1, d.shift1 = self._ptr(op.name + ".s1"), self._ptr(op.name + ".b1")
-            d.residual = bufs[op.residual].data_ptr() if op.residual else None
+            d.residual = rd(op.residual, odt).data_ptr() if op.residual else None
             if op.ds_src:
                 sh2, sw2, sc2 = shapes[op.ds_src]
                 d.src2, d.in2_h, d.in2_w, d.cin2, d.stride2 = bufs[op.ds_src].data_ptr(), sh2, sw2, sc2, op.ds_stride
@@ -396,24 +467,28 @@ class PoseProposalNet:
                     entries.append((f"{name}[{lo}:{lo + n}]", flops * n // m_all))
                 continue
             L.check(lib.ppn_plan_add_conv(handle, C.byref(d)), f"ppn_plan_add_conv({op.name})")
+            if x3 and odt == L.PPN_F32:
+                add_splits(op)
         head = (bufs["unary"], bufs["keys"]) if fused else bufs["head"]
         return _Plan(handle, bufs, head, entries, A.conv_flops(self._ops, h, w) * batch, src)
 
-    def _get_plan(self, b: int, h: int, w: int, src_is_u8: bool, fused: bool = False, slot: int = 0) -> _Plan:
+    def _get_plan(self, b: int, h: int, w: int, src_is_u8: bool, fused: bool = False, slot: int = 0,
+                  conv_flags: int = 0) -> _Plan:
         if not self._dev:
             raise RuntimeError("PoseProposalNet: call load_state_dict() first")
-        key = (b, h, w, src_is_u8, fused, slot)       # slot: independent output buffers (pipelined serving)
+        # slot: independent output buffers (pipelined serving); conv_flags: ppn_conv_desc.flags of every conv of the plan
+        key = (b, h, w, src_is_u8, fused, slot) if not conv_flags else (b, h, w, src_is_u8, fused, slot, conv_flags)
         plan = self._plans.get(key)
         if plan is None:
-            plan = self._plans[key] = self._build_plan(b, h, w, src_is_u8, fused)
+            plan = self._plans[key] = self._build_plan(b, h, w, src_is_u8, fused, conv_flags)
         return plan
 
-    def _plan_for(self, x: torch.Tensor, src_is_u8: bool, fused: bool = False, slot: int = 0) -> _Plan:
+    def _plan_for(self, x: torch.Tensor, src_is_u8: bool, fused: bool = False, slot: int = 0, conv_flags: int = 0) -> _Plan:
         if src_is_u8:
             b, h, w, _ = x.shape
         else:
             b, _, h, w = x.shape
-        plan = self._get_plan(b, h, w, src_is_u8, fused, slot)
+        plan = self._get_plan(b, h, w, src_is_u8, fused, slot, conv_flags)
         # Frames go through the plan's own input buffer (a D2D copy on the caller's stream: 442 KB per 384x384 u8
         # frame), so the hipGraph captured for this plan is replayed whatever tensor the caller hands in -- a server
         # that uploads a fresh tensor per frame would otherwise re-capture ~35 nodes on every call.  Callers that
@@ -423,10 +498,10 @@ class PoseProposalNet:
         return plan
 
     def input_buffer(self, batch: int, h: int, w: int, u8: bool = True, fused_decode: bool = False,
-                     slot: int = 0) -> torch.Tensor:
+                     slot: int = 0, conv_flags: int = 0) -> torch.Tensor:
         """The plan-owned input tensor for this shape (u8 [B,H,W,3] or f32 [B,3,H,W]): fill it (e.g. an H2D copy
         straight into it) and pass it to forward_u8 / forward to skip the D2D copy."""
-        return self._get_plan(batch, h, w, u8, fused_decode, slot).input
+        return self._get_plan(batch, h, w, u8, fused_decode, slot, conv_flags).input
 
     # ---- forward --------------------------------------------------------------------------------
     def forward(self, input: torch.Tensor) -> torch.Tensor:
@@ -445,20 +520,21 @@ class PoseProposalNet:
 
     __call__ = forward
 
-    def forward_u8(self, frames: torch.Tensor, fused_decode: bool = False, slot: int = 0):
+    def forward_u8(self, frames: torch.Tensor, fused_decode: bool = False, slot: int = 0, conv_flags: int = 0):
         """Fused rt_test.py:97-101 + forward: u8 [B,H,W,3] RGB frames on the device -> head.
 
         With ``fused_decode=True`` the head conv's epilogue runs the decode's limb arg-max itself and the
         17.5 MB/image head is never written: returns ``(unary f32 [B,6K,H,W], keys i64 [B,E,H,W])`` for
         ``Decoder.decode_fused`` (results bit-identical to decoding the materialised head).  Plans of different
         ``slot`` own different output buffers, so a consumer on another stream may still be reading slot 0's
-        outputs while slot 1's forward runs (rt.InferencePipeline)."""
+        outputs while slot 1's forward runs (rt.InferencePipeline).  ``conv_flags``: ppn_conv_desc.flags of the plan's
+        convolutions (lib.PPN_CONV_NO_FILTER_BANK: the choice of a plan that shares the GPU with other lanes)."""
         if not (frames.is_cuda and frames.dtype == torch.uint8 and frames.dim() == 4 and frames.shape[3] == 3):
             raise ValueError("forward_u8 expects a uint8 CUDA tensor [B,H,W,3]")
         if self.training:
             raise RuntimeError("forward_u8 is the inference entry point (folded BN): call model.eval() first")
         x = frames.contiguous()
-        plan = self._plan_for(x, True, fused_decode, slot)
+        plan = self._plan_for(x, True, fused_decode, slot, conv_flags)
         L.check(self._lib.ppn_plan_run(plan.handle, L.current_stream_ptr()), "ppn_plan_run")
         return plan.head
 

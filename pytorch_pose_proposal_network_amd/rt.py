@@ -185,15 +185,15 @@ class MultiLaneInference:
         # csrc/conv64.hip (64 -> 64 3x3 with the filter bank in registers) shortens layer3's launches by ~7 us each when
         # one launch is in flight, but its workgroups own a CU's whole LDS and register file, so another lane's kernels
         # cannot share the CU: with several lanes the generic kernel gives the higher throughput (same-box A/B: 11.04 k
-        # vs 10.96 k images/s with three lanes).  Process-wide, restored by close(); results are bit-identical either way.
-        self._conv64 = lanes <= 1
-        L.check(L.load().ppn_set_conv64_enabled(1 if self._conv64 else 0), "ppn_set_conv64_enabled")
+        # vs 10.96 k images/s with three lanes).  The choice travels in THIS pipeline's plans (ppn_conv_desc.flags), so
+        # other plans, trainers and pipelines of the process -- and a user's PPN_CONV64 setting -- are untouched;
+        # results are bit-identical either way.
+        self._conv_flags = L.PPN_CONV_NO_FILTER_BANK if lanes > 1 else 0
 
     def close(self):
         from . import lib as L
         self.flush()
         L.check(L.load().ppn_set_conv_tile_policy(0), "ppn_set_conv_tile_policy")
-        L.check(L.load().ppn_set_conv64_enabled(1), "ppn_set_conv64_enabled")
 
     def submit(self, frames_u8: torch.Tensor, to_host: bool = False) -> D.DecodeResult:
         """Queue one batch on the next lane.  `frames_u8`: u8 [B,S,S,3] on the device, or in PINNED host memory -- then
@@ -215,12 +215,12 @@ class MultiLaneInference:
             ready.record(main)                               # the frames are complete on the caller's stream
         with torch.cuda.stream(st):
             if on_host:
-                buf = self.model.input_buffer(b, h, w, True, True, slot=k)
+                buf = self.model.input_buffer(b, h, w, True, True, slot=k, conv_flags=self._conv_flags)
                 buf.copy_(frames_u8, non_blocking=True)
                 frames_u8 = buf
             else:
                 st.wait_event(ready)
-            unary, keys = self.model.forward_u8(frames_u8, fused_decode=True, slot=k)
+            unary, keys = self.model.forward_u8(frames_u8, fused_decode=True, slot=k, conv_flags=self._conv_flags)
             res = self.decoders[k].decode_fused(unary, keys)
             if to_host:
                 if self._stages[k] is None:

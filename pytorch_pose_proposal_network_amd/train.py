@@ -198,7 +198,9 @@ class GradNormWeights:
         self.lr, self.alpha, self.betas, self.eps = lr, alpha, betas, eps
         self.step_count = 0
         self.log = torch.zeros(20, dtype=torch.float32, device=device)
-        self._pin, self._pin_event, self._pin_version = None, None, -1
+        # staged host copy of w (host_weights): valid only for the generation it was staged in.  EVERY method that lets a
+        # kernel write `w` through its raw pointer bumps _gen (torch's tensor version counter never sees those writes).
+        self._pin, self._pin_event, self._pin_version, self._pin_gen, self._gen = None, None, -1, -1, 0
 
     def host_weights(self):
         """The five weights as Python floats (coefficients of the loss kernel).  renorm() stages them into pinned memory
@@ -206,17 +208,32 @@ class GradNormWeights:
         of an iteration made the host wait for the whole forward pass it had just enqueued to its own stream and lose
         its run-ahead -- the loss, the head backward and the GradNorm probes were then enqueued at launch latency while
         the GPU idled (~1.5 ms per iteration).  Any in-place write to `w` by the caller invalidates the staged copy."""
-        if self._pin_event is not None and self._pin_version == self.w._version:
+        if self._pin_event is not None and self._pin_gen == self._gen and self._pin_version == self.w._version:
             self._pin_event.synchronize()
             return self._pin.tolist()
         return self.w.tolist()
+
+    def bind(self, view: torch.Tensor):
+        """Move the five weights into `view` (f32[5] on the same device, e.g. the prefix of the trainer's gradient store,
+        so that the last gradient bucket of the data-parallel exchange carries them): same values, same object otherwise."""
+        if view.numel() != 5 or view.dtype != torch.float32 or view.device != self.w.device:
+            raise ValueError("GradNormWeights.bind: f32[5] on the weights' device")
+        view.copy_(self.w)
+        self.w = view
+        self._gen += 1
+
+    def touched(self):
+        """Call after ANY raw-pointer write to `w` outside this class (a direct lib.ppn_gradnorm_* call, a fused kernel):
+        invalidates the staged host copy."""
+        self._gen += 1
 
     def local_step(self, losses: torch.Tensor, gnorm: torch.Tensor, base: torch.Tensor):
         """This rank's optimizerR.step() (main.py:717-768): G_i, C_i, Lgrad, dLgrad/dw, Adam on w -- before the
         all-reduce and the renormalisation.  losses, gnorm, base: f32[5] device tensors."""
         lib = L.load()
         self.step_count += 1
-        self._pin_event = None                               # w changes behind torch's back: staged copy is stale
+        self._gen += 1                                       # w changes behind torch's back: staged copy is stale
+        self._pin_event = None
         L.check(lib.ppn_gradnorm_weight_step(self.w.data_ptr(), _f32(losses, 5, "losses"), _f32(gnorm, 5, "gnorm"),
                                              _f32(base, 5, "base"), self.alpha, self.exp_avg.data_ptr(),
                                              self.exp_avg_sq.data_ptr(), self.lr, self.betas[0], self.betas[1],
@@ -227,13 +244,14 @@ class GradNormWeights:
     def renorm(self, world: int = 1):
         """main.py:769-777 after the SUM all-reduce: w / world, clamp, renormalise to sum 5."""
         L.check(L.load().ppn_gradnorm_renorm(self.w.data_ptr(), world, L.current_stream_ptr()), "ppn_gradnorm_renorm")
+        self._gen += 1
         if self.w.is_cuda:
             if self._pin is None:
                 self._pin = torch.empty(5, dtype=torch.float32, pin_memory=True)
             self._pin.copy_(self.w, non_blocking=True)
             self._pin_event = torch.cuda.Event()
             self._pin_event.record()
-            self._pin_version = self.w._version
+            self._pin_version, self._pin_gen = self.w._version, self._gen
 
     def step(self, losses: torch.Tensor, gnorm: torch.Tensor, base: torch.Tensor, group=None):
         """local_step, SUM all-reduce of the five weights over `group` (main.py:769-771), renorm.
@@ -358,7 +376,10 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, in_hw, stride: int = 1, dilati
     # measured at batch 32 (tools/bench_dgrad_s2.py, bit-identical results): 1x1 projections 119 -> 51 and 74 -> 37 us,
     # layer2 (16 -> 32) 402 -> 359 us; the 3x3 layers with >= 32 input channels do not gain (181 -> 187, 106 -> 130 us:
     # four short-K launches and four strided copies cost what the 2.25x fewer FLOPs save) and keep the zero-upsampled form
+    # With a skip-path gradient to add, the 16-bit modes keep the zero-upsampled form: its epilogue adds in f32 and rounds
+    # ONCE, whereas the parity form could only add after its sub-convolutions have been rounded (two roundings).
     if (_S2_PARITY and stride == 2 and dilation == 1 and pad == k // 2 and (k == 1 or (k == 3 and cin <= 16)) and
+            (add is None or dy.dtype == torch.float32) and
             Ho == (H + 2 * pad - k) // 2 + 1 and Wo == (W + 2 * pad - k) // 2 + 1):
         return _dgrad_stride2(dy, w, H, W, add)
     hup, wup = H + 2 * pad - eff + 1, W + 2 * pad - eff + 1
@@ -465,9 +486,19 @@ class BucketedAllReduce:
     returns the 1/world factor the optimiser kernel applies (reduce_tensor of main.py:1233-1238 without its clone and
     divide passes).  Without an initialised process group (or world size 1) everything is a no-op."""
 
-    def __init__(self, flat: torch.Tensor, bucket_elems: int = 8 * 1024 * 1024, group=None):
+    def __init__(self, flat: torch.Tensor, bucket_elems: int = 8 * 1024 * 1024, group=None, store=None, before_last=None):
+        """store: the allocation `flat` is a trailing view of (trainer: 16 leading floats whose first five are the GradNorm
+        task weights); the LAST bucket -- the one that starts at flat[0] -- is then issued from store[0], i.e. the prefix
+        rides on it.  before_last(): called once right before that bucket is issued (the task weights' local step)."""
         import torch.distributed as dist
         self.flat, self.group = flat, group
+        self.store, self.before_last = store, before_last
+        self.prefix = 0
+        if store is not None:
+            self.prefix = flat.storage_offset() - store.storage_offset()
+            if (self.prefix < 0 or store.numel() != self.prefix + flat.numel() or
+                    store.untyped_storage().data_ptr() != flat.untyped_storage().data_ptr()):
+                raise ValueError("BucketedAllReduce: `flat` must be the trailing view of `store`")
         # PPN_FORCE_DP=1: run the exchange even in a one-rank group (a SUM over one rank is the identity) -- how the
         # RCCL code path (async bucketed all-reduce against side-stream weight gradients) is exercised on a 1-GPU box
         self.enabled = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or _force_dp())
@@ -489,8 +520,11 @@ class BucketedAllReduce:
                 before_issue()
                 called = True
             lo, hi = self.bounds[self.next + 1], self.bounds[self.next]
-            self.handles.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group,
-                                                async_op=True))
+            buf = self.flat[lo:hi]
+            if lo == 0 and self.store is not None and self.before_last is not None:
+                self.before_last()                                    # e.g. the task weights' local step into the prefix
+                buf = self.store[:self.prefix + hi]                   # prefix + first bucket: one message
+            self.handles.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
             self.next += 1
 
     def finish(self, before_issue=None) -> float:

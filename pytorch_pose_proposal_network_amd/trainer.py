@@ -53,7 +53,12 @@ class PPNTrainer:
         shapes = dict(spec)
         n_total = sum(int(np.prod(shapes[n])) for n in self.param_names)
         self.flat = torch.zeros(n_total, dtype=torch.float32, device=self.device)
-        self.grad = torch.zeros(n_total, dtype=torch.float32, device=self.device)
+        # The flat gradient buffer sits behind a 16-float prefix of its own allocation: the five GradNorm task weights
+        # live in prefix[0:5] (GradNormWeights.bind), so the LAST gradient bucket of the data-parallel exchange -- the
+        # lowest addresses, issued when the backward is complete -- carries them along and the separate 20-byte,
+        # latency-bound all-reduce of main.py:769-771 disappears (one collective fewer per step).
+        self._grad_store = torch.zeros(16 + n_total, dtype=torch.float32, device=self.device)
+        self.grad = self._grad_store[16:]
         self.P: Dict[str, torch.Tensor] = {}
         self.G: Dict[str, torch.Tensor] = {}
         self.offset: Dict[str, int] = {}
@@ -77,6 +82,10 @@ class PPNTrainer:
         self.opt = T.FlatAdam(self.flat, lr=lr)                               # optimizerM, main.py:278
         # weight_model + optimizerR: the reference gives both optimisers args.lr (main.py:278-279)
         self.task = T.GradNormWeights(self.device, lr=lr if lr_weights is None else lr_weights, alpha=alpha)
+        # an ALIAS of store[0:5], not a view: a view would share the store's version counter, and every torch op on a
+        # gradient slice would then invalidate the staged host copy of the weights (GradNormWeights.host_weights)
+        self.task.bind(torch.empty(0, dtype=torch.float32, device=self.device).set_(
+            self._grad_store.untyped_storage(), self._grad_store.storage_offset(), (5,), (1,)))
         self.criterion = PPNLoss(insize=insize, outsize=(insize[0] // 16, insize[1] // 16))
         self.base: Optional[torch.Tensor] = None
         self._tape = None
@@ -736,11 +745,14 @@ class PPNTrainer:
             base /= dist.get_world_size(group)
         self.base = base
 
-    def local_pass(self, x: torch.Tensor, targets: Dict[str, torch.Tensor], group=None):
+    def local_pass(self, x: torch.Tensor, targets: Dict[str, torch.Tensor], group=None, w_step=None):
         """Everything of main.py:664-759 that happens on this rank's shard: train-mode forward, PPNLoss fwd+bwd, the
         backward pass (with the second-order term when enabled) into self.grad -- its 32 MB buckets all-reduced
         (SUM) over `group` while the backward runs -- and the five probe-gradient norms.
-        Returns (losses f32[5], gnorm f32[5], scale = 1/world for the optimiser)."""
+        Returns (losses f32[5], gnorm f32[5], scale = 1/world for the optimiser).
+        `w_step(losses, gnorm)` (train_step passes it): where the exchange is enabled and the probe norms are known before
+        the last bucket goes out (the second-order path), it is called right before that bucket is issued so that the task
+        weights' local step can ride on it; it is NOT called otherwise (the caller then steps and all-reduces them)."""
         head = self.forward(x)
         ev_head = torch.cuda.Event()
         ev_head.record(torch.cuda.current_stream(self.device))        # the probe passes need the head, not the loss
@@ -802,7 +814,10 @@ class PPNTrainer:
                       stream=pst if pst is not main else None, launch_probes=launch_probes)
             if dz_pre is not None:
                 so["dz"] = (dz_pre, dbsum)
-            exchange = T.BucketedAllReduce(self.grad, group=group)
+            # the task weights' local step (it needs the probe norms, which the head backward has produced long before
+            # the last bucket) runs just before the LAST gradient bucket is issued and rides on it
+            before_last = (lambda: w_step(losses, so["gnorm"])) if w_step is not None else None
+            exchange = T.BucketedAllReduce(self.grad, group=group, store=self._grad_store, before_last=before_last)
             self.backward(ghead, exchange, so=so)
             scale = exchange.finish()
             gn = so["gnorm"]
@@ -862,7 +877,16 @@ class PPNTrainer:
 
     def train_step(self, x: torch.Tensor, targets: Dict[str, torch.Tensor], group=None):
         """main.py:664-777 for one minibatch shard.  Returns (losses f32[5], task weights f32[5]) device tensors."""
-        losses, gn, scale = self.local_pass(x, targets, group)
-        self.task.step(losses, gn, self.base, group=group)               # optimizerR.step + all-reduce + renormalise
+        rode = []
+
+        def w_step(losses_, gn_):
+            self.task.local_step(losses_, gn_, self.base)                # optimizerR.step on this rank's values ...
+            rode.append(True)                                            # ... summed over the ranks with the last bucket
+
+        losses, gn, scale = self.local_pass(x, targets, group, w_step=w_step)
+        if rode:
+            self.task.renorm(int(round(1.0 / scale)))                    # / world, clamp, renormalise (main.py:772-777)
+        else:
+            self.task.step(losses, gn, self.base, group=group)           # optimizerR.step + all-reduce + renormalise
         self.opt.step(self.grad, grad_scale=scale)                       # optimizerM.step
         return losses, self.task.w

@@ -1,0 +1,80 @@
+"""Fixture generator: what the EMULATED-STORAGE ORACLE (oracle/fused_ref.py: the fused program with weights and stored
+activations rounded to bf16 / f16 exactly where the HIP 16-bit modes round them, f32 accumulation, torch-CPU) returns on
+the two reference-generated end-to-end fixtures -- its distance to the reference head, the people it decodes, how many
+of the REFERENCE pipeline's people those reproduce, and its AP against them.
+
+    python tests/golden/make_emulated.py          # ~4 min on 8 cores; writes tests/golden/e2e_emulated.npz
+
+Why: a 16-bit mode cannot meet north_star's 1e-4 / bit-exact tolerance by construction; the requirement a 16-bit KERNEL
+can be held to is "no worse than a correct implementation of the same storage policy".  tests/test_e2e_gpu.py gates the
+HIP bf16 / f16 pipelines against these numbers with stated factors instead of against their own past measurements.
+Runs on the CPU only and does not need /root/reference (the reference's people are in the e2e fixtures)."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import decode_ref as D, forward_ref as Fr, fused_ref  # noqa: E402
+from pytorch_pose_proposal_network_amd import decode, evaluate, prng, synth  # noqa: E402
+
+MODES = {"bfloat16": torch.bfloat16, "float16": torch.float16}
+FIXTURES = ["e2e_d22_384", "e2e_tuned_d22_384"]
+
+
+def setup(fixture):
+    g = np.load(os.path.join(ROOT, "tests", "golden", fixture + ".npz"))
+    arch, size, batch = str(g["arch"]), int(g["size"]), int(g["batch"])
+    st = np.load(os.path.join(ROOT, "pytorch_pose_proposal_network_amd", "data", f"bn_calib_{arch}_seed0.npz"))
+    sd = synth.make_state_dict(arch, int(g["seed_w"]), bn_stats={k: st[k] for k in st.files})
+    for k in g.files:
+        if k.startswith("override/"):
+            sd[k[len("override/"):]] = g[k]
+    u8 = prng.u8_frames(int(g["seed_in"]), batch, (size, size))
+    exp = [{k: g[f"{i}/{k}"] for k in ("n", "kp_cell", "limb_arg", "bbox", "score")} for i in range(batch)]
+    return sd, arch, size, u8, exp
+
+
+def emulate(sd, arch, size, u8, exp, mode, frames=None):
+    """(head error max, mean vs the f32 oracle head == the reference head), people lists, agreement totals, 8 AP values."""
+    idx = range(len(exp)) if frames is None else frames
+    x = torch.as_tensor(Fr.normalize_u8(u8))
+    emax, esum, n_el, tot, people = 0.0, 0.0, 0, np.zeros(5, np.int64), []
+    for i in idx:
+        ref = Fr.forward_ref(sd, x[i:i + 1], arch).numpy()
+        head = fused_ref.fused_forward_ref(sd, x[i:i + 1], arch, fuse_stem="all", emulate_dtype=MODES[mode]).numpy()
+        d = np.abs(head - ref)
+        emax, esum, n_el = max(emax, float(d.max())), esum + float(d.sum(dtype=np.float64)), n_el + d.size
+        p = D.decode_ref(head[0], insize=(size, size))
+        people.append(p)
+        tot += np.array(decode.people_agreement(exp[i], p))
+    return emax, esum / n_el, people, tot
+
+
+def main():
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    out = {}
+    for fx in FIXTURES:
+        sd, arch, size, u8, exp = setup(fx)
+        self_ap = evaluate.ap_against_people(exp, exp)
+        out[f"{fx}/ap_self"] = np.array(self_ap)
+        for mode in MODES:
+            emax, emean, people, tot = emulate(sd, arch, size, u8, exp, mode)
+            ap = evaluate.ap_against_people(exp, people)
+            out[f"{fx}/{mode}/head_err"] = np.array([emax, emean])
+            out[f"{fx}/{mode}/agreement"] = tot           # people, exact, same root, kp cells equal, kp cells compared
+            out[f"{fx}/{mode}/ap"] = np.array(ap)
+            for i, p in enumerate(people):                # frame 0's people: re-checked by the CPU test
+                if i == 0:
+                    out[f"{fx}/{mode}/frame0/n"] = np.int64(p["n"])
+                    out[f"{fx}/{mode}/frame0/kp_cell"] = p["kp_cell"]
+                    out[f"{fx}/{mode}/frame0/limb_arg"] = p["limb_arg"]
+            print(f"{fx} {mode}: head err max {emax:.4f} mean {emean:.5f}; people exact {tot[1]}/{tot[0]}, same root "
+                  f"{tot[2]}, kp {tot[3]}/{tot[4]}; AP total {ap[-1]:.2f} (ceiling {self_ap[-1]:.2f})", flush=True)
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "e2e_emulated.npz"), **out)
+
+
+if __name__ == "__main__":
+    main()

@@ -15,10 +15,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(extra, env_extra=None, timeout=420):
+def _run(extra, env_extra=None, timeout=420, gpus=2):
     env = dict(os.environ, PPN_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("OMP_NUM_THREADS", None)                            # bench.py's self-launch divides the cores itself
     env.update(env_extra or {})
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--windows", "2",
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "3", "--warmup", "1", "--windows", "2",
            "--no-extras", "--no-cpu-baseline"] + extra
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout, cwd=ROOT)
     return p
@@ -46,6 +47,29 @@ def test_self_launched_two_rank_training_line():
     assert r["n_gpus"] == 2 and r["rccl_ranks"] == 0 and r["value"] > 0
     assert len(r["losses"]) == 5 and all(v == v for v in r["losses"])         # finite, not NaN
     assert abs(sum(r["task_weights"]) - 5.0) < 1e-2                              # renormalised to sum 5 (main.py:773-777)
+
+
+@pytest.mark.parametrize("workload", ["inference", "train"])
+def test_self_launched_five_rank_rehearsal(workload):
+    """The widest N > 1 rehearsal one GPU box allows: `python bench.py --gpus 5` (the pool's process guard admits at most
+    SIX processes on a card -- this pytest process holds the GPU too -- so the driver's N = 8 cannot be started here; world
+    8 itself is rehearsed on CPU tensors by tests/test_host_cpu.py::test_task_weights_ride_on_the_last_gradient_bucket).
+    Five ranks over gloo share cuda:0, four frames each: one JSON line, the self-launch gave each rank cpu_count // 5 OpenMP threads,
+    the per-rank host submit time is in the line; training: finite losses, task weights renormalised to sum 5 after they
+    rode on the last gradient bucket (/root/reference/main.py:240-245,289,769-771,1233-1238)."""
+    p = _run(["--workload", workload, "--batch", "4"], gpus=5, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 5 and r["rccl_ranks"] == 0 and r["scaling"] == "weak" and r["steps"] == 3 and r["value"] > 0
+    assert r["host"]["omp_num_threads"] == str(max(1, (os.cpu_count() or 8) // 5))
+    assert 0 < r["host"]["submit_ms_per_step_max_over_ranks"] < 1e4
+    if workload == "train":
+        assert len(r["losses"]) == 5 and all(v == v for v in r["losses"])
+        assert abs(sum(r["task_weights"]) - 5.0) < 1e-2
+    else:
+        assert r["config"]["frames_per_gpu"] == 4 and r["batch_consistency"]["ok"]
 
 
 @pytest.mark.parametrize("workload", ["inference", "train"])

@@ -412,3 +412,29 @@ def test_fused_stem_equals_layer_by_layer(shape, u8):
     got_y, got_u = raw_f.float().cpu().permute(0, 3, 1, 2).double(), act_f.float().cpu().permute(0, 3, 1, 2).double()
     assert float((got_y - y).abs().max()) <= 4e-2 * max(1.0, float(y.abs().max()))
     assert float((got_u - u).abs().max()) <= 4e-2 * max(1.0, float(u.abs().max()))
+
+
+def test_f16_stores_stay_finite_past_65504():
+    """The f16 mode stores RAW pre-activation residual streams in IEEE half: a value past 65504 must be stored as the
+    largest finite half, not +-inf (an inf becomes a NaN in the next residual add / BN affine and a garbage decode).
+    Both outputs of the chunked epilogue, the single-output fast epilogue and the small-channel kernel."""
+    from pytorch_pose_proposal_network_amd import lib as L
+    g = torch.Generator().manual_seed(3)
+    for cin, cout in ((64, 128), (32, 64)):
+        x = torch.randn(2, cin, 12, 12, generator=g) * 100.0
+        w = torch.randn(cout, cin, 3, 3, generator=g)
+        res = torch.randn(2, cout, 12, 12, generator=g) * 1000.0
+        # dual-output launch with a residual (chunked f32 epilogue): |v| reaches ~2e5 here
+        raw, act = run_conv(x, w, L.PPN_F16, pad=1, s1=torch.full((cout,), 16.0), residual=res, s2=torch.full((cout,), 2.0),
+                            act2=1, want_act=True)
+        ref = F.conv2d(x.half().float(), w.half().float(), None, 1, 1) * 16.0 + res.half().float()
+        assert float(ref.abs().max()) > 1e5                                   # the case really overflows half
+        assert torch.isfinite(raw).all() and torch.isfinite(act).all()
+        over = ref.abs() > 70000.0
+        assert torch.equal(raw[over].abs(), torch.full_like(raw[over], 65504.0))
+        assert torch.equal(torch.sign(raw[over]), torch.sign(ref[over]))
+        ok = ref.abs() < 60000.0
+        assert float((raw[ok] - ref[ok]).abs().max()) <= 3e-3 * 60000.0
+        # single-output launch (the bf16/f16 fast epilogue where the tile has one)
+        raw1, _ = run_conv(x, w, L.PPN_F16, pad=1, s1=torch.full((cout,), 16.0))
+        assert torch.isfinite(raw1).all() and float(raw1.abs().max()) == 65504.0

@@ -152,67 +152,71 @@ def test_f32_pipeline_reproduces_reference_people_up_to_knife_edges(fixture):
     assert tot["exact"] >= 0.97 * tot["people"]
 
 
+def _emulated(fixture, mode):
+    """What the EMULATED-STORAGE ORACLE (oracle/fused_ref.py with this mode's roundings, torch-CPU, f32 accumulation) returns
+    on this fixture: tests/golden/e2e_emulated.npz, written by tests/golden/make_emulated.py and re-checked on the CPU by
+    tests/test_oracle.py.  Keys: agreement (people, exact, same root, kp equal, kp compared), ap[8], ap_self[8], head_err."""
+    z = np.load(os.path.join(ROOT, "tests", "golden", "e2e_emulated.npz"))
+    return {k: z[f"{fixture}/{mode}/{k}"] for k in ("agreement", "ap", "head_err")} | {"ap_self": z[f"{fixture}/ap_self"]}
+
+
+# ---- 16-bit modes: gates DERIVED from the requirement, not from this implementation's past measurements ---------------
+# A 16-bit storage policy cannot meet north_star's 1e-4 / bit-exact tolerance by construction (bf16 keeps 8 significant
+# bits); what a 16-bit KERNEL can be required to do is to be no worse than a correct implementation of the same policy.
+# That implementation is the emulated-storage oracle; the HIP pipeline may fall short of it only by what two correct
+# implementations differ by -- different f32 summation orders flip single 16-bit roundings, which this chaotic random
+# network then amplifies like any other storage noise:
+#   people reproduced exactly / same root   >= 85 % of the oracle's own count
+#   keypoint-cell agreement                 >= the oracle's fraction - 0.02
+#   total AP against the reference people   >= the oracle's AP - (15 % of the AP the policy itself loses + 2 points;
+#                                              one person on these 8 frames moves the total by ~0.4-1.3 points)
+PEOPLE_SHARE, KP_SLACK, AP_LOSS_SHARE, AP_SLACK = 0.85, 0.02, 0.15, 2.0
+
+
 @pytest.mark.parametrize("fixture", FIXTURES)
 @pytest.mark.parametrize("mode", ["bfloat16", "float16"])
-def test_bf16_pipeline_agreement_with_reference_people(mode, fixture):
-    """bf16 is the benchmarked mode: how many of the reference's people it returns (stated, gated, and repeated in
-    bench.py's JSON line); f16 (same MFMA rate, 3 more mantissa bits) beside it."""
-    from pytorch_pose_proposal_network_amd import rt
+def test_16bit_pipeline_no_worse_than_emulated_oracle(mode, fixture):
+    """bf16 is BASELINE configs[1]'s dtype (the benchmarked mode), f16 runs at the same MFMA rate with 3 more mantissa
+    bits: people and AP of each HIP pipeline against the reference pipeline's people, gated relative to what the
+    emulated-storage oracle of the same mode achieves (rule above); bench.py prints the same numbers."""
+    from pytorch_pose_proposal_network_amd import evaluate, rt
     g, sd, net, u8, exp, arch = _setup(mode, fixture)
     got = rt.inference_batch(torch.from_numpy(u8).cuda(), net).to_host()
     tot = np.zeros(5, np.int64)
     for i in range(len(exp)):
         tot += np.array(_agreement(exp[i], got[i]))
-        print(f"frame {i}: reference {exp[i]['n']} people, {mode} {got[i]['n']}")
     n, exact, same_root, kp_eq, kp_all = (int(v) for v in tot)
-    print(f"{fixture}: {mode} mode vs reference people: {exact}/{n} exact ({exact / n:.3f}), same root {same_root}/{n} "
-          f"({same_root / n:.3f}), keypoint cells among same-root people {kp_eq}/{kp_all} ({kp_eq / max(kp_all, 1):.3f})")
-    min_root, min_kp, min_exact = GATES[(fixture, mode)]
-    assert same_root >= min_root * n and kp_eq >= min_kp * kp_all and exact >= min_exact * n
+    emu = _emulated(fixture, mode)
+    en, eexact, esame, ekp, ekpall = (int(v) for v in emu["agreement"])
+    ap = np.array(evaluate.ap_against_people(exp, got))
+    ceiling, eap = float(emu["ap_self"][-1]), float(emu["ap"][-1])
+    ap_floor = eap - (AP_LOSS_SHARE * (ceiling - eap) + AP_SLACK)
+    print(f"{fixture} {mode}: HIP vs reference people: exact {exact}/{n}, same root {same_root}/{n}, keypoint cells "
+          f"{kp_eq}/{kp_all} ({kp_eq / max(kp_all, 1):.3f}), total AP {ap[-1]:.2f} | emulated oracle: exact {eexact}/{en}, "
+          f"same root {esame}, cells {ekp}/{ekpall} ({ekp / ekpall:.3f}), AP {eap:.2f} (ceiling {ceiling:.2f}) -> AP floor {ap_floor:.2f}")
+    assert n == en
+    assert exact >= PEOPLE_SHARE * eexact and same_root >= PEOPLE_SHARE * esame
+    assert kp_eq / max(kp_all, 1) >= ekp / ekpall - KP_SLACK
+    assert ap[-1] >= ap_floor, (ap, eap, ceiling)
 
 
 @pytest.mark.parametrize("fixture", FIXTURES)
-def test_ap_of_each_mode_against_reference_people(fixture):
-    """What a reduced-precision mode costs in the TASK metric (BASELINE metric "PCKh@0.5 vs ref"): the reference
-    pipeline's people taken as ground truth (keypoint = box centre, head box = instance box), the HIP pipeline's people
-    scored with the reference's own matcher and metric (evaluate.evaluation == datatest.evaluation,
-    /root/reference/datatest.py:278-369, eval_helpers.py:300-468).  On these dense synthetic crowds the metric's ceiling
-    -- the reference people scored against themselves -- is below 100 (overlapping people tie in assignGTmulti); f32
-    must reach that ceiling up to the knife edges, bf16 is gated just under its measured value."""
+def test_f32_ap_reaches_the_ceiling(fixture):
+    """The TASK metric of the parity mode (BASELINE metric "PCKh@0.5 vs ref"): the reference pipeline's people taken as
+    ground truth (keypoint = box centre, head box = instance box), the HIP f32 pipeline's people scored with the
+    reference's own matcher and metric (evaluate.evaluation == datatest.evaluation, /root/reference/datatest.py:278-369,
+    eval_helpers.py:300-468).  On these dense synthetic crowds the metric's ceiling -- the reference people scored
+    against themselves -- is below 100 (overlapping people tie in assignGTmulti); f32 must reach that ceiling up to the
+    knife edges (one person moves a joint group's AP by <= 1 point)."""
     from pytorch_pose_proposal_network_amd import evaluate, rt
-    names = ["head", "shoulder", "elbow", "wrist", "hip", "knee", "ankle", "total"]
-    aps = {}
-    for mode in ("float32", "bfloat16", "float16"):
-        g, sd, net, u8, exp, arch = _setup(mode, fixture)
-        got = rt.inference_batch(torch.from_numpy(u8).cuda(), net).to_host()
-        aps[mode] = np.array(evaluate.ap_against_people(exp, got))
-        if "self" not in aps:
-            aps["self"] = np.array(evaluate.ap_against_people(exp, exp))
-    for k, v in aps.items():
-        print(f"{fixture}: AP vs reference people, {k:9s}: " + ", ".join(f"{n} {x:.2f}" for n, x in zip(names, v)))
-    assert np.all(np.abs(aps["float32"] - aps["self"]) <= AP_F32_MAX_GAP), (aps["float32"], aps["self"])
-    max_bf16, max_f16 = AP_MAX_LOSS[fixture]
-    assert aps["bfloat16"][-1] >= aps["self"][-1] - max_bf16, (aps["bfloat16"], aps["self"])
-    assert aps["float16"][-1] >= aps["self"][-1] - max_f16, (aps["float16"], aps["self"])
+    g, sd, net, u8, exp, arch = _setup("float32", fixture)
+    got = rt.inference_batch(torch.from_numpy(u8).cuda(), net).to_host()
+    ap, ceiling = np.array(evaluate.ap_against_people(exp, got)), np.array(evaluate.ap_against_people(exp, exp))
+    print(f"{fixture}: AP vs reference people, f32 {np.round(ap, 2).tolist()} ceiling {np.round(ceiling, 2).tolist()}")
+    assert np.all(np.abs(ap - ceiling) <= AP_F32_MAX_GAP), (ap, ceiling)
 
 
-# AP gates (see the test above): f32 within 1 point of the ceiling per joint group (knife edges move single people);
-# bf16 total AP at most this far below the ceiling (measured on MI355X, round 3: see profiles/README.md)
 AP_F32_MAX_GAP = 1.0
-AP_MAX_LOSS = {"e2e_d22_384": (45.0, 10.0),          # measured losses of total AP: bf16 41.2, f16 7.6
-               "e2e_tuned_d22_384": (50.0, 11.0)}    # ceiling 92.2: bf16 46.6 (loss 45.6), f16 83.8 (loss 8.4)
-
-# bf16 gates: measured on MI355X (see profiles/README.md, round 2), set just below the measurement.  The synthetic
-# checkpoint is a randomly initialised network: ~490 of 576 cells are root candidates with near-equal scores, so which
-# of two overlapping roots survives NMS is decided by differences far below bf16 resolution.
-BF16_MIN_SAME_ROOT, BF16_MIN_KP = 0.62, 0.92            # measured 0.650 / 0.937 (95 of 260 people exact)
-# f16 (same MFMA rate, 11 significant bits): measured 0.969 / 0.9958, 233 of 260 people exact
-F16_MIN_SAME_ROOT, F16_MIN_KP, F16_MIN_EXACT = 0.95, 0.99, 0.85
-# (same root, keypoint cells among same-root people, reproduced exactly) as fractions of the reference people
-GATES = {("e2e_d22_384", "bfloat16"): (BF16_MIN_SAME_ROOT, BF16_MIN_KP, 0.33),
-         ("e2e_d22_384", "float16"): (F16_MIN_SAME_ROOT, F16_MIN_KP, F16_MIN_EXACT),
-         ("e2e_tuned_d22_384", "bfloat16"): (0.70, 0.92, 0.40),      # measured 0.737 / 0.938 / 0.434 (33 of 76)
-         ("e2e_tuned_d22_384", "float16"): (0.94, 0.99, 0.88)}       # measured 0.961 / 0.997 / 0.921 (70 of 76)
 
 
 def test_d54_384_f32_head_vs_reference(golden_dir):

@@ -14,9 +14,30 @@ from pytorch_pose_proposal_network_amd import prng, synth
 pytestmark = pytest.mark.gpu
 
 F32_TOL = 1e-4
-# bf16 mode (bf16 weights + stored activations, f32 accumulate/epilogue/head) on the synthetic checkpoint:
-BF16_MAX_TOL, BF16_MEAN_TOL = 0.15, 0.02            # vs the fp32 reference head (quantisation noise included)
-BF16_EMU_MAX_TOL, BF16_EMU_MEAN_TOL = 0.06, 0.006   # vs the oracle with bf16 storage emulated
+# 16-bit modes (16-bit weights + stored activations, f32 accumulate / epilogue / head).  They cannot meet 1e-4 by
+# construction; the gates are DERIVED from the emulated-storage oracle (oracle/fused_ref.py: the same roundings at the same
+# points, torch-CPU) computed inside the test, not from this implementation's past measurements.  With
+# E = |emulated oracle - fp32 reference| (what the storage policy itself costs on this checkpoint):
+#   |HIP - reference|        mean <= 1.25 x mean(E), 99.99th percentile <= 1.5 x that of E, max <= 2 x max(E)
+#                                                              -- the kernels add no error class of their own
+#   |HIP - emulated oracle|  mean <= mean(E), 99.99th percentile <= that of E, max <= 1.5 x max(E)
+#                               -- two correct implementations of one policy differ by single flipped roundings
+#                               (summation order), amplified like the policy's own noise: their distance must stay
+#                               below the policy's distance to the reference
+# (the maximum over 10^5..10^6 head elements is a tail statistic of two samples of one distribution: hence its own factor)
+REF_FACTORS, EMU_FACTORS = (1.25, 1.5, 2.0), (1.0, 1.0, 1.5)
+
+
+def _assert_16bit(de, dr, dq, what):
+    """de = |HIP - emulated|, dr = |HIP - reference|, dq = |emulated - reference| (same positions)."""
+    def stats(d):
+        return float(d.mean()), float(np.quantile(d, 0.9999)), float(d.max())
+    sq = stats(dq)
+    for d, fac, name in ((dr, REF_FACTORS, "the reference"), (de, EMU_FACTORS, "the emulated oracle")):
+        sd_ = stats(d)
+        assert all(a <= f * b for a, f, b in zip(sd_, fac, sq)), \
+            (f"{what}: HIP is mean {sd_[0]:.5f} / p99.99 {sd_[1]:.4f} / max {sd_[2]:.4f} from {name}; the storage policy "
+             f"itself is {sq[0]:.5f} / {sq[1]:.4f} / {sq[2]:.4f} from the reference (factors {fac})")
 
 
 def _model(arch, g, dtype):
@@ -80,46 +101,32 @@ def _bf16_case(golden_dir, name, mode="bfloat16"):
     torch.set_num_threads(min(16, os.cpu_count() or 1))   # a 1-GPU box owns a 16-core share
     emu = fused_ref.fused_forward_ref(sd, Fr.normalize_u8(u8), arch, fuse_stem="all" if mode == "float16" else False,
                                       emulate_dtype=torch.float16 if mode == "float16" else torch.bfloat16).numpy()
-    de = np.abs(head - emu)
     if "head" in g.files:
-        dr = np.abs(head - g["head"])
-    else:
-        dr = np.abs(head.reshape(-1)[g["head_idx"]] - g["head_val"])
+        de, dr, dq = np.abs(head - emu), np.abs(head - g["head"]), np.abs(emu - g["head"])
+    else:                                                  # 384x384 fixtures hold sampled positions of the reference head
+        hv, ev = head.reshape(-1)[g["head_idx"]], emu.reshape(-1)[g["head_idx"]]
+        de, dr, dq = np.abs(hv - ev), np.abs(hv - g["head_val"]), np.abs(ev - g["head_val"])
     print(f"{name} {mode}: vs emulated oracle max {de.max():.4f} mean {de.mean():.5f} | "
-          f"vs fp32 reference max {dr.max():.4f} mean {dr.mean():.5f}")
-    return de, dr
+          f"vs fp32 reference max {dr.max():.4f} mean {dr.mean():.5f} | emulated oracle vs reference max {dq.max():.4f} "
+          f"mean {dq.mean():.5f}")
+    return de, dr, dq
 
 
-def test_forward_bf16_d22_96(golden_dir):
-    de, dr = _bf16_case(golden_dir, "forward_d22_96")
-    assert de.max() <= BF16_EMU_MAX_TOL and de.mean() <= BF16_EMU_MEAN_TOL
-    assert dr.max() <= BF16_MAX_TOL and dr.mean() <= BF16_MEAN_TOL
-
-
-def test_forward_bf16_d22_384(golden_dir):
-    de, dr = _bf16_case(golden_dir, "forward_d22_384")
-    assert de.max() <= BF16_EMU_MAX_TOL and de.mean() <= BF16_EMU_MEAN_TOL
-    assert dr.max() <= BF16_MAX_TOL and dr.mean() <= BF16_MEAN_TOL
-
-
-# f16 mode (IEEE half weights + stored activations, 11 significant bits instead of bf16's 8; f32 accumulate / epilogue /
-# head): measured on MI355X (round 3) and gated just above -- the head is ~8x closer to the fp32 reference than bf16's
-F16_MAX_TOL, F16_MEAN_TOL = 0.02, 0.0025            # measured 0.0130 / 0.00169 (bf16: 0.101 / 0.0128)
-F16_EMU_MAX_TOL, F16_EMU_MEAN_TOL = 0.009, 0.001     # measured 0.0060 / 0.00066 vs the oracle with f16 storage emulated
-
-
+@pytest.mark.parametrize("mode", ["bfloat16", "float16"])
 @pytest.mark.parametrize("name", ["forward_d22_96", "forward_d22_384"])
-def test_forward_f16_d22(golden_dir, name):
-    de, dr = _bf16_case(golden_dir, name, "float16")
-    assert de.max() <= F16_EMU_MAX_TOL and de.mean() <= F16_EMU_MEAN_TOL
-    assert dr.max() <= F16_MAX_TOL and dr.mean() <= F16_MEAN_TOL
+def test_forward_16bit_d22(golden_dir, name, mode):
+    """Round-3 measurements for orientation (not gates): bf16 0.101 max / 0.0128 mean from the reference and 0.06 / 0.006
+    from the emulated oracle; f16 0.013 / 0.0017 and 0.006 / 0.00066."""
+    de, dr, dq = _bf16_case(golden_dir, name, mode)
+    _assert_16bit(de, dr, dq, f"{name} {mode}")
 
 
-def test_forward_bf16_d54_96(golden_dir):
-    # this fixture amplifies rounding 20x more than D-22 (its fp32 noise floor is 2.8e-4): only the
-    # emulated-bf16 comparison is meaningful
-    de, dr = _bf16_case(golden_dir, "forward_d54_96")
-    assert de.mean() <= 20 * BF16_EMU_MEAN_TOL
+@pytest.mark.parametrize("mode", ["bfloat16", "float16"])
+def test_forward_16bit_d54_96(golden_dir, mode):
+    # this fixture amplifies rounding ~20x more than D-22 (its fp32 noise floor is 2.8e-4, forward_d54_96.npz
+    # `ref_f32_noise`): the same derived rule applies -- the emulated oracle's own distance sets the scale
+    de, dr, dq = _bf16_case(golden_dir, "forward_d54_96", mode)
+    _assert_16bit(de, dr, dq, f"forward_d54_96 {mode}")
 
 
 def test_forward_batch_independence_and_replay(golden_dir):
@@ -194,7 +201,11 @@ def test_fused_stem_variant(golden_dir, dtype):
         x = torch.from_numpy(synth.normalized_frames(u8)).cuda()
         assert np.abs(m(x).cpu().numpy() - g["head"]).max() <= F32_TOL
     else:
-        assert d.max() <= BF16_MAX_TOL and d.mean() <= BF16_MEAN_TOL
+        # layer0+layer1 fused keeps one more tensor on chip: held to the emulated oracle of the SAME fusion
+        from oracle import forward_ref as Fr, fused_ref
+        emu = fused_ref.fused_forward_ref(sd, Fr.normalize_u8(u8), "drn_d_22", fuse_stem=True,
+                                          emulate_dtype=torch.bfloat16).numpy()
+        _assert_16bit(np.abs(head - emu), d, np.abs(emu - g["head"]), "fuse_stem=True bf16")
 
 
 def test_train_eval_toggle_on_the_same_object(golden_dir):
@@ -263,21 +274,16 @@ def test_non_square_inputs(golden_dir, hw):
     d16, de16 = np.abs(heads["float16"] - ref), np.abs(heads["float16"] - emu16)
     print(f"{H}x{W}: f16 vs f32 oracle max {d16.max():.4f} mean {d16.mean():.5f}, vs emulated-f16 oracle max {de16.max():.4f} "
           f"mean {de16.mean():.5f}")
-    assert d16.mean() <= 0.004 and de16.max() <= 0.02 and de16.mean() <= 0.0015
+    _assert_16bit(de16, d16, np.abs(emu16 - ref), f"{H}x{W} float16")
     emu = fused_ref.fused_forward_ref(sd, Fr.normalize_u8(u8), "drn_d_22", emulate_bf16=True, fuse_stem="all").numpy()
     err = np.abs(heads["float32"] - ref).max()
     d, de = np.abs(heads["bfloat16"] - ref), np.abs(heads["bfloat16"] - emu)
     print(f"{H}x{W}: f32 |hip-oracle| {err:.2e}; bf16 vs f32 oracle max {d.max():.3f} mean {d.mean():.4f}, "
           f"vs emulated-bf16 oracle max {de.max():.4f} mean {de.mean():.5f}")
     assert err <= F32_TOL
-    # kernel error proper: against the oracle with bf16 storage emulated at the same points.  Against the f32 head the
-    # quantisation noise of this checkpoint (BN statistics calibrated on 96x96 frames) reaches 0.17 on single elements
-    # of the 2.4 M, so only the mean is gated there.
-    # The emulation rounds at the same points but sums in another order, so single bf16 roundings flip and the flips
-    # are amplified by the layers behind them: the MAXIMUM over 1-3 M head elements is a tail statistic (0.05-0.08 on
-    # these frames).  Gated: the mean and the 99.99th percentile at the fixture tolerances, the maximum at 0.15.
-    assert de.mean() <= BF16_EMU_MEAN_TOL and np.quantile(de, 0.9999) <= BF16_EMU_MAX_TOL and de.max() <= BF16_MAX_TOL
-    assert d.mean() <= BF16_MEAN_TOL
+    # kernel error proper: against the oracle with bf16 storage emulated at the same points (the derived rule above; on
+    # this checkpoint -- BN statistics calibrated on 96x96 frames -- the policy's own noise reaches 0.17 on single elements)
+    _assert_16bit(de, d, np.abs(emu - ref), f"{H}x{W} bfloat16")
 
 
 @pytest.mark.parametrize("arch", ["drn_d_24", "drn_d_40", "drn_d_56", "drn_d_105", "drn_d_107"])

@@ -196,6 +196,59 @@ def test_two_rank_gloo_bucketed_exchange(tmp_path):
     assert scale == 0.5 and total == 3 * sum(range(1000))
 
 
+_PIGGY_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as dist
+from pytorch_pose_proposal_network_amd import train as T
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+n = 1000
+store = torch.zeros(16 + n)
+flat = store[16:]
+flat.copy_(torch.arange(n, dtype=torch.float32) * (rank + 1))
+task = T.GradNormWeights("cpu", lr=0.01)
+task.bind(torch.empty(0).set_(store.untyped_storage(), 0, (5,), (1,)))          # as trainer.PPNTrainer does
+calls = []
+def before_last():
+    calls.append(len(ex.handles))                                               # buckets already out when it runs
+    task.w.copy_(torch.tensor([1.0, 2.0, 0.5, 1.5, 0.25]) * (rank + 1))          # stands in for the local Adam step
+ex = T.BucketedAllReduce(flat, bucket_elems=300, store=store, before_last=before_last)
+ex.ready(650)
+ex.ready(120)
+scale = ex.finish()
+if rank == 0:
+    print("RESULT", calls, scale, float(flat.sum()), store[:16].tolist())
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_task_weights_ride_on_the_last_gradient_bucket(tmp_path, world):
+    """The exchange step of the training path at world 2 and at world 8 (BASELINE configs[3]: 8 ranks) on CPU (gloo): the
+    five GradNorm task weights live in the 16-float prefix of the gradient store, their local step runs right before the
+    LAST bucket is issued (three buckets are already out), and that bucket carries them: SUM over the ranks with no
+    collective of their own (/root/reference/main.py:769-771 is a separate all-reduce)."""
+    script = tmp_path / "piggy_worker.py"
+    script.write_text(_PIGGY_WORKER)
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), OMP_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    line = [l for l in outs[0].splitlines() if l.startswith("RESULT")][0]
+    calls, rest = eval(line[len("RESULT "):line.index("]") + 1]), line[line.index("]") + 2:].split(" ", 2)
+    scale, total, prefix = float(rest[0]), float(rest[1]), eval(rest[2])
+    tri = world * (world + 1) // 2
+    assert calls == [3]                                        # once, with the three earlier buckets already issued
+    assert scale == 1.0 / world and total == tri * sum(range(1000))
+    assert prefix[:5] == [1.0 * tri, 2.0 * tri, 0.5 * tri, 1.5 * tri, 0.25 * tri] and prefix[5:] == [0.0] * 11
+
+
 def test_ap_against_people_on_the_reference_fixture():
     """evaluate.ap_against_people (the task-metric account of the 16-bit modes, bench.py::ap_vs_reference): a people list
     scored against itself gives the metric's ceiling on that list (the same number whatever the order of the people);

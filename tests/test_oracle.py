@@ -283,3 +283,25 @@ def test_ingest_oracle_properties():
     src = prng.u8_frames(12, 1, (768, 768))[0].astype(np.int64)
     box = (src[0::2, 0::2] + src[0::2, 1::2] + src[1::2, 0::2] + src[1::2, 1::2] + 2) >> 2
     assert np.array_equal(I.resize_linear_u8(src.astype(np.uint8), (384, 384)), box.astype(np.uint8))
+
+
+def test_emulated_oracle_fixture_frame0(golden_dir):
+    """tests/golden/e2e_emulated.npz (what the emulated-storage oracle returns on the end-to-end fixtures: the yardstick of
+    the 16-bit GPU gates, tests/test_e2e_gpu.py) is what tests/golden/make_emulated.py computes: frame 0 of the tuned
+    fixture recomputed here in both modes -- same people, same agreement with the reference pipeline's people."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_emulated", os.path.join(golden_dir, "make_emulated.py"))
+    me = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(me)
+    z = np.load(os.path.join(golden_dir, "e2e_emulated.npz"))
+    fx = "e2e_tuned_d22_384"
+    sd, arch, size, u8, exp = me.setup(fx)
+    for mode in me.MODES:
+        emax, emean, people, tot = me.emulate(sd, arch, size, u8, exp, mode, frames=[0])
+        assert people[0]["n"] == int(z[f"{fx}/{mode}/frame0/n"])
+        assert np.array_equal(people[0]["kp_cell"], z[f"{fx}/{mode}/frame0/kp_cell"])
+        assert np.array_equal(people[0]["limb_arg"], z[f"{fx}/{mode}/frame0/limb_arg"])
+        assert emax <= float(z[f"{fx}/{mode}/head_err"][0]) + 1e-12
+        assert 0 < tot[1] <= tot[0] and tot[0] == int(exp[0]["n"])
+    # the yardstick is what DESIGN.md section 2 quotes
+    assert int(z["e2e_d22_384/bfloat16/agreement"][0]) == 260 and int(z["e2e_tuned_d22_384/float16/agreement"][0]) == 76

@@ -267,3 +267,16 @@ def test_stride2_dgrad_by_parity_equals_zero_upsampled(dtype, case):
     tol = 2e-5 if dtype == torch.float32 else 2e-2
     err = (got.cpu().double() - x.grad.permute(0, 2, 3, 1)).abs().max().item()
     assert err <= tol * max(1.0, x.grad.abs().max().item()), err
+    # with a skip-path gradient to add: conv_dgrad must give the fused (add in f32, ONE rounding) result whatever the
+    # PPN_DGRAD_S2_PARITY switch says -- the parity form could only add after rounding its sub-convolutions
+    add = torch.randn(B, H, H, ci, generator=g).to(dtype).to(dev)
+    with_add = T.conv_dgrad(dy.to(dev), w.to(dev), (H, H), 2, 1, pad, add=add)
+    T._S2_PARITY = False
+    try:
+        ref_add = T.conv_dgrad(dy.to(dev), w.to(dev), (H, H), 2, 1, pad, add=add)
+    finally:
+        T._S2_PARITY = old
+    torch.cuda.synchronize()
+    assert torch.equal(with_add, ref_add)
+    exact = x.grad.permute(0, 2, 3, 1) + add.cpu().double()
+    assert (with_add.cpu().double() - exact).abs().max().item() <= tol * max(1.0, exact.abs().max().item())

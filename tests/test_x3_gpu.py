@@ -1,0 +1,235 @@
+"""GPU: the split-f16 ("float16x3", PPN_F16X3) inference mode -- the tolerance-meeting mode above the exact-f32 MFMA rate.
+
+Every value is stored as an IEEE-half pair (hi, lo' = (v - hi) * 2^11), weights as three half copies of w * 2^s per
+64-channel slab, and the K loop of csrc/conv_big.hip accumulates a_hi w_hi + a_hi w_lo + a_lo w_hi in f32 on
+v_mfma_f32_16x16x32_f16.  north_star's tolerance applies unchanged: 1e-4 on the raw head against the reference's golden
+heads (/root/reference/model.py:104-136 run by tests/golden/make_golden.py) and the reference pipeline's people up to the
+knife edges of the reference head (tests/test_e2e_gpu.py's rule for f32)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from pytorch_pose_proposal_network_amd import prng, synth
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+X3_CONV_TOL = 4e-6      # relative to the output scale, vs an fp64 convolution of the SAME f32 inputs (f32 MFMA: 2e-5 gate)
+HEAD_TOL = 1e-4
+
+
+def _split(t):
+    """f32 NCHW CPU tensor -> half pairs NHWC [B,H,W,2C] as the kernels store them."""
+    v = t.permute(0, 2, 3, 1).contiguous()
+    hi = v.to(torch.float16)
+    lo = ((v - hi.float()) * 2048.0).to(torch.float16)
+    return torch.cat([hi, lo], dim=3).contiguous()
+
+
+def _join(p):
+    """half pairs NHWC [B,H,W,2C] (any device) -> f64 NCHW CPU."""
+    p = p.cpu()
+    c = p.shape[3] // 2
+    return (p[..., :c].double() + p[..., c:].double() / 2048.0).permute(0, 3, 1, 2).contiguous()
+
+
+def _x3_conv(x, w, stride=1, dil=1, pad=0, s1=None, b1=None, act1=0, residual=None, s2=None, b2=None, act2=0,
+             want_act=False, nchw=False, tile=None):
+    from pytorch_pose_proposal_network_amd import lib as L
+    lib = L.load()
+    dev = torch.device("cuda")
+    B, Cin, H, W = x.shape
+    Cout, _, k, _ = w.shape
+    eff = dil * (k - 1) + 1
+    Ho, Wo = (H + 2 * pad - eff) // stride + 1, (W + 2 * pad - eff) // stride + 1
+    _, _, _, kpad, cpad = L.conv_tiling(L.PPN_F16X3, Cin, Cout, k)
+    st = torch.cuda.current_stream().cuda_stream
+    sl2 = int(np.floor(np.log2(32768.0 / float(w.abs().max()))))
+    wd = w.contiguous().to(dev)
+    packed = torch.empty(cpad, 3 * kpad, dtype=torch.float16, device=dev)
+    L.check(lib.ppn_pack_weight_x3(wd.data_ptr(), Cout, Cin, k, cpad, sl2, packed.data_ptr(), st), "ppn_pack_weight_x3")
+    xs = _split(x).to(dev)
+    zero = torch.zeros(64, device=dev)
+    scale = ((s1.double() if s1 is not None else torch.ones(Cout, dtype=torch.float64)) * 2.0 ** -sl2).float().to(dev)
+    keep = [wd, packed, xs, zero, scale]
+    d = L.ConvDesc()
+    d.dtype, d.batch, d.in_h, d.in_w, d.cin = L.PPN_F16X3, B, H, W, Cin
+    d.out_h, d.out_w, d.cout = Ho, Wo, Cout
+    d.ksize, d.stride, d.dilation, d.pad = k, stride, dil, pad
+    d.k_total, d.cout_pad, d.act1, d.act2, d.out_nchw_f32 = 3 * kpad, cpad, act1, act2, int(nchw)
+    d.src, d.weight, d.zero_page, d.scale1 = xs.data_ptr(), packed.data_ptr(), zero.data_ptr(), scale.data_ptr()
+    for name, t in (("shift1", b1), ("scale2", s2), ("shift2", b2)):
+        if t is not None:
+            t = t.float().contiguous().to(dev)
+            keep.append(t)
+            setattr(d, name, t.data_ptr())
+    if residual is not None:
+        r = _split(residual).to(dev)
+        keep.append(r)
+        d.residual = r.data_ptr()
+    raw = (torch.full((B, Cout, Ho, Wo), float("nan"), device=dev) if nchw
+           else torch.full((B, Ho, Wo, 2 * Cout), float("nan"), device=dev).half())
+    d.out_raw = raw.data_ptr()
+    act = None
+    if want_act:
+        act = torch.full((B, Ho, Wo, 2 * Cout), float("nan"), device=dev).half()
+        d.out_act = act.data_ptr()
+    if tile is not None:
+        L.check(lib.ppn_set_conv_tile_override(*tile), "ppn_set_conv_tile_override")
+    try:
+        L.check(lib.ppn_conv2d_fused(C.byref(d), st), "ppn_conv2d_fused")
+    finally:
+        if tile is not None:
+            L.check(lib.ppn_set_conv_tile_override(0, 0), "ppn_set_conv_tile_override")
+    torch.cuda.synchronize()
+    kern = lib.ppn_last_conv_kernel().decode()
+    return (raw.double().cpu() if nchw else _join(raw)), (None if act is None else _join(act)), kern
+
+
+def _act(v, a):
+    return [lambda t: t, F.relu, lambda t: F.leaky_relu(t, 0.1), torch.sigmoid][a](v)
+
+
+def test_split_helper_round_trip():
+    """ppn_split_f16x3: hi + lo'/2^11 reproduces an f32 tensor to 2^-21 relative (22 significant bits) over nine decades,
+    including values whose lo part would be a half subnormal without the 2^11 scaling."""
+    from pytorch_pose_proposal_network_amd import lib as L
+    lib = L.load()
+    g = torch.Generator().manual_seed(5)
+    v = torch.randn(4096, 64, generator=g) * torch.logspace(-4, 4, 4096).view(-1, 1)
+    vd = v.cuda()
+    out = torch.empty(4096, 128, dtype=torch.float16, device="cuda")
+    L.check(lib.ppn_split_f16x3(vd.data_ptr(), 4096, 64, out.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    back = out[:, :64].double().cpu() + out[:, 64:].double().cpu() / 2048.0
+    rel = ((back - v.double()).abs() / v.double().abs().clamp_min(1e-30))
+    big = v.abs() >= 2.0 ** -13                     # hi normal: the pair carries 22 bits
+    assert float(rel[big].max()) <= 2.0 ** -21, float(rel[big].max())
+    assert float((back - v.double()).abs()[~big].max()) <= 2.0 ** -24
+
+
+CASES = [
+    # (name, B, Cin, H, W, Cout, k, stride, dil, pad, tile)
+    ("3x3 64->128 s2", 2, 64, 24, 24, 128, 3, 2, 1, 1, None),
+    ("3x3 128->256 dil2", 2, 128, 20, 20, 256, 3, 1, 2, 2, None),
+    ("3x3 512->512 dil4 192x256", 1, 512, 18, 18, 512, 3, 1, 4, 4, (192, 256)),
+    ("3x3 256->256 256x256", 2, 256, 16, 16, 256, 3, 1, 1, 1, (256, 256)),
+    ("1x1 512->128", 2, 512, 12, 12, 128, 1, 1, 1, 0, None),
+    ("3x3 64->64 (64-channel tile)", 2, 64, 24, 24, 64, 3, 1, 1, 1, None),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_x3_conv_matches_fp64(case):
+    """One split-f16 convolution with BN affine, ReLU, residual and the second (pre-activation) output against an fp64
+    evaluation of the same f32 inputs.  Activations span four decades (small values exercise the scaled lo part)."""
+    name, B, Cin, H, W, Cout, k, stride, dil, pad, tile = case
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(B, Cin, H, W, generator=g) * torch.logspace(-3, 1, H).view(1, 1, H, 1)
+    w = torch.randn(Cout, Cin, k, k, generator=g) * (2.0 / (Cin * k * k)) ** 0.5
+    s1, b1 = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.1
+    s2, b2 = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.1
+    eff = dil * (k - 1) + 1
+    Ho, Wo = (H + 2 * pad - eff) // stride + 1, (W + 2 * pad - eff) // stride + 1
+    res = torch.randn(B, Cout, Ho, Wo, generator=g)
+    raw, act, kern = _x3_conv(x, w, stride, dil, pad, s1, b1, 1, res, s2, b2, 1, want_act=True, tile=tile)
+    assert kern.startswith("conv_igemm_big_kernel<_Float16") and kern.endswith(", true>"), kern
+    # the kernel sees the inputs through their half pairs: compare against fp64 on exactly those values
+    xq, rq = _join(_split(x)), _join(_split(res))
+    acc = F.conv2d(xq, w.double(), None, stride, pad, dil)
+    v = F.relu(acc * s1.double().view(1, -1, 1, 1) + b1.double().view(1, -1, 1, 1)) + rq
+    u = F.relu(v * s2.double().view(1, -1, 1, 1) + b2.double().view(1, -1, 1, 1))
+    scale = float(v.abs().max())
+    e_raw, e_act = float((raw - v).abs().max()) / scale, float((act - u).abs().max()) / scale
+    print(f"{name}: {kern}: raw {e_raw:.2e} act {e_act:.2e} of the output scale {scale:.2f}")
+    assert e_raw <= X3_CONV_TOL and e_act <= X3_CONV_TOL
+
+
+def test_x3_conv_nchw_head():
+    """conv3's form: 1x1 512 -> 1000 with bias and sigmoid into an f32 NCHW tensor."""
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(2, 512, 12, 12, generator=g)
+    w = torch.randn(1000, 512, 1, 1, generator=g) * 0.05
+    b = torch.randn(1000, generator=g)
+    raw, _, kern = _x3_conv(x, w, b1=b, act1=3, nchw=True)
+    ref = torch.sigmoid(F.conv2d(_join(_split(x)), w.double(), b.double()))
+    err = float((raw - ref).abs().max())
+    print(f"x3 head conv: {kern}: max err {err:.2e}")
+    assert err <= 2e-6
+
+
+def _model(arch, g, dtype="float16x3"):
+    from pytorch_pose_proposal_network_amd import drn, model
+    stats = {k[3:]: g[k] for k in g.files if k.startswith("bn/")}
+    sd = synth.make_state_dict(arch, int(g["seed_w"]), bn_stats=stats)
+    m = model.PoseProposalNet(getattr(drn, arch)(), local_grid_size=(21, 21), compute_dtype=dtype).cuda()
+    m.load_state_dict(sd)
+    return m.eval()
+
+
+@pytest.mark.parametrize("name", ["forward_d22_96", "forward_d38_96", "forward_d54_96"])
+def test_x3_forward_small_full_head(golden_dir, name):
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    m = _model(str(g["arch"]), g)
+    u8 = prng.u8_frames(int(g["seed_in"]), int(g["batch"]), (int(g["size"]), int(g["size"])))
+    head = m.forward_u8(torch.from_numpy(u8).cuda()).cpu().numpy()
+    noise = float(g["ref_f32_noise"])
+    err, err64 = np.abs(head - g["head"]).max(), np.abs(head - g["head_f64"]).max()
+    print(f"{name} float16x3: |hip-ref| {err:.3e}  |hip-f64| {err64:.3e}  |ref-f64| {noise:.3e}")
+    assert err <= HEAD_TOL or err64 <= 1.5 * noise, (err, err64, noise)       # the f32 mode's rule (test_forward_gpu.py)
+    x = torch.from_numpy(synth.normalized_frames(u8)).cuda()                   # model.forward() entry
+    assert np.abs(m(x).cpu().numpy() - g["head"]).max() <= max(HEAD_TOL, 1.5 * noise + np.abs(g["head"] - g["head_f64"]).max())
+
+
+def test_x3_forward_384(golden_dir):
+    g = np.load(os.path.join(golden_dir, "forward_d22_384.npz"))
+    m = _model("drn_d_22", g)
+    u8 = prng.u8_frames(int(g["seed_in"]), int(g["batch"]), (384, 384))
+    head = m.forward_u8(torch.from_numpy(u8).cuda()).cpu().numpy()
+    err = np.abs(head.reshape(-1)[g["head_idx"]] - g["head_val"]).max()
+    print(f"forward_d22_384 float16x3: |hip-ref| {err:.3e}")
+    assert err <= HEAD_TOL, err
+    assert np.allclose(head.astype(np.float64).sum(axis=(2, 3)), g["head_chan_sum"], atol=2e-2)
+
+
+@pytest.mark.parametrize("fixture", ["e2e_d22_384", "e2e_tuned_d22_384"])
+def test_x3_pipeline_reproduces_reference_people(fixture):
+    """frames -> people in the float16x3 mode vs the reference pipeline's own people lists: the f32 mode's bar."""
+    from pytorch_pose_proposal_network_amd import decode, drn, model, rt
+    g = np.load(os.path.join(ROOT, "tests", "golden", fixture + ".npz"))
+    arch, size, batch = str(g["arch"]), int(g["size"]), int(g["batch"])
+    st = np.load(os.path.join(ROOT, "pytorch_pose_proposal_network_amd", "data", f"bn_calib_{arch}_seed0.npz"))
+    sd = synth.make_state_dict(arch, int(g["seed_w"]), bn_stats={k: st[k] for k in st.files})
+    for k in g.files:
+        if k.startswith("override/"):
+            sd[k[len("override/"):]] = g[k]
+    net = model.PoseProposalNet(getattr(drn, arch)(), insize=(size, size), outsize=(size // 16, size // 16),
+                                compute_dtype="float16x3").cuda()
+    net.load_state_dict(sd)
+    frames = torch.from_numpy(prng.u8_frames(int(g["seed_in"]), batch, (size, size))).cuda()
+    got = rt.inference_batch(frames, net).to_host()
+    got2 = decode.decode_heads(net.forward_u8(frames)).to_host()
+    tot = np.zeros(5, np.int64)
+    for i in range(batch):
+        exp = {k: g[f"{i}/{k}"] for k in ("n", "kp_cell", "limb_arg")}
+        tot += np.array(decode.people_agreement(exp, got[i]))
+        assert got[i]["n"] == got2[i]["n"]                       # fused decode == decode of the materialised head
+        for k in ("kp_cell", "limb_arg", "bbox", "score"):
+            assert np.array_equal(got[i][k], got2[i][k]), k
+    n, exact, same, kp_eq, kp_all = (int(v) for v in tot)
+    print(f"{fixture}: float16x3 vs reference people: {exact}/{n} exact, same root {same}/{n}, keypoint cells {kp_eq}/{kp_all}")
+    assert exact >= 0.97 * n and same >= 0.98 * n
+
+
+def test_x3_mode_is_inference_only_and_rejects_small_cin():
+    from pytorch_pose_proposal_network_amd import lib as L, model
+    m = model.PoseProposalNet("drn_d_22", compute_dtype="float16x3")
+    m.load_state_dict(synth.make_state_dict("drn_d_22", 0))
+    with pytest.raises(RuntimeError):
+        m.train()
+    with pytest.raises(L.PPNError):
+        L.conv_tiling(L.PPN_F16X3, 32, 64, 3)

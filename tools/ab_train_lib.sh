@@ -5,7 +5,7 @@
 V=${1:-bnlds}
 for rep in 1 2 3; do
 for v in default $V; do
-if [ $v = default ]; then unset PPN_LIB; else export PPN_LIB=$GRAFT_REPO_ROOT/tools/bin/libppn_$v.so; fi
+if [ $v = default ]; then unset PPN_LIB; else export PPN_LIB=${GRAFT_REPO_ROOT:-/root/repo}/tools/bin/libppn_$v.so; fi
 timeout -k 10 200 python tools/bench_train.py --steps 8 --warmup 2 2>/dev/null | tail -1 | python -c "
 import json,sys; d=json.loads(sys.stdin.read()); print('$v', d['ms_per_step'])"
 done; done

@@ -23,6 +23,9 @@ for k, d in res.items():
         table[k] = {"launches": d["fetch"][1], "fetch_bytes_per_launch_corrected": round(fetch_b),
                     "fetch_kib_raw": round(d["fetch"][0], 1), "write_bytes_per_launch": round(write_b),
                     "hbm_bytes_per_launch": round(fetch_b + write_b)}
+import time
+table["_date"] = time.strftime("%Y-%m-%d")                  # bench.py quotes it as the provenance of roofline.traffic
 json.dump(table, open(out, "w"), indent=1, sort_keys=True)
+del table["_date"]
 for k, v in sorted(table.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:8]:
     print(k[:80].ljust(80), v["launches"], "fetch(corr) %.1f MB  write %.1f MB" % (v["fetch_bytes_per_launch_corrected"] / 1e6, v["write_bytes_per_launch"] / 1e6))

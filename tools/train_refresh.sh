@@ -1,5 +1,6 @@
+#!/bin/bash
 set -e
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r03t; mkdir -p $O
+R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/r03t; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 python3 $R/tools/bench_train.py --phases --first-order > $O/train_bench.txt 2>&1
 python3 $R/bench.py --workload train --steps 10 --warmup 2 > $O/bench_train.json 2> $O/bench_train.err
