@@ -118,12 +118,18 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
     constexpr int BK = 8 * EPC;
     constexpr int ES = sizeof(T);
     constexpr int NT = 64 * NW;
-    constexpr int WP = NW / 2;                                      // waves along the pixel dimension
-    constexpr int NXI = BP / (8 * NW), NWI = BC / (8 * NW);        // load instructions per thread and K step
-    constexpr int TP = BP / WP / 16, TC = BC / 2 / 16;             // 16x16 tiles per wave
+    // Wave grid WC (channels) x WP (pixels): 2 x NW/2 wherever the pixel tile splits into NW/2 multiples of 16; else (the
+    // 144-pixel tile: 9 x 16) all NW waves side by side along the channels, each owning every pixel of the tile.
+    constexpr int WC = (BP % (16 * (NW / 2)) == 0) ? 2 : NW;
+    constexpr int WP = NW / WC;                                     // waves along the pixel dimension
+    // load instructions per thread and K step: an activation piece is 8 rows x 128 B; a tile whose row count is not a
+    // multiple of 8 * NW (144 = 18 pieces over 8 waves) gives its last round of pieces to the first waves only (xpiece())
+    constexpr int NXI = (BP + 8 * NW - 1) / (8 * NW), NWI = BC / (8 * NW);
+    constexpr bool XRAGGED = BP % (8 * NW) != 0;
+    constexpr int TP = BP / WP / 16, TC = BC / WC / 16;            // 16x16 tiles per wave
     constexpr int STAGE = (BP + BC) * 128;
-    static_assert(BP % (8 * NW) == 0 && BC % (8 * NW) == 0 && (BP / WP) % 16 == 0, "tile shape");
-    static_assert(TP <= 8 && TC <= 8 && TC * TP % 4 == 0, "accumulators must fit the register file");
+    static_assert(BP % 8 == 0 && BC % (8 * NW) == 0 && (BP / WP) % 16 == 0 && BC % (16 * WC) == 0, "tile shape");
+    static_assert(TP <= 9 && TC <= 8 && TC * TP % 2 == 0, "accumulators must fit the register file");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef PPN_CLOCK
@@ -239,6 +245,8 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
         constexpr int g = decltype(gc)::value;
         char* xs = smem + buf * STAGE;
         if constexpr (g < NXI) {
+            if constexpr (XRAGGED && g == NXI - 1)
+                if ((g * NW + wave) * 8 >= BP) return;               // wave-uniform: this piece lies past the tile
             if (!SC || !phase2) {
                 const unsigned voff = (xmask[g] & tapbit) ? (unsigned)(xbase[g] + tapoff) : kOOB;
                 bufload_lds16(xrs, xs + (g * NW + wave) * 1024, voff, 0);
@@ -259,7 +267,7 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
     foff[0] = frow * 128 + (((0 + fq) ^ fswz) << 4);
     foff[1] = frow * 128 + (((4 + fq) ^ fswz) << 4);
     const int x_tile_off = wp * (BP / WP) * 128;
-    const int w_tile_off = BP * 128 + wc * (BC / 2) * 128;
+    const int w_tile_off = BP * 128 + wc * (BC / WC) * 128;
 
     f32x4 acc[TC][TP];
 #pragma unroll
@@ -280,8 +288,9 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
         else
             wf[r - TP] = *reinterpret_cast<const f32x4*>(smem + buf * STAGE + w_tile_off + foff[ks] + (r - TP) * 16 * 128);
     };
-    // MFMA group: 4 consecutive output tiles of the wave (flat index = i*TP + j)
-    constexpr int NG = TC * TP / 4;
+    // MFMA group: GS consecutive output tiles of the wave (flat index = i*TP + j); 4 wherever the tile count allows
+    constexpr int GS = (TC * TP % 4 == 0) ? 4 : ((TC * TP % 3 == 0) ? 3 : 2);
+    constexpr int NG = TC * TP / GS;
 #if PPN_DIAG == 3 || PPN_DIAG == 4
     typedef float f32x16 __attribute__((ext_vector_type(16)));
     f32x16 acc32[TC * TP / 4];
@@ -302,8 +311,8 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
             return;
         }
 #endif
-        static_for<4>([&](auto tc) {
-            constexpr int idx = g * 4 + decltype(tc)::value;
+        static_for<GS>([&](auto tc) {
+            constexpr int idx = g * GS + decltype(tc)::value;
             mma_step(acc[idx / TP][idx % TP], wf[idx / TP], xf[idx % TP], (T*)nullptr);
         });
     };
@@ -320,7 +329,13 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
     advance();
     static_for<NL>([&](auto gc) { issue_one(gc, 1); });
     advance();
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");
+    if constexpr (XRAGGED) {
+        // waves whose last activation piece lies past the tile issued one DMA fewer per stage
+        if ((NXI - 1) * NW * 8 + wave * 8 < BP) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL - 1) : "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");
+    }
     __syncthreads();
 #ifdef PPN_CLOCK
     const unsigned long long ck_bar = __builtin_amdgcn_s_memtime();
@@ -444,7 +459,7 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
                             (!a.shift1 || (reinterpret_cast<size_t>(a.shift1) & 15) == 0);
 #pragma unroll
             for (int i = 0; i < TC; ++i) {
-                const int chl = wc * (BC / 2) + i * 16 + 4 * fq;     // this lane's 4 channels of channel tile i
+                const int chl = wc * (BC / WC) + i * 16 + 4 * fq;    // this lane's 4 channels of channel tile i
                 const int c = c0 + chl;
                 float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
                 if (al && c + 4 <= a.Cout) {
@@ -524,7 +539,7 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
 #pragma unroll
                 for (int i = 0; i < TC; ++i) {
                     const int px = (wp * JC + jj) * 16 + frow;
-                    const int ch = wc * (BC / 2) + i * 16 + 4 * fq;
+                    const int ch = wc * (BC / WC) + i * 16 + 4 * fq;
                     *reinterpret_cast<f32x4*>(ct + px * LD + ch) = acc[i][q * JC + jj];
                 }
             lds_barrier();
@@ -611,11 +626,11 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
     } else {
         // head: f32 NCHW [B, Cout, Ho*Wo] (model.py:136): 64 channels per chunk, pixel-contiguous rows
         constexpr int LD = BP + 4;                                   // [channel][pixel] f32
-        constexpr int IC = 2;                                        // channel tiles per wave and chunk
+        constexpr int IC = WC == 2 ? 2 : 1;                          // channel tiles per wave and chunk
         constexpr int TPC = BP / 4;                                  // threads per channel row (4 pixels each)
-        constexpr int NITEM = 2 * IC * 16 * TPC;                     // (channel row, pixel quad) items per chunk
+        constexpr int NITEM = WC * IC * 16 * TPC;                    // (channel row, pixel quad) items per chunk
         static_assert(TC % IC == 0, "channel tiles per wave must be even");
-        static_assert((size_t)(2 * IC * 16 * LD + 4 * IC * 16) * 4 <= 2 * (size_t)STAGE, "epilogue chunk must fit the staging LDS");
+        static_assert((size_t)(WC * IC * 16 * LD + 4 * IC * 16) * 4 <= 2 * (size_t)STAGE, "epilogue chunk must fit the staging LDS");
         float* out = reinterpret_cast<float*>(a.out_raw);
         const bool vec = (a.HoWo & 3) == 0;
         auto chunk = [&](auto qc) {
@@ -626,7 +641,7 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
 #pragma unroll
             for (int ii = 0; ii < IC; ++ii) {
                 const int chl = (wc * IC + ii) * 16 + 4 * fq;            // row of this lane's first channel in the chunk
-                const int c = c0 + wc * (BC / 2) + (q * IC + ii) * 16 + 4 * fq;
+                const int c = c0 + wc * (BC / WC) + (q * IC + ii) * 16 + 4 * fq;
                 float sc[4], sh[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -665,12 +680,12 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
                 // sigmoid of every element, as before.
                 constexpr int RUN = IC * 16;
                 const int nedges = (a.Cout - a.unary_ch) / a.window;
-                for (int item = tid; item < 2 * BP; item += NT) {
+                for (int item = tid; item < WC * BP; item += NT) {
                     const int cw = item / BP, px = item - cw * BP;
                     const int m = m0 + px;
                     if (m >= a.M) continue;
                     const int nb = fast_div(m, a.div_howo), np = m - nb * a.HoWo;
-                    const int cb = c0 + cw * (BC / 2) + q * RUN;     // first channel of this run
+                    const int cb = c0 + cw * (BC / WC) + q * RUN;    // first channel of this run
                     const float* row = ct + (cw * RUN) * LD + px;
                     int r = 0;
                     // unary part of the run (only the first channel tile of the layer has one)
@@ -722,7 +737,7 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
             for (int item = tid; item < NITEM; item += NT) {
                 const int chl = item / TPC, pq = item - chl * TPC;   // 0 .. 2*IC*16-1
                 const int cw = chl / (IC * 16), ci = (chl / 16) % IC, cr = chl % 16;
-                const int c = c0 + cw * (BC / 2) + (q * IC + ci) * 16 + cr;
+                const int c = c0 + cw * (BC / WC) + (q * IC + ci) * 16 + cr;
                 const int m = m0 + 4 * pq;
                 if (c < a.Cout && m < a.M) {
                     const f32x4 t4 = *reinterpret_cast<const f32x4*>(ct + chl * LD + 4 * pq);
@@ -802,7 +817,7 @@ int launch_one(const ConvKArgs& a, hipStream_t st, const char** kname) {
 template <typename T>
 int launch_T(const ConvKArgs& a, BigTile t, hipStream_t st, const char** kname) {
     static const int nw = getenv("PPN_CONV_WAVES") ? atoi(getenv("PPN_CONV_WAVES")) : 8;   // tuning knob
-    if (nw == 4) {
+    if (nw == 4 && t.bp != 144) {
         if (t.bc == 256) {
             if (t.bp == 256) return launch_one<T, 256, 256, 4>(a, st, kname);
             if (t.bp == 192) return launch_one<T, 192, 256, 4>(a, st, kname);
@@ -815,6 +830,7 @@ int launch_T(const ConvKArgs& a, BigTile t, hipStream_t st, const char** kname) 
     if (t.bc == 256) {
         if (t.bp == 256) return launch_one<T, 256, 256, 8>(a, st, kname);
         if (t.bp == 192) return launch_one<T, 192, 256, 8>(a, st, kname);
+        if (t.bp == 144) return launch_one<T, 144, 256, 8>(a, st, kname);
         return launch_one<T, 128, 256, 8>(a, st, kname);
     }
     if (t.bc == 128) {
@@ -832,6 +848,7 @@ int launch_X3(const ConvKArgs& a, BigTile t, hipStream_t st, const char** kname)
     if (t.bc == 256) {
         if (t.bp == 256) return launch_sc<_Float16, 256, 256, 8, false, true>(a, st, kname);
         if (t.bp == 192) return launch_sc<_Float16, 192, 256, 8, false, true>(a, st, kname);
+        if (t.bp == 144) return launch_sc<_Float16, 144, 256, 8, false, true>(a, st, kname);
         return launch_sc<_Float16, 128, 256, 8, false, true>(a, st, kname);
     }
     if (t.bc == 128) {
@@ -855,8 +872,12 @@ static int g_tile_policy = getenv("PPN_CONV_CONT") ? 1 : 0;
 static int g_ov_bp = -1, g_ov_bc = 0;
 
 static bool tile_shape_ok(int bp, int bc) {
+    if (bp == 144) return bc == 256;                     // the 8 x 1 wave grid exists for the 256-channel tile only
     return (bp == 128 || bp == 192 || bp == 256) && (bc == 64 || bc == 128 || bc == 256) && !(bc == 64 && bp == 192);
 }
+
+// relative efficiency of the 144 x 256 tile in the cost model below (PPN_EFF144 overrides: 0 takes the tile out)
+static const double kEff144 = getenv("PPN_EFF144") ? atof(getenv("PPN_EFF144")) : 0.98;
 
 bool big_tile_for(int cout, long long m, BigTile* out, int ksteps) {
     if (cout < 64) return false;
@@ -883,7 +904,10 @@ bool big_tile_for(int cout, long long m, BigTile* out, int ksteps) {
     // staged byte feed the MFMA pipe.  For Cout = 256 the 128-channel tile wins through quantisation
     // (768 workgroups = 3 full rounds instead of 384 = 1.5).
     struct Cand { int bp, bc; double eff; };
-    static const Cand cands[] = {{256, 256, 1.27}, {192, 256, 1.10}, {128, 256, 0.92}, {256, 128, 0.90},
+    // 144 x 256 (round 4; 8 waves side by side along the channels, each 32 channels x all 144 pixels): 18 432 pixels x 512
+    // channels (the five 24 x 24 layers of DRN-D-22 at batch 32) = exactly 256 workgroups = one full round, where 192 x 256
+    // leaves 64 of the 256 CUs idle; and 73 728 x 256 (layer5) = 512 = two rounds.  Same K order: results unchanged.
+    static const Cand cands[] = {{256, 256, 1.27}, {192, 256, 1.10}, {144, 256, kEff144}, {128, 256, 0.92}, {256, 128, 0.90},
                                  {192, 128, 0.95}, {128, 128, 0.87}, {256, 64, 0.60},  {128, 64, 0.55}};
     int bc_max = cout >= 256 ? 256 : (cout >= 128 ? 128 : 64);
     const int bc_min = cout >= 256 ? 128 : bc_max;
@@ -893,7 +917,7 @@ bool big_tile_for(int cout, long long m, BigTile* out, int ksteps) {
     if (ksteps > 0 && ksteps <= 8 && bc_max == 256) bc_max = 128;
     double best = 1e30;
     for (const Cand& cd : cands) {
-        if (cd.bc > bc_max || cd.bc < bc_min) continue;
+        if (cd.bc > bc_max || cd.bc < bc_min || cd.eff <= 0.0) continue;
         const long long tiles = ((m + cd.bp - 1) / cd.bp) * ((cout + cd.bc - 1) / cd.bc);
         // policy 1 (several launches in flight on different streams, ppn_set_conv_tile_policy): another stream's
         // workgroups fill a partial last round, so only the tile's efficiency counts
@@ -959,7 +983,7 @@ int launch_big(const ConvKArgs& a, int dtype, BigTile t, hipStream_t st, const c
 extern "C" int ppn_set_conv_tile_override(int32_t bp, int32_t bc) {
     if (bp == 0 && bc == 0) { ppnconv::g_ov_bp = ppnconv::g_ov_bc = 0; return PPN_OK; }
     if (!ppnconv::tile_shape_ok(bp, bc))
-        return ppn::fail(PPN_E_INVALID, "ppn_set_conv_tile_override: bp in {128,192,256}, bc in {64,128,256}, not 192x64");
+        return ppn::fail(PPN_E_INVALID, "ppn_set_conv_tile_override: bp in {128,192,256}, bc in {64,128,256}, not 192x64; or 144x256");
     ppnconv::g_ov_bp = bp; ppnconv::g_ov_bc = bc;
     return PPN_OK;
 }

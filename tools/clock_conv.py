@@ -16,7 +16,7 @@ B, cin, cout, H, k, s, d = 32, 512, 512, 48, 3, 1, 2
 HEAD = "--head" in sys.argv          # the fused head conv (512 -> 7605, 1x1, 24x24)
 if HEAD:
     cin, cout, H, k, s, d = 512, 7605, 24, 1, 1, 1
-dtype, tdt = L.PPN_BF16, torch.bfloat16
+dtype, tdt = (L.PPN_F16, torch.float16) if "--f16" in sys.argv else (L.PPN_BF16, torch.bfloat16)   # --f16: the IEEE-half instantiation
 dev = torch.device("cuda")
 pad = d * (k - 1) // 2
 kstep, _, korder, ktot, cpad = L.conv_tiling(dtype, cin, cout, k)
@@ -58,7 +58,7 @@ import numpy as np
 clk = np.median(t[:, 0] / t[:, 1]) * 100e6
 nsteps = ktot // kstep - 1
 fl = 2.0 * B * H * H * cout * cin * k * k
-print(f"launch {us:.1f} us = {fl / us / 1e6:.0f} TFLOP/s; in-kernel clock {clk / 1e9:.3f} GHz (median over {len(t)} waves); "
+print(("f16 " if "--f16" in sys.argv else "bf16 ") + f"launch {us:.1f} us = {fl / us / 1e6:.0f} TFLOP/s; in-kernel clock {clk / 1e9:.3f} GHz (median over {len(t)} waves); "
       f"K loop {np.median(t[:, 0]) / nsteps:.0f} cycles per step ({nsteps} steps), ideal MFMA time 1536; "
       f"peak at this clock {256 * 4096 * clk / 1e15:.3f} PFLOP/s")
 print(f"per workgroup: prologue {np.median(t[:, 2]):.0f} cycles, K loop {np.median(t[:, 0]):.0f}, epilogue {np.median(t[:, 4]):.0f} "
