@@ -753,14 +753,17 @@ def main():
         # launch between its two events, i.e. warm caches and no launch gap, the figure round 1 quoted (~5 % higher).
         agg, table, agg4 = {}, [], {}
         reps = 5
-        net.profile_layers(frames, src_is_u8=True, repeats=1, fused_decode=fused)   # untimed: first direct launches
+        # the same plan flags as the timed path (a multi-lane plan leaves out the filter-bank kernel and the lone-launch
+        # tiles): the per-launch figures describe the kernels `value` ran
+        pflags = getattr(pipe, "_conv_flags", 0) if pipe is not None else 0
+        net.profile_layers(frames, src_is_u8=True, repeats=1, fused_decode=fused, conv_flags=pflags)   # untimed: first direct launches
         for r in range(reps):
-            for name, kern, ms, fl in net.profile_layers(frames, src_is_u8=True, repeats=1, fused_decode=fused):
+            for name, kern, ms, fl in net.profile_layers(frames, src_is_u8=True, repeats=1, fused_decode=fused, conv_flags=pflags):
                 a = agg.setdefault(kern, [0.0, 0.0, 0])
                 a[0] += ms; a[1] += fl; a[2] += 1
                 if r == 0:
                     table.append((name, kern, ms, fl))
-            for name, kern, ms, fl in net.profile_layers(frames, src_is_u8=True, repeats=4, fused_decode=fused):
+            for name, kern, ms, fl in net.profile_layers(frames, src_is_u8=True, repeats=4, fused_decode=fused, conv_flags=pflags):
                 a = agg4.setdefault(kern, [0.0, 0.0, 0])
                 a[0] += ms; a[1] += fl; a[2] += 1
         # An event pair around ONE launch also spans the marker and launch latency (6-7 us around an empty kernel on

@@ -86,6 +86,16 @@ int ppn_decode_fused(const ppn_decode_cfg* cfg, const float* unary, const uint64
                      int32_t* out_count, int32_t* out_kp_cell, int32_t* out_limb_arg, float* out_bbox,
                      float* out_score, void* stream);
 
+/* ppn_decode_fused with a device workspace (>= ppn_decode_fused_workspace_bytes, 16-byte aligned): the O(n^2) pairwise-IoU
+ * bit matrix of every image's root candidates (datatest.py:134-160 inside get_humans_by_feature, :87-95) is then computed
+ * by a launch of 8 workgroups per image in front of the per-image parse workgroup, which only runs the greedy order on it
+ * (dense heads: ~490 of 576 cells are candidates on the benchmark's synthetic checkpoint).  Images with fewer than 128
+ * candidates keep the single-workgroup form.  Same results, bit for bit. */
+size_t ppn_decode_fused_workspace_bytes(const ppn_decode_cfg* cfg, int32_t batch);
+int ppn_decode_fused_ws(const ppn_decode_cfg* cfg, const float* unary, const uint64_t* keys, int32_t batch, void* workspace,
+                        int32_t* out_count, int32_t* out_kp_cell, int32_t* out_limb_arg, float* out_bbox,
+                        float* out_score, void* stream);
+
 /* First half of ppn_decode on its own (the HBM-bound kernel): dense first-index arg-max over the
  * sH*sW limb window for every (image, edge, cell).  out_arg i32 [batch, E, H, W]. */
 int ppn_limb_argmax(const ppn_decode_cfg* cfg, const float* head, int32_t batch, int32_t* out_arg,
@@ -255,6 +265,10 @@ typedef struct ppn_conv_desc {
     int32_t flags;
 } ppn_conv_desc;
 #define PPN_CONV_NO_FILTER_BANK 1
+/* PPN_CONV_SHARED_GPU: this launch runs beside other streams' launches (rt.MultiLaneInference): the tile chooser then
+ * leaves out the tiles that only shorten a LONE launch by filling every CU with smaller, less efficient workgroups (the
+ * 144 x 256 tile of the 24 x 24 layers: -11 % in sequence, +19 % CU-time, -3.5 % images/s with three lanes). */
+#define PPN_CONV_SHARED_GPU 2
 
 /* GEMM-depth step / channel tile the packer must pad to for a conv of this shape and dtype, and the order of
  * the GEMM depth index in the packed weight rows:

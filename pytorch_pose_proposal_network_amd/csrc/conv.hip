@@ -557,7 +557,7 @@ int ppn::conv_launch(const ppn_conv_desc* d, hipStream_t st, const char** kname)
     const long long m = m_hi - m_lo;                                  // pixels of THIS launch: the tile is chosen for them
     TileChoice tc = choose_tile(d->cout);
     BigTile bt{0, 0};
-    const bool big = !smallc && big_tile_for(d->cout, m, &bt, kpad / bk);
+    const bool big = !smallc && big_tile_for(d->cout, m, &bt, kpad / bk, (d->flags & PPN_CONV_SHARED_GPU) != 0);
     if (d->limb_edge_pad != 0) {
         // edge-aligned limb tile (conv_head.hip): rows [e * limb_edge_pad, +limb_window) of the packed weight / shift1
         // hold edge e's window, the rest of each edge's rows are padding

@@ -876,10 +876,15 @@ static bool tile_shape_ok(int bp, int bc) {
     return (bp == 128 || bp == 192 || bp == 256) && (bc == 64 || bc == 128 || bc == 256) && !(bc == 64 && bp == 192);
 }
 
-// relative efficiency of the 144 x 256 tile in the cost model below (PPN_EFF144 overrides: 0 takes the tile out)
-static const double kEff144 = getenv("PPN_EFF144") ? atof(getenv("PPN_EFF144")) : 0.98;
+// relative efficiency of the 144 x 256 tile in the cost model below (PPN_EFF144 overrides: 0 takes the tile out).
+// Measured (round 4, same box, in sequence): the five 24 x 24 512 -> 512 layers 106.5 -> 94.9 us (= 0.93 on this scale), but
+// layer5's 256 -> 256 launches 101.5 -> 118 / 87.8 -> 96.1 us against 192 x 128 at three rounds (= 0.82-0.87): 0.90 picks it
+// for the former only.  It shortens a LONE launch by filling all 256 CUs with smaller, less efficient workgroups (CU-time
+// per launch +19 %): with three lanes in flight the same switch cost 3.5 % of the images/s (10.69 k vs 11.07 k, two
+// interleaved pairs of runs), so plans that share the GPU (PPN_CONV_SHARED_GPU) never take it.
+static const double kEff144 = getenv("PPN_EFF144") ? atof(getenv("PPN_EFF144")) : 0.90;
 
-bool big_tile_for(int cout, long long m, BigTile* out, int ksteps) {
+bool big_tile_for(int cout, long long m, BigTile* out, int ksteps, bool shared_gpu) {
     if (cout < 64) return false;
     if (g_ov_bp < 0) {                                   // first call: the environment knob
         g_ov_bp = g_ov_bc = 0;
@@ -917,7 +922,7 @@ bool big_tile_for(int cout, long long m, BigTile* out, int ksteps) {
     if (ksteps > 0 && ksteps <= 8 && bc_max == 256) bc_max = 128;
     double best = 1e30;
     for (const Cand& cd : cands) {
-        if (cd.bc > bc_max || cd.bc < bc_min || cd.eff <= 0.0) continue;
+        if (cd.bc > bc_max || cd.bc < bc_min || cd.eff <= 0.0 || (shared_gpu && cd.bp == 144)) continue;
         const long long tiles = ((m + cd.bp - 1) / cd.bp) * ((cout + cd.bc - 1) / cd.bc);
         // policy 1 (several launches in flight on different streams, ppn_set_conv_tile_policy): another stream's
         // workgroups fill a partial last round, so only the tile's efficiency counts

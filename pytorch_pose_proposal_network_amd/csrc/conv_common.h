@@ -188,7 +188,9 @@ struct BigTile {
 };
 // edge-aligned limb tile of the head conv (ppn_conv_desc.limb_edge_pad): 128 pixels x one edge's window padded to 448 rows
 constexpr int kEdgeTileBP = 128, kEdgeTileBC = 448;
-bool big_tile_for(int cout, long long m, BigTile* out, int ksteps = 0);   // ksteps: K steps of the launch (0 = unknown)
+// ksteps: K steps of the launch (0 = unknown); shared_gpu: the launch shares the GPU with other streams' launches
+// (ppn_conv_desc.flags & PPN_CONV_SHARED_GPU): tiles that only shorten a LONE launch are left out
+bool big_tile_for(int cout, long long m, BigTile* out, int ksteps = 0, bool shared_gpu = false);
 // Split point of a two-segment launch (0 = single launch): pixels [0, split) run whole rounds of the most efficient
 // tile, the rest a smaller tile that fills one more round (conv_big.hip).
 long long big_split_for(int cout, long long m);

@@ -40,6 +40,10 @@ struct DecodeParams {
     int S;       // sH*sW
     const unsigned long long* keys;   // fused path: arg-max keys u64 [B][E][ncell] instead of the int arg-max map
     const int* early;                 // root NMS done inside the arg-max launch (early_root_nms) or nullptr
+    // fused path, round 4: the sorted root candidates and their pairwise-suppression bit matrix, computed by the
+    // root_mask_kernel launch in front of the parse (G workgroups per image) -- or nullptr
+    const int* root_hdr;              // i32 [B][root_hdr_stride]: n (-1: not computed, the parse kernel does it), sorted cells
+    const unsigned long long* root_mask;   // u64 [B][ncell][nwords]: row i, word w = [iou(i, j) >= thr] for j = 64 w .. < i
 };
 
 // Root candidates + NMS of an image do not depend on the limb arg-max: in the stand-alone decode the FIRST workgroup of
@@ -123,6 +127,34 @@ __device__ __forceinline__ int block_compact(bool flag, int* s_wave_cnt, int* to
 
 // Steps shared by parse and nms, operating on n boxes already in sorted (priority) order.
 //   s_box/s_area [n], s_mask [n][nw] scratch, s_sel [n] out (sorted positions kept, in order), *s_nsel out.
+// One 64-bit word of the pairwise-suppression matrix: row i, candidates j = 64 w .. min(64 w + 64, i) - 1.
+__device__ __forceinline__ unsigned long long iou_word(int i, int w, const float4* s_box, const float* s_area, float thr) {
+    const int j0 = w * 64;
+    const int j1 = min(j0 + 64, i);
+    unsigned long long bits = 0ull;
+    if (j0 < j1) {
+        const float4 bi = s_box[i];
+        const float ai = s_area[i];
+        // four independent IoU chains in flight: one evaluation is a ~300-cycle dependent chain
+        // (LDS read, min/max, IEEE division) and only ~2 waves share a SIMD here
+        int j = j0;
+        for (; j + 4 <= j1; j += 4) {
+            bool r[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) r[u] = iou_ge(bi, ai, s_box[j + u], s_area[j + u], thr);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) bits |= r[u] ? (1ull << (j + u - j0)) : 0ull;
+        }
+        for (; j < j1; ++j) {
+            if (iou_ge(bi, ai, s_box[j], s_area[j], thr)) bits |= (1ull << (j - j0));
+        }
+    }
+    return bits;
+}
+
+__device__ __forceinline__ void greedy_resolve(int n, int nwords, const unsigned long long* s_mask, int* s_sel, int* s_nsel,
+                                               int limit);
+
 __device__ __forceinline__ void greedy_nms(int n, int nwords, const float4* s_box, const float* s_area,
                                            unsigned long long* s_mask, int* s_sel, int* s_nsel, float thr,
                                            int limit) {
@@ -133,29 +165,16 @@ __device__ __forceinline__ void greedy_nms(int n, int nwords, const float4* s_bo
     // one bank with 9 addresses) and whole waves of the empty upper triangle exit at once.
     for (int q = t; q < n * nwords; q += blockDim.x) {
         const int w = q / n, i = q - w * n;
-        const int j0 = w * 64;
-        const int j1 = min(j0 + 64, i);
-        unsigned long long bits = 0ull;
-        if (j0 < j1) {
-            const float4 bi = s_box[i];
-            const float ai = s_area[i];
-            // four independent IoU chains in flight: one evaluation is a ~300-cycle dependent chain
-            // (LDS read, min/max, IEEE division) and only ~2 waves share a SIMD here
-            int j = j0;
-            for (; j + 4 <= j1; j += 4) {
-                bool r[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) r[u] = iou_ge(bi, ai, s_box[j + u], s_area[j + u], thr);
-#pragma unroll
-                for (int u = 0; u < 4; ++u) bits |= r[u] ? (1ull << (j + u - j0)) : 0ull;
-            }
-            for (; j < j1; ++j) {
-                if (iou_ge(bi, ai, s_box[j], s_area[j], thr)) bits |= (1ull << (j - j0));
-            }
-        }
-        s_mask[(size_t)i * nwords + w] = bits;
+        s_mask[(size_t)i * nwords + w] = iou_word(i, w, s_box, s_area, thr);
     }
     __syncthreads();
+    greedy_resolve(n, nwords, s_mask, s_sel, s_nsel, limit);
+}
+
+// The greedy order on a finished bit matrix (rows in LDS); ends with a workgroup barrier.
+__device__ __forceinline__ void greedy_resolve(int n, int nwords, const unsigned long long* s_mask, int* s_sel, int* s_nsel,
+                                               int limit) {
+    const int t = threadIdx.x;
     // One wave resolves the greedy order, 64 candidates (one per lane) at a time:
     //   (a) in parallel, a lane drops out if any already-kept box of an EARLIER chunk suppresses it;
     //   (b) inside the chunk the dependence is sequential, but it runs on scalar registers only: the chunk's
@@ -201,21 +220,11 @@ __device__ __forceinline__ void greedy_nms(int n, int nwords, const float4* s_bo
     __syncthreads();
 }
 
-// Phases 1-4 of the parse (candidates, rank sort, greedy NMS) for one image.
-// Called by a whole workgroup with blockDim.x >= ncell; LDS: early_lds_bytes(ncell).
-__device__ __forceinline__ void early_root_nms(const ppn_decode_cfg& c, const float* __restrict__ img, int ncell,
-                                               char* smem, int* __restrict__ out) {
+// Phases 1-2 of the parse for one image: root candidates (delta[0] > thr, datatest.py:89), ranked by descending score
+// (ties: ascending cell), boxes / areas / cells stored in priority order.  Whole workgroup, blockDim.x >= ncell; returns n.
+__device__ __forceinline__ int sort_roots(const ppn_decode_cfg& c, const float* __restrict__ img, int ncell, float4* s_box,
+                                          unsigned long long* s_key, float* s_area, int* s_cell, int* s_misc) {
     const int t = threadIdx.x, K = c.K, W = c.W, H = c.H;
-    const int nwords = (ncell + 63) >> 6;
-    size_t off = 0;
-    auto carve = [&](size_t bytes) { char* ptr = smem + off; off += (bytes + 15) & ~size_t(15); return ptr; };
-    float4* s_box = reinterpret_cast<float4*>(carve(sizeof(float4) * ncell));
-    unsigned long long* s_key = reinterpret_cast<unsigned long long*>(carve(8 * ncell));
-    unsigned long long* s_mask = reinterpret_cast<unsigned long long*>(carve(8 * (size_t)ncell * nwords));
-    float* s_area = reinterpret_cast<float*>(carve(4 * ncell));
-    int* s_cell = reinterpret_cast<int*>(carve(4 * ncell));
-    int* s_sel = reinterpret_cast<int*>(carve(4 * ncell));
-    int* s_misc = reinterpret_cast<int*>(carve(4 * 40));
     float d0 = 0.0f;
     bool is_c = false;
     if (t < ncell) {
@@ -243,10 +252,75 @@ __device__ __forceinline__ void early_root_nms(const ppn_decode_cfg& c, const fl
         s_cell[rank] = t;
     }
     __syncthreads();
+    return n;
+}
+
+// Phases 1-4 of the parse (candidates, rank sort, greedy NMS) for one image.
+// Called by a whole workgroup with blockDim.x >= ncell; LDS: early_lds_bytes(ncell).
+__device__ __forceinline__ void early_root_nms(const ppn_decode_cfg& c, const float* __restrict__ img, int ncell,
+                                               char* smem, int* __restrict__ out) {
+    const int t = threadIdx.x;
+    const int nwords = (ncell + 63) >> 6;
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { char* ptr = smem + off; off += (bytes + 15) & ~size_t(15); return ptr; };
+    float4* s_box = reinterpret_cast<float4*>(carve(sizeof(float4) * ncell));
+    unsigned long long* s_key = reinterpret_cast<unsigned long long*>(carve(8 * ncell));
+    unsigned long long* s_mask = reinterpret_cast<unsigned long long*>(carve(8 * (size_t)ncell * nwords));
+    float* s_area = reinterpret_cast<float*>(carve(4 * ncell));
+    int* s_cell = reinterpret_cast<int*>(carve(4 * ncell));
+    int* s_sel = reinterpret_cast<int*>(carve(4 * ncell));
+    int* s_misc = reinterpret_cast<int*>(carve(4 * 40));
+    const int n = sort_roots(c, img, ncell, s_box, s_key, s_area, s_cell, s_misc);
     greedy_nms(n, nwords, s_box, s_area, s_mask, s_sel, s_misc + 33, c.nms_thr, 0);
     const int nsel = s_misc[33];
     if (t == 0) out[0] = nsel;
     if (t < nsel) out[1 + t] = s_cell[s_sel[t]];
+}
+
+// ------------------------------------------------------------------------------------------
+// Fused path, dense heads (round 4): the O(n^2) pairwise-IoU bit matrix of an image's root candidates spread over G
+// workgroups.  One workgroup per image took ~60 of the parse kernel's 109 us for it on the benchmark's heads (~490 of 576
+// cells are root candidates there: 120 k IoU evaluations, each an IEEE division); here every workgroup of an image
+// repeats the cheap phases (candidates, rank sort: identical results) and computes every G-th block of (row, word) items.
+// grid = (G, batch), blockDim >= ncell.  Output per image: hdr[0] = n, hdr[1..n] = cells in priority order, mask rows
+// [n][nwords] (word w of row i written iff 64 w <= i; the rest is never read).  Below `min_n` candidates the spread is not
+// worth a global round trip: hdr[0] = -1 and the parse kernel runs its own NMS as before.  Same device functions, same
+// operation order as the parse kernel's own phases: bit-identical people.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024)
+root_mask_kernel(ppn_decode_cfg c, const float* __restrict__ unary, int C, int ncell, int hdr_stride, int min_n,
+                 int* __restrict__ hdr, unsigned long long* __restrict__ mask) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int t = threadIdx.x, g = blockIdx.x, G = gridDim.x, b = blockIdx.y;
+    const int nwords = (ncell + 63) >> 6;
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { char* ptr = smem + off; off += (bytes + 15) & ~size_t(15); return ptr; };
+    float4* s_box = reinterpret_cast<float4*>(carve(sizeof(float4) * ncell));
+    unsigned long long* s_key = reinterpret_cast<unsigned long long*>(carve(8 * ncell));
+    float* s_area = reinterpret_cast<float*>(carve(4 * ncell));
+    int* s_cell = reinterpret_cast<int*>(carve(4 * ncell));
+    int* s_misc = reinterpret_cast<int*>(carve(4 * 40));
+    const int n = sort_roots(c, unary + (size_t)b * C * ncell, ncell, s_box, s_key, s_area, s_cell, s_misc);
+    int* h = hdr + (size_t)b * hdr_stride;
+    if (n < min_n) {
+        if (g == 0 && t == 0) h[0] = -1;
+        return;
+    }
+    if (g == 0) {
+        if (t == 0) h[0] = n;
+        if (t < n) h[1 + t] = s_cell[t];
+    }
+    unsigned long long* m = mask + (size_t)b * ncell * nwords;
+    const int nw_n = (n + 63) >> 6, total = n * nw_n;
+    for (int q = g * (int)blockDim.x + t; q < total; q += G * (int)blockDim.x) {
+        const int w = q / n, i = q - w * n;
+        if (64 * w <= i) m[(size_t)i * nwords + w] = iou_word(i, w, s_box, s_area, c.nms_thr);
+    }
+}
+
+size_t root_mask_lds_bytes(int ncell) {
+    auto r16 = [](size_t x) { return (x + 15) & ~size_t(15); };
+    return r16(16 * (size_t)ncell) + r16(8 * (size_t)ncell) + 2 * r16(4 * (size_t)ncell) + r16(4 * 40);
 }
 
 size_t early_lds_bytes(int ncell) {
@@ -405,8 +479,40 @@ parse_kernel(DecodeParams p, const float* __restrict__ head, const int* __restri
     // phases 1-4 may already have run inside the arg-max launch (early_root_nms): workgroup-uniform
     const int* early_b = p.early ? p.early + (size_t)b * early_stride(ncell) : nullptr;
     const int early_n = early_b ? early_b[0] : -1;
+    // ... or phases 1-3 in the root_mask_kernel launch in front of this one (fused path): sorted cells + bit matrix
+    const int* root_b = p.root_hdr ? p.root_hdr + (size_t)b * early_stride(ncell) : nullptr;
+    const int root_n = root_b ? root_b[0] : -1;
     int nsel;
-    if (early_n < 0) {
+    if (early_n < 0 && root_n >= 0) {
+        PPN_DT(1);
+        const int n = root_n;
+        if (t < n) s_cell[t] = root_b[1 + t];
+        const unsigned long long* gm = p.root_mask + (size_t)b * ncell * nwords;
+        // rows of the bit matrix, eight loads in flight per thread (words past the diagonal were never written and are
+        // never read by the resolve: they may hold anything)
+        for (int q0 = t; q0 < n * nwords; q0 += 8 * (int)blockDim.x) {
+            unsigned long long v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int q = q0 + u * (int)blockDim.x;
+                v[u] = q < n * nwords ? gm[q] : 0ull;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int q = q0 + u * (int)blockDim.x;
+                if (q < n * nwords) s_mask[q] = v[u];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int i = t + u * pstride;
+            if (i < na) s_am[i] = (unsigned short)pf_a[u];
+        }
+        __syncthreads();
+        PPN_DT(2);
+        greedy_resolve(n, nwords, s_mask, s_sel, s_misc + 33, 0);
+        nsel = s_misc[33];
+    } else if (early_n < 0) {
         // 1. candidates: delta[0] > thr, row-major (datatest.py:89)
         float d0 = 0.0f;
         bool is_c = false;
@@ -742,6 +848,8 @@ extern "C" int ppn_decode(const ppn_decode_cfg* cfg, const float* head, int32_t 
     p.C = 6 * cfg->K + cfg->E * p.S;
     p.keys = nullptr;
     p.early = early_used ? early : nullptr;
+    p.root_hdr = nullptr;
+    p.root_mask = nullptr;
     const int threads = ((ncell + 63) / 64) * 64;
     {
         static int max_lds_set = 0;   // the attribute sticks to the function: set it when it grows
@@ -754,9 +862,19 @@ extern "C" int ppn_decode(const ppn_decode_cfg* cfg, const float* head, int32_t 
     return PPN_OK;
 }
 
-extern "C" int ppn_decode_fused(const ppn_decode_cfg* cfg, const float* unary, const uint64_t* keys, int32_t batch,
-                                int32_t* out_count, int32_t* out_kp_cell, int32_t* out_limb_arg, float* out_bbox,
-                                float* out_score, void* stream) {
+// workspace of the fused decode: root headers i32 [B][early_stride] (whole 128-byte lines) | bit matrices u64 [B][ncell][nwords]
+static size_t ws_root_hdr_bytes(const ppn_decode_cfg* c, int batch) {
+    return (((size_t)batch * early_stride(c->H * c->W) * 4) + 127) & ~size_t(127);
+}
+extern "C" size_t ppn_decode_fused_workspace_bytes(const ppn_decode_cfg* cfg, int32_t batch) {
+    if (!cfg || batch < 0) return 0;
+    const size_t ncell = (size_t)cfg->H * cfg->W;
+    return ws_root_hdr_bytes(cfg, batch) + (size_t)batch * ncell * ((ncell + 63) / 64) * 8;
+}
+
+static int decode_fused_impl(const ppn_decode_cfg* cfg, const float* unary, const uint64_t* keys, int32_t batch,
+                             void* workspace, int32_t* out_count, int32_t* out_kp_cell, int32_t* out_limb_arg,
+                             float* out_bbox, float* out_score, void* stream) {
     if (int rc = check_cfg(cfg)) return rc;
     if (batch < 0) return ppn::fail(PPN_E_INVALID, "ppn_decode_fused: batch < 0");
     if (batch == 0) return PPN_OK;
@@ -765,6 +883,8 @@ extern "C" int ppn_decode_fused(const ppn_decode_cfg* cfg, const float* unary, c
     if (cfg->max_humans < 1) return ppn::fail(PPN_E_INVALID, "ppn_decode_fused: max_humans < 1");
     if (reinterpret_cast<uintptr_t>(out_bbox) % 16 != 0)
         return ppn::fail(PPN_E_INVALID, "ppn_decode_fused: out_bbox must be 16-byte aligned");
+    if (workspace && reinterpret_cast<uintptr_t>(workspace) % 16 != 0)
+        return ppn::fail(PPN_E_INVALID, "ppn_decode_fused_ws: workspace must be 16-byte aligned");
     const int ncell = cfg->H * cfg->W;
     const size_t lds = parse_lds_bytes(ncell, cfg->K, cfg->E);
     if (ncell > 1024 || lds > 160 * 1024)
@@ -776,16 +896,54 @@ extern "C" int ppn_decode_fused(const ppn_decode_cfg* cfg, const float* unary, c
     p.C = 6 * cfg->K;                                                 // compact unary tensor
     p.keys = reinterpret_cast<const unsigned long long*>(keys);
     p.early = nullptr;
+    p.root_hdr = nullptr;
+    p.root_mask = nullptr;
     const int threads = ((ncell + 63) / 64) * 64;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // Spread root NMS (root_mask_kernel): G workgroups per image compute the pairwise-IoU bit matrix in front of the parse.
+    // PPN_DECODE_SPREAD=0 keeps the single-kernel form; PPN_DECODE_SPREAD_MIN: candidates below which an image leaves
+    // the matrix to its parse workgroup (default 128: ~8 k IoU evaluations, a few microseconds on one CU).
+    static const int spread_g = getenv("PPN_DECODE_SPREAD") ? atoi(getenv("PPN_DECODE_SPREAD")) : 8;
+    static const int spread_min = getenv("PPN_DECODE_SPREAD_MIN") ? atoi(getenv("PPN_DECODE_SPREAD_MIN")) : 128;
+    if (workspace && spread_g > 0 && threads <= 1024) {
+        int* hdr = static_cast<int*>(workspace);
+        unsigned long long* mask = reinterpret_cast<unsigned long long*>(static_cast<char*>(workspace) + ws_root_hdr_bytes(cfg, batch));
+        const size_t rlds = root_mask_lds_bytes(ncell);
+        {
+            static int max_lds_set = 0;
+            PPN_LDS_ONCE(max_lds_set, reinterpret_cast<const void*>(root_mask_kernel),
+                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds);
+        }
+        hipLaunchKernelGGL(root_mask_kernel, dim3(spread_g, batch), dim3(threads), rlds, st, *cfg, unary, p.C, ncell,
+                           early_stride(ncell), spread_min, hdr, mask);
+        PPN_LAUNCH_CHECK();
+        p.root_hdr = hdr;
+        p.root_mask = mask;
+    }
     {
         static int max_lds_set = 0;
         PPN_LDS_ONCE(max_lds_set, reinterpret_cast<const void*>(parse_kernel),
                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
-    hipLaunchKernelGGL(parse_kernel, dim3(batch), dim3(threads), lds, static_cast<hipStream_t>(stream), p, unary,
+    hipLaunchKernelGGL(parse_kernel, dim3(batch), dim3(threads), lds, st, p, unary,
                        static_cast<const int*>(nullptr), out_count, out_kp_cell, out_limb_arg, out_bbox, out_score);
     PPN_LAUNCH_CHECK();
     return PPN_OK;
+}
+
+extern "C" int ppn_decode_fused(const ppn_decode_cfg* cfg, const float* unary, const uint64_t* keys, int32_t batch,
+                                int32_t* out_count, int32_t* out_kp_cell, int32_t* out_limb_arg, float* out_bbox,
+                                float* out_score, void* stream) {
+    return decode_fused_impl(cfg, unary, keys, batch, nullptr, out_count, out_kp_cell, out_limb_arg, out_bbox, out_score,
+                             stream);
+}
+
+extern "C" int ppn_decode_fused_ws(const ppn_decode_cfg* cfg, const float* unary, const uint64_t* keys, int32_t batch,
+                                   void* workspace, int32_t* out_count, int32_t* out_kp_cell, int32_t* out_limb_arg,
+                                   float* out_bbox, float* out_score, void* stream) {
+    if (!workspace) return ppn::fail(PPN_E_INVALID, "ppn_decode_fused_ws: NULL workspace");
+    return decode_fused_impl(cfg, unary, keys, batch, workspace, out_count, out_kp_cell, out_limb_arg, out_bbox, out_score,
+                             stream);
 }
 
 extern "C" int ppn_nms(const float* bbox, const float* score, int32_t n, float thresh, int32_t limit,

@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("PPN_LIB", os.path.join(_HERE, "csrc", "libppn.so"))  
 PPN_MAX_EDGES = 32
 PPN_MAX_KP = 32
 PPN_F32, PPN_BF16, PPN_F16, PPN_F16X3 = 0, 1, 2, 3
-PPN_CONV_NO_FILTER_BANK = 1          # ppn_conv_desc.flags
+PPN_CONV_NO_FILTER_BANK, PPN_CONV_SHARED_GPU = 1, 2          # ppn_conv_desc.flags
 PPN_ACT_NONE, PPN_ACT_RELU, PPN_ACT_LRELU, PPN_ACT_SIGMOID = 0, 1, 2, 3
 
 
@@ -80,6 +80,9 @@ _SIGNATURES = {
                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ppn_decode_fused": (C.c_int, [C.POINTER(DecodeCfg), C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ppn_decode_fused_workspace_bytes": (C.c_size_t, [C.POINTER(DecodeCfg), C.c_int32]),
+    "ppn_decode_fused_ws": (C.c_int, [C.POINTER(DecodeCfg), C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ppn_limb_argmax": (C.c_int, [C.POINTER(DecodeCfg), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "ppn_nms": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_int32, C.c_void_p, C.c_void_p,
                           C.c_void_p]),

@@ -538,10 +538,12 @@ class PoseProposalNet:
         L.check(self._lib.ppn_plan_run(plan.handle, L.current_stream_ptr()), "ppn_plan_run")
         return plan.head
 
-    def profile_layers(self, x: torch.Tensor, src_is_u8: bool = False, repeats: int = 1, fused_decode: bool = False):
+    def profile_layers(self, x: torch.Tensor, src_is_u8: bool = False, repeats: int = 1, fused_decode: bool = False,
+                       conv_flags: int = 0):
         """Per-launch durations (ms) measured with HIP events on the launch stream: [(op name, kernel, ms, flops)].
-        `repeats` launches of each op are issued back to back between its events (amortises the event gap)."""
-        plan = self._plan_for(x.contiguous(), src_is_u8, fused_decode)
+        `repeats` launches of each op are issued back to back between its events (amortises the event gap).
+        conv_flags: as forward_u8 -- pass the timed path's flags to time the kernels THAT path runs."""
+        plan = self._plan_for(x.contiguous(), src_is_u8, fused_decode, conv_flags=conv_flags)
         ms = (C.c_float * plan.n_ops)()
         L.check(self._lib.ppn_plan_run_timed(plan.handle, L.current_stream_ptr(), ms, plan.n_ops, repeats),
                 "ppn_plan_run_timed")

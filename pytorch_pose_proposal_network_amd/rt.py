@@ -188,7 +188,7 @@ class MultiLaneInference:
         # vs 10.96 k images/s with three lanes).  The choice travels in THIS pipeline's plans (ppn_conv_desc.flags), so
         # other plans, trainers and pipelines of the process -- and a user's PPN_CONV64 setting -- are untouched;
         # results are bit-identical either way.
-        self._conv_flags = L.PPN_CONV_NO_FILTER_BANK if lanes > 1 else 0
+        self._conv_flags = (L.PPN_CONV_NO_FILTER_BANK | L.PPN_CONV_SHARED_GPU) if lanes > 1 else 0
 
     def close(self):
         from . import lib as L

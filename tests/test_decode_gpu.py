@@ -209,3 +209,56 @@ def test_early_root_nms_candidate_cap_boundary():
         exp = D.decode_ref(heads[i])
         assert len(exp["cand"]) == n, (i, len(exp["cand"]), n)
         _assert_same(out[i], exp, f"{n} candidates")
+
+
+def _unary_and_keys(heads):
+    """What the fused head conv leaves for Decoder.decode_fused: the 6K unary channels and one u64 key per (image, edge,
+    cell) = sigmoid value bits << 32 | ~(first arg-max index of the 21x21 window)."""
+    h = torch.from_numpy(heads).cuda()
+    B = h.shape[0]
+    e = h[:, 6 * cfg.K:].reshape(B, len(cfg.EDGES), -1, h.shape[2], h.shape[3])
+    val, _ = e.max(dim=2)
+    first = (e == val.unsqueeze(2)).float().argmax(dim=2)                              # lowest index among ties
+    keys = (val.contiguous().view(torch.int32).to(torch.int64) << 32) | (0xFFFFFFFF - first)
+    return h[:, :6 * cfg.K].contiguous(), keys.contiguous()
+
+
+def test_fused_decode_spread_root_nms_candidate_counts():
+    """Fused path (round 4): the pairwise-IoU bit matrix of an image's root candidates is computed by 8 workgroups per image
+    in front of the parse kernel (csrc/decode.hip root_mask_kernel) when the image has >= 128 candidates, by the parse
+    workgroup itself below that.  One batch mixing 0, 1, 64, 127, 128, 129, 200, 490 and 576 candidates: every image equals
+    the NumPy oracle (datatest.py:74-160 restated) AND the single-kernel entry point, bit for bit, whichever kernel built
+    its matrix."""
+    import ctypes as C
+    from pytorch_pose_proposal_network_amd import lib as L
+    dec = _decode_mod()
+    counts = [0, 1, 127, 128, 129, 200, 576, 64, 490]
+    heads = []
+    for i, n in enumerate(counts):
+        h = make_head("random", 700 + i)
+        g = np.random.default_rng(900 + i)
+        cells = g.permutation(576)[:n]
+        resp = np.full(576, 0.05, np.float32)
+        resp[cells] = g.uniform(0.6, 1.0, n).astype(np.float32)
+        h[0] = resp.reshape(24, 24)
+        h[18] = np.float32(0.9)
+        heads.append(h)
+    heads = np.stack(heads)
+    unary, keys = _unary_and_keys(heads)
+    d = dec.Decoder(len(counts))
+    got = d.decode_fused(unary, keys).to_host()
+    got = [{k: (v.copy() if hasattr(v, "copy") else v) for k, v in r.items()} for r in got]
+    for i, n in enumerate(counts):
+        exp = D.decode_ref(heads[i])
+        assert len(exp["cand"]) == n, (i, len(exp["cand"]), n)
+        _assert_same(got[i], exp, f"fused, {n} candidates")
+    # the single-kernel entry point (no workspace): same people
+    o, c = d.out, d.cfg
+    L.check(d.lib.ppn_decode_fused(C.byref(c), unary.data_ptr(), keys.data_ptr(), len(counts), o.count.data_ptr(),
+                                   o.kp_cell.data_ptr(), o.limb_arg.data_ptr(), o.bbox.data_ptr(), o.score.data_ptr(),
+                                   L.current_stream_ptr()), "ppn_decode_fused")
+    one = o.to_host()
+    for i in range(len(counts)):
+        assert one[i]["n"] == got[i]["n"]
+        for k in ("kp_cell", "limb_arg", "bbox", "score"):
+            assert np.array_equal(one[i][k], got[i][k]), (i, k)
