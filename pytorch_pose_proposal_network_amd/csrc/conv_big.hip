@@ -926,6 +926,9 @@ bool big_tile_for(int cout, long long m, BigTile* out, int ksteps, bool shared_g
         const long long tiles = ((m + cd.bp - 1) / cd.bp) * ((cout + cd.bc - 1) / cd.bc);
         // policy 1 (several launches in flight on different streams, ppn_set_conv_tile_policy): another stream's
         // workgroups fill a partial last round, so only the tile's efficiency counts
+        // (round 4, measured and dropped: under PPN_CONV_SHARED_GPU, launches with fewer tiles than CUs -- the 24 x 24 layers --
+        // priced by efficiency alone, i.e. 256 x 256 tiles on 144 of the CUs: 10.79 / 10.79 k images/s against 10.83 / 10.84 k
+        // with the whole-round rule, interleaved runs on one box, and 3.25 vs 3.16 ms for the conv stack in sequence)
         const double rounds = g_tile_policy == 1 ? (double)tiles / 256.0 : (double)((tiles + 255) / 256);
         const double cost = rounds * cd.bp * cd.bc / cd.eff;
         if (cost < best) { best = cost; out->bp = cd.bp; out->bc = cd.bc; }

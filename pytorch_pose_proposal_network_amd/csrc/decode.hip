@@ -310,11 +310,31 @@ root_mask_kernel(ppn_decode_cfg c, const float* __restrict__ unary, int C, int n
         if (t == 0) h[0] = n;
         if (t < n) h[1 + t] = s_cell[t];
     }
-    unsigned long long* m = mask + (size_t)b * ncell * nwords;
-    const int nw_n = (n + 63) >> 6, total = n * nw_n;
+    // Work item = one QUARTER (16 candidates j) of one 64-bit word of one row: 4x the items of the per-word split, so that
+    // every thread of the G workgroups has one and the dependent chain per thread is 16 IoU evaluations, not 64.
+    unsigned short* m16 = reinterpret_cast<unsigned short*>(mask + (size_t)b * ncell * nwords);
+    const int nq_n = 4 * ((n + 63) >> 6), total = n * nq_n;     // whole words: every quarter of a word that is read is written
     for (int q = g * (int)blockDim.x + t; q < total; q += G * (int)blockDim.x) {
-        const int w = q / n, i = q - w * n;
-        if (64 * w <= i) m[(size_t)i * nwords + w] = iou_word(i, w, s_box, s_area, c.nms_thr);
+        const int qw = q / n, i = q - qw * n;                      // consecutive lanes: consecutive rows, same s_box[j]
+        const int w = qw >> 2, j0 = qw * 16;
+        if (64 * w > i) continue;                                 // word past the diagonal: never read
+        const int j1 = min(j0 + 16, i);
+        unsigned bits = 0u;
+        if (j0 < j1) {
+            const float4 bi = s_box[i];
+            const float ai = s_area[i];
+            int j = j0;
+            for (; j + 4 <= j1; j += 4) {
+                bool r[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) r[u] = iou_ge(bi, ai, s_box[j + u], s_area[j + u], c.nms_thr);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) bits |= r[u] ? (1u << (j + u - j0)) : 0u;
+            }
+            for (; j < j1; ++j)
+                if (iou_ge(bi, ai, s_box[j], s_area[j], c.nms_thr)) bits |= (1u << (j - j0));
+        }
+        m16[((size_t)i * nwords + w) * 4 + (qw & 3)] = (unsigned short)bits;      // little endian: quarter k = bits 16k..
     }
 }
 

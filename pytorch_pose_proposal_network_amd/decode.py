@@ -170,7 +170,9 @@ class Decoder:
         ws = self.lib.ppn_decode_workspace_bytes(C.byref(c), batch)
         dev = torch.device(device)
         self.workspace = torch.empty(max(ws, 16) // 4, dtype=torch.int32, device=dev)
-        self._fused_ws = None
+        # root candidates + pairwise-IoU bit matrices of the fused path (ppn_decode_fused_ws)
+        wsf = self.lib.ppn_decode_fused_workspace_bytes(C.byref(c), batch)
+        self._fused_ws = torch.empty(max(wsf, 16) // 4, dtype=torch.int32, device=dev)
         m = c.max_humans
         self.out = DecodeResult(
             count=torch.zeros(batch, dtype=torch.int32, device=dev),
@@ -200,9 +202,6 @@ class Decoder:
         if tuple(keys.shape) != (self.batch, c.E, c.H, c.W) or keys.dtype != torch.int64:
             raise ValueError(f"keys must be i64 {(self.batch, c.E, c.H, c.W)}")
         o = self.out
-        if self._fused_ws is None:                      # root candidates + pairwise-IoU bit matrices (ppn_decode_fused_ws)
-            nbytes = self.lib.ppn_decode_fused_workspace_bytes(C.byref(c), self.batch)
-            self._fused_ws = torch.empty(max(nbytes, 16) // 4, dtype=torch.int32, device=unary.device)
         L.check(self.lib.ppn_decode_fused_ws(C.byref(c), unary.data_ptr(), keys.data_ptr(), self.batch,
                                              self._fused_ws.data_ptr(), o.count.data_ptr(), o.kp_cell.data_ptr(),
                                              o.limb_arg.data_ptr(), o.bbox.data_ptr(), o.score.data_ptr(),
