@@ -125,8 +125,8 @@ def main_train(args):
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    if args.dtype == "f16":
-        raise SystemExit("--workload train: the float16 mode is inference only (bf16 / f32)")
+    if args.dtype in ("f16", "f16x3"):
+        raise SystemExit("--workload train: the float16 / float16x3 modes are inference only (bf16 / f32)")
     # PPN_BENCH_BACKEND=gloo rehearses the N>1 control flow on a box with fewer GPUs than ranks (ranks share devices)
     backend = os.environ.get("PPN_BENCH_BACKEND", "nccl")
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -596,9 +596,10 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="frames per GPU")
     ap.add_argument("--size", type=int, default=384)
     ap.add_argument("--arch", default="drn_d_22")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "f16"],
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "f16", "f16x3"],
                     help="bf16 = BASELINE configs[1] (the headline); f32 = the 1e-4 parity mode; f16 = IEEE half at the bf16 MFMA "
-                         "rate (inference only)")
+                         "rate (inference only); f16x3 = split-f16 operands, three products per pair: meets the 1e-4 tolerance "
+                         "at ~2.7x the f32 rate (inference only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true",
                     help="skip the batch-consistency check of the last timed step (profiling runs: its batch-2 passes would mix "
@@ -652,7 +653,8 @@ def main():
     _fail_hook(rank)
     B, S = args.batch, args.size
     net = model.PoseProposalNet(getattr(drn, args.arch)(), insize=(S, S), outsize=(S // 16, S // 16),
-                                compute_dtype={"bf16": "bfloat16", "f32": "float32", "f16": "float16"}[args.dtype]).cuda(dev)
+                                compute_dtype={"bf16": "bfloat16", "f32": "float32", "f16": "float16",
+                                               "f16x3": "float16x3"}[args.dtype]).cuda(dev)
     net.load_state_dict(synth.make_state_dict(args.arch, 0, bn_stats=load_bn_stats(args.arch)))
     net.eval()
     # resident in HBM: NROT distinct batches, step i reads batch i % NROT (no step re-reads its predecessor's frames)
@@ -783,7 +785,9 @@ def main():
         fwd_flops = sum(a[1] for a in agg.values()) / reps
         dom = max(agg.items(), key=lambda kv: kv[1][0])
         dk, (dms, dfl, dn) = dom
-        peak = F32_MFMA_PEAK_TFLOPS if args.dtype == "f32" else BF16_DENSE_PEAK_TFLOPS     # f16 MFMA = the bf16 rate
+        # f16 MFMA = the bf16 rate; f16x3 spends three f16 MFMAs per algorithmic multiply-add: a third of it
+        peak = (F32_MFMA_PEAK_TFLOPS if args.dtype == "f32" else
+                BF16_DENSE_PEAK_TFLOPS / 3.0 if args.dtype == "f16x3" else BF16_DENSE_PEAK_TFLOPS)
         achieved = dfl / (dms * 1e-3) / 1e12
         if args.layers:
             for name, kern, ms, fl in table:
