@@ -818,7 +818,10 @@ def main():
             "value_windows": {"what": f"{len(win)} consecutive windows of {args.steps} steps each, same fences; `value` "
                                       "is the first", "n": len(win), "min": round(win_vals[0], 2),
                               "median": round(win_vals[len(win_vals) // 2], 2), "max": round(win_vals[-1], 2)},
-            "config": {"workload": f"{args.arch} PPN inference {args.dtype}, batch {B}/GPU synthetic {S}x{S} u8 frames: "
+            "config": {"workload": f"{args.arch} PPN inference {args.dtype}"
+                                   + (" (stem internals in IEEE half: 1.8 % of the FLOPs, the model's default)"
+                                      if (args.dtype == "bf16" and getattr(net, "stem_dtype", None) == 2) else "")
+                                   + f", batch {B}/GPU synthetic {S}x{S} u8 frames: "
                                    "fused normalise + conv stack + head + decode/NMS/limb-parse (BASELINE configs[1])"
                                    + ("" if fused else ", head tensor materialised")
                                    + (f", batches go round-robin over {max(1, args.lanes)} stream lanes (rt.MultiLaneInference)"

@@ -387,6 +387,10 @@ int ppn_plan_add_stem012(ppn_plan* p, int32_t src_is_u8, const void* src, int32_
                          const float* shift2, const float* scale3, const float* shift3, void* out_raw, void* out_act);
 /* The same with the 16-bit type as an argument: dtype = PPN_BF16 (== the two entry points above) or PPN_F16 (IEEE half
  * storage and MFMA operands, outputs NHWC f16). */
+/* dtype of the *_dt entry points: PPN_BF16 / PPN_F16 = the stem's MFMA operand type, on-chip storage type and output
+ * type; PPN_STEM_IO(PPN_F16, PPN_BF16) = IEEE-half operands and on-chip tensors, bf16 OUTPUT tensors (what the bf16 mode runs
+ * since round 4: the stem's rounding noise is amplified by every layer behind it, csrc/stem012.hip). */
+#define PPN_STEM_IO(internal, out) ((internal) | (((out) + 1) << 8))
 int ppn_stem012_dt(int32_t dtype, int32_t src_is_u8, const void* src, int32_t batch, int32_t h, int32_t w, const float* w0,
                    const float* scale0, const float* shift0, const float* mean, const float* std_, const float* w1,
                    const float* scale1, const float* shift1, const float* w2, const float* scale2, const float* shift2,

@@ -179,7 +179,8 @@ extern "C" int ppn_plan_add_stem012_dt(ppn_plan* p, int32_t dtype, int32_t src_i
                                     const float* shift1, const float* w2, const float* scale2, const float* shift2,
                                     const float* scale3, const float* shift3, void* out_raw, void* out_act) {
     if (!p) return ppn::fail(PPN_E_INVALID, "ppn_plan_add_stem012: NULL plan");
-    if (dtype != PPN_BF16 && dtype != PPN_F16) return ppn::fail(PPN_E_INVALID, "ppn_plan_add_stem012: dtype must be PPN_BF16 or PPN_F16");
+    if ((dtype & 0xff) != PPN_BF16 && (dtype & 0xff) != PPN_F16)
+        return ppn::fail(PPN_E_INVALID, "ppn_plan_add_stem012: dtype must be PPN_BF16, PPN_F16 or PPN_STEM_IO(PPN_F16, PPN_BF16)");
     ppn_plan::Op op{};
     op.kind = 4;
     op.dtype = dtype; op.src_is_u8 = src_is_u8; op.src = src; op.batch = batch; op.h = h; op.w = w;

@@ -61,7 +61,8 @@ class _Plan:
 class PoseProposalNet:
     def __init__(self, backbone="drn_d_22", insize=(384, 384), outsize=(24, 24),
                  keypoint_names=cfg.KEYPOINT_NAMES, local_grid_size=(21, 21), edges=cfg.EDGES,
-                 compute_dtype: str = "float32", fuse_stem=None, fuse_shortcut: Optional[bool] = None):
+                 compute_dtype: str = "float32", fuse_stem=None, fuse_shortcut: Optional[bool] = None,
+                 stem_dtype: Optional[str] = None):
         self.arch = _arch_of(backbone)
         self.insize = insize
         self.outsize = outsize
@@ -78,6 +79,17 @@ class PoseProposalNet:
                               "float16x3": L.PPN_F16X3, "f16x3": L.PPN_F16X3}[compute_dtype]
         self.training = False
         self.device = torch.device("cuda")
+        # Type the FUSED stem (csrc/stem012.hip, 16-bit modes) computes in: its MFMA operands and on-chip tensors; its two
+        # output tensors are always stored in the trunk's type.  The bf16 mode defaults to IEEE half (round 4): the stem
+        # is 1.8 % of the FLOPs, but its rounding noise passes through every layer behind it -- half internals take the
+        # bf16 pipeline from 95 to ~150 of the reference's 260 people at the same speed (PPN_STEM_DTYPE=bfloat16 / the
+        # argument restore the all-bf16 stem).
+        sdt = stem_dtype or (os.environ.get("PPN_STEM_DTYPE") if self.compute_dtype == L.PPN_BF16 else None) or \
+            ("float16" if self.compute_dtype in (L.PPN_BF16, L.PPN_F16) else None)
+        self.stem_dtype = {None: None, "float16": L.PPN_F16, "fp16": L.PPN_F16, "f16": L.PPN_F16, "bfloat16": L.PPN_BF16,
+                           "bf16": L.PPN_BF16}[sdt]
+        if self.compute_dtype == L.PPN_F16 and self.stem_dtype == L.PPN_BF16:
+            raise ValueError("the float16 mode has no bfloat16 stem")
         if fuse_stem is None:
             # bf16 mode: the three stem layers share one launch (csrc/stem012.hip; PPN_FUSE_STEM=0 keeps them apart);
             # the exact-f32 parity mode runs them layer by layer
@@ -379,7 +391,10 @@ class PoseProposalNet:
             odt = self._op_dtype(op)
             if op.k == 7 and op.next_s2 is not None:
                 assert op.src == "input" and self.compute_dtype in (L.PPN_BF16, L.PPN_F16)
-                L.check(lib.ppn_plan_add_stem012_dt(handle, self.compute_dtype, 1 if src_is_u8 else 0, src.data_ptr(), batch, h, w,
+                sdt = self.compute_dtype
+                if self.stem_dtype is not None and self.stem_dtype != self.compute_dtype:
+                    sdt = self.stem_dtype | ((self.compute_dtype + 1) << 8)          # PPN_STEM_IO(internal, out)
+                L.check(lib.ppn_plan_add_stem012_dt(handle, sdt, 1 if src_is_u8 else 0, src.data_ptr(), batch, h, w,
                                                  self._ptr(op.name + ".w"), self._ptr(op.name + ".s1"),
                                                  self._ptr(op.name + ".b1"), self._mean, self._std,
                                                  self._ptr(op.name + ".w1"), self._ptr(op.name + ".s1b"),
