@@ -269,6 +269,10 @@ typedef struct ppn_conv_desc {
  * leaves out the tiles that only shorten a LONE launch by filling every CU with smaller, less efficient workgroups (the
  * 144 x 256 tile of the 24 x 24 layers: -11 % in sequence, +19 % CU-time, -3.5 % images/s with three lanes). */
 #define PPN_CONV_SHARED_GPU 2
+/* PPN_CONV_OUT_BF16: a PPN_F16 launch (large-tile kernel, NHWC) stores out_raw / out_act as bf16 -- the last launch of an
+ * IEEE-half PREFIX in front of a bf16 trunk.  The bf16 mode runs the stem and layer3-4 (6.9 % of DRN-D-22's FLOPs) in half
+ * since round 4: same kernels, same rate, and the rounding noise injected there is what every later layer amplifies. */
+#define PPN_CONV_OUT_BF16 4
 
 /* GEMM-depth step / channel tile the packer must pad to for a conv of this shape and dtype, and the order of
  * the GEMM depth index in the packed weight rows:

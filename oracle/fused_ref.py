@@ -44,13 +44,15 @@ def _bf16(t):
 
 def fused_forward_ref(sd, x: torch.Tensor, arch: str = "drn_d_22", emulate_bf16: bool = False, taps=None,
                       fuse_stem=False, emulate_dtype=None, residual_dtype="same", fuse_shortcut: bool = True,
-                      stem_dtype=None):
+                      stem_dtype=None, half_prefix: int = -1):
     """x f32 [B,3,H,W] (normalised) -> head f32 [B,C,H/16,W/16], walking the fused program.
     emulate_dtype=torch.float16 emulates the PPN_F16 mode's storage roundings the way emulate_bf16 does bf16's.
     residual_dtype (precision study, tests/precision_study.py): storage type of the tensors that are ONLY ever read as a
     residual (never as a convolution operand) -- "same" = emulate_dtype, None = f32, or a torch dtype.
     stem_dtype: the type the stem (layer0-2) computes in -- its weights, input patch and the tensors between its layers --
-    while its outputs are stored in emulate_dtype (the bf16 mode's default since round 4: torch.float16)."""
+    while its outputs are stored in emulate_dtype (the bf16 mode's default since round 4: torch.float16).
+    half_prefix: the launches of backbone.0 .. backbone.{half_prefix} compute and store in IEEE half, and a tensor is stored
+    in the type of the launches that read it (the bf16 mode's default since round 4: 4 = stem + layer3 + layer4)."""
     ops = A.build_program(arch, fuse_stem=fuse_stem, fuse_shortcut=fuse_shortcut)
     if emulate_dtype is None and emulate_bf16:
         emulate_dtype = torch.bfloat16
@@ -61,6 +63,14 @@ def fused_forward_ref(sd, x: torch.Tensor, arch: str = "drn_d_22", emulate_bf16:
     else:
         q_res = (lambda t: t.to(residual_dtype).float()) if residual_dtype is not None else (lambda t: t)
     q_trunk = q
+    half_names = tuple(f"backbone.{i}." for i in range(half_prefix + 1)) if (half_prefix >= 3 and emulate_dtype is not None) else ()
+    q_half = lambda t: t.to(torch.float16).float()          # noqa: E731
+    in_half = lambda o: bool(half_names) and o.name.startswith(half_names)          # noqa: E731
+    read_q = {}                                             # tensor -> rounding of the launches that read it
+    for o in ops:
+        for name in (o.src, o.residual, o.ds_src):
+            if name:
+                read_q[name] = q_half if in_half(o) else q_trunk
     qs = (lambda t: t.to(stem_dtype).float()) if (stem_dtype is not None and emulate_dtype is not None) else None
     stem_names = {o.name for o in ops[:3] if o.cin in (3, 16)} if qs is not None else set()
     tensors = {"input": x.float()}
@@ -69,9 +79,9 @@ def fused_forward_ref(sd, x: torch.Tensor, arch: str = "drn_d_22", emulate_bf16:
             # inside the stem: weights, patch and the tensors between its layers in stem_dtype; what LEAVES the stem (the
             # outputs of its last layer) in the trunk's type
             in_stem = op.name in stem_names
-            q = qs if in_stem else q_trunk
+            q = qs if in_stem else (q_half if in_half(op) else q_trunk)
             last_stem = in_stem and (op.next_s2 is not None or (op.cin == 16 and op.cout == 32))
-            q_store = q_trunk if (last_stem or not in_stem) else qs
+            q_store = qs if (in_stem and not last_stem) else None      # None: the type of the launches that read the tensor
             src = tensors[op.src]
             w = _t(sd[op.weight]).float()
             if op.k == 7:
@@ -111,13 +121,14 @@ def fused_forward_ref(sd, x: torch.Tensor, arch: str = "drn_d_22", emulate_bf16:
             if op.residual:
                 v = v + tensors[op.residual]
             if op.out_raw:
-                tensors[op.out_raw] = v if op.nchw_f32_out else (q_store(v) if op.out_raw in operands else q_res(v))
+                qo = q_store or read_q.get(op.out_raw, q_trunk)
+                tensors[op.out_raw] = v if op.nchw_f32_out else (qo(v) if op.out_raw in operands else q_res(v))
             if op.out_act:
                 u = v
                 if op.bn2:
                     s2, b2 = _fold(sd, op.bn2)
                     u = u * s2.float().view(1, -1, 1, 1) + b2.float().view(1, -1, 1, 1)
-                tensors[op.out_act] = q_store(_ACT[op.act2](u))
+                tensors[op.out_act] = (q_store or read_q.get(op.out_act, q_trunk))(_ACT[op.act2](u))
             if taps is not None:
                 taps[op.name] = tensors[op.out_raw or op.out_act]
     return tensors["head"]

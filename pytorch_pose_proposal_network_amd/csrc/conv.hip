@@ -553,7 +553,8 @@ int ppn::conv_launch(const ppn_conv_desc* d, hipStream_t st, const char** kname)
         }
     }
     // 64 -> 64 3x3 stride 1 in the 16-bit modes: the register-resident filter bank kernel (conv64.hip), same results
-    if (ppn::conv64_supported(d) && d->in_h == d->out_h && d->in_w == d->out_w) return ppn::conv64_launch(d, st, kname);
+    if (ppn::conv64_supported(d) && d->in_h == d->out_h && d->in_w == d->out_w && !(d->flags & PPN_CONV_OUT_BF16))
+        return ppn::conv64_launch(d, st, kname);
     const long long m = m_hi - m_lo;                                  // pixels of THIS launch: the tile is chosen for them
     TileChoice tc = choose_tile(d->cout);
     BigTile bt{0, 0};
@@ -622,6 +623,9 @@ int ppn::conv_launch(const ppn_conv_desc* d, hipStream_t st, const char** kname)
     a.unary_ch = d->unary_channels;
     a.window = d->limb_window;
     a.lo_off = x3 ? d->cin * 2 : 0;                                   // source pixel = [hi(cin) | lo'(cin)] halves
+    a.out_bf16 = (d->flags & PPN_CONV_OUT_BF16) ? 1 : 0;
+    if (a.out_bf16 && (d->dtype != PPN_F16 || !big || d->out_nchw_f32))
+        return ppn::fail(PPN_E_UNSUPPORTED, "PPN_CONV_OUT_BF16: a PPN_F16 launch of the large-tile kernel with NHWC outputs");
     if (x3 && !big) return ppn::fail(PPN_E_UNSUPPORTED, "PPN_F16X3 is implemented by the large-tile kernel only");
     if (big) return launch_big(a, d->dtype, bt, st, kname);
     if (d->argmax_keys) return ppn::fail(PPN_E_UNSUPPORTED, "fused arg-max is implemented by the large-tile kernel only");

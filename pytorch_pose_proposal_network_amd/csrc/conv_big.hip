@@ -451,7 +451,7 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
     constexpr bool kFastFits = !X3 && sizeof(T) == 2 && BC >= 128 && (size_t)BP * RS16 <= 2 * (size_t)STAGE;
 #endif
     bool fast = false;
-    if constexpr (kFastFits) fast = !a.nchw && !a.residual && !a.out_act && a.out_raw && (a.Cout & 7) == 0;
+    if constexpr (kFastFits) fast = !a.nchw && !a.residual && !a.out_act && a.out_raw && (a.Cout & 7) == 0 && !a.out_bf16;
     if (fast) {
         if constexpr (kFastFits) {
             const float slope1 = a.act1 == PPN_ACT_RELU ? 0.f : (a.act1 == PPN_ACT_LRELU ? 0.1f : 1.f);
@@ -594,7 +594,10 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
 #else
                         if (a.out_raw) {
                             if constexpr (X3) store8_x3(a.out_raw + off, lo_bytes, v);
-                            else store8<T>(a.out_raw + off, v);
+                            else if constexpr (std::is_same<T, _Float16>::value) {
+                                if (a.out_bf16) store8<__bf16>(a.out_raw + off, v);      // f16 launch feeding a bf16 trunk
+                                else store8<T>(a.out_raw + off, v);
+                            } else store8<T>(a.out_raw + off, v);
                         }
 #endif
                         if (a.out_act) {
@@ -605,7 +608,10 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
                                 u[i] = fmaxf(t2, t2 * slope2);
                             }
                             if constexpr (X3) store8_x3(a.out_act + off, lo_bytes, u);
-                            else store8<T>(a.out_act + off, u);
+                            else if constexpr (std::is_same<T, _Float16>::value) {
+                                if (a.out_bf16) store8<__bf16>(a.out_act + off, u);
+                                else store8<T>(a.out_act + off, u);
+                            } else store8<T>(a.out_act + off, u);
                         }
                     }
                 }

@@ -58,6 +58,7 @@ struct ConvKArgs {
     int nsteps_main;                  // K steps of the main convolution; the rest belong to the shortcut
     unsigned src2_bytes;
     int lo_off;                       // PPN_F16X3: bytes from a pixel's hi block to its lo' block in the SOURCE tensor
+    int out_bf16;                     // PPN_F16 launch whose NHWC outputs are stored as bf16 (PPN_CONV_OUT_BF16)
 };
 
 template <typename T>

@@ -17,7 +17,7 @@ from oracle import decode_ref as D, forward_ref as Fr, fused_ref  # noqa: E402
 from pytorch_pose_proposal_network_amd import arch as A, decode, prng, synth  # noqa: E402
 
 
-def forward_mixed(sd, x, arch, first_16bit, dt, exact_from=0, stem_dt=None):
+def forward_mixed(sd, x, arch, first_16bit, dt, exact_from=0, stem_dt=None, prefix_dt=None):
     """fused program without stem / shortcut fusion; launches [exact_from, first_16bit) are exact, the others round weights
     and stored outputs to `dt`."""
     ops = A.build_program(arch, fuse_stem=False, fuse_shortcut=False)
@@ -25,6 +25,8 @@ def forward_mixed(sd, x, arch, first_16bit, dt, exact_from=0, stem_dt=None):
     with torch.no_grad():
         for i, op in enumerate(ops):
             q = (lambda t: t.to(dt).float()) if (i >= first_16bit or i < exact_from) else (lambda t: t)
+            if prefix_dt is not None and exact_from <= i < first_16bit:
+                q = lambda t: t.to(prefix_dt).float()           # noqa: E731  the "exact" range runs in prefix_dt instead
             if stem_dt is not None and i < 3:
                 # the stem computes in `stem_dt` (its weights, its input patch, the tensors between its layers); what leaves
                 # it (launch 2's outputs) is stored in the trunk's type
@@ -68,6 +70,7 @@ def main():
     ap.add_argument("--exact-from", type=int, default=0, help="first exact launch (3 = behind the three stem layers)")
     ap.add_argument("--cuts", default="")
     ap.add_argument("--stem", default="", help="float16 / float32: the three stem launches compute in this type")
+    ap.add_argument("--prefix", default="", help="float16: launches [exact-from, cut) run in this 16-bit type instead of exactly")
     args = ap.parse_args()
     dt = {"float16": torch.float16, "bfloat16": torch.bfloat16}[args.tail]
     torch.set_num_threads(min(8, os.cpu_count() or 1))
@@ -91,7 +94,9 @@ def main():
         cuts = [int(c) for c in args.cuts.split(",")]
     for cut in cuts:
         stem_dt = {"": None, "float16": torch.float16, "float32": torch.float32}[args.stem]
-        head = np.concatenate([forward_mixed(sd, x[i:i + 1], arch, cut, dt, args.exact_from, stem_dt)[0].numpy() for i in range(batch)])
+        prefix_dt = {"": None, "float16": torch.float16}[args.prefix]
+        head = np.concatenate([forward_mixed(sd, x[i:i + 1], arch, cut, dt, args.exact_from, stem_dt, prefix_dt)[0].numpy()
+                               for i in range(batch)])
         tot = np.zeros(5, np.int64)
         for i in range(batch):
             tot += np.array(decode.people_agreement(exp[i], D.decode_ref(head[i], insize=(size, size))))
@@ -99,7 +104,8 @@ def main():
         share = sum(fl[args.exact_from:cut]) / sum(fl)
         # cost model: exact launches at 3x the 16-bit cost (float16x3)
         cost = (2 * sum(fl[args.exact_from:cut]) + sum(fl)) / sum(fl)
-        print((f"[stem in {args.stem}] " if args.stem else "") + f"{args.fixture} exact from launch {args.exact_from} up to launch {cut:2d} ({names[cut] if cut < len(ops) else 'end':26s}) = {share:5.1%} of the FLOPs, "
+        print((f"[stem in {args.stem}] " if args.stem else "") + (f"[prefix in {args.prefix}] " if args.prefix else "") +
+              f"{args.fixture} exact from launch {args.exact_from} up to launch {cut:2d} ({names[cut] if cut < len(ops) else 'end':26s}) = {share:5.1%} of the FLOPs, "
               f"tail {args.tail}: people exact {exact}/{n}, same root {same}/{n}, kp cells {kp_eq}/{kp_all}; relative MFMA cost {cost:.2f}",
               flush=True)
 

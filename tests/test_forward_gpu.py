@@ -99,8 +99,9 @@ def _bf16_case(golden_dir, name, mode="bfloat16"):
     stats = {k[3:]: g[k] for k in g.files if k.startswith("bn/")}
     sd = synth.make_state_dict(arch, int(g["seed_w"]), bn_stats=stats)
     torch.set_num_threads(min(16, os.cpu_count() or 1))   # a 1-GPU box owns a 16-core share
-    # the 16-bit models' default: the fused stem with IEEE-half internals, outputs in the trunk's type
+    # the 16-bit models' default policy: the fused stem with IEEE-half internals; bf16 mode: stem + layer3-4 in half
     emu = fused_ref.fused_forward_ref(sd, Fr.normalize_u8(u8), arch, fuse_stem="all", stem_dtype=torch.float16,
+                                      half_prefix=4 if mode == "bfloat16" else -1,
                                       emulate_dtype=torch.float16 if mode == "float16" else torch.bfloat16).numpy()
     if "head" in g.files:
         de, dr, dq = np.abs(head - emu), np.abs(head - g["head"]), np.abs(emu - g["head"])
@@ -277,7 +278,7 @@ def test_non_square_inputs(golden_dir, hw):
           f"mean {de16.mean():.5f}")
     _assert_16bit(de16, d16, np.abs(emu16 - ref), f"{H}x{W} float16")
     emu = fused_ref.fused_forward_ref(sd, Fr.normalize_u8(u8), "drn_d_22", emulate_bf16=True, fuse_stem="all",
-                                      stem_dtype=torch.float16).numpy()
+                                      stem_dtype=torch.float16, half_prefix=4).numpy()
     err = np.abs(heads["float32"] - ref).max()
     d, de = np.abs(heads["bfloat16"] - ref), np.abs(heads["bfloat16"] - emu)
     print(f"{H}x{W}: f32 |hip-oracle| {err:.2e}; bf16 vs f32 oracle max {d.max():.3f} mean {d.mean():.4f}, "

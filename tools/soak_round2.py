@@ -20,7 +20,7 @@ sd = synth.make_state_dict("drn_d_22", 0, bn_stats={k: g[k] for k in g.files})
 def net(size_hw, fuse):
     h, w = size_hw
     m = model.PoseProposalNet(drn.drn_d_22(), insize=(w, h), outsize=(w // 16, h // 16), compute_dtype="bfloat16",
-                              fuse_stem=fuse, stem_dtype="bfloat16").cuda()     # all-bf16 stem: bit-identical to the three launches
+                              fuse_stem=fuse, stem_dtype="bfloat16", half_prefix=-1).cuda()     # all-bf16 stem: bit-identical to the three launches
     m.load_state_dict(sd)
     return m.eval()
 
