@@ -531,6 +531,23 @@ def extra_sections(args, dev, net, frames, dec):
         if args.arch == "drn_d_22" and S == 384:
             res["f16_agreement"] = _agreement(n16, "e2e_d22_384")
             res["f16_agreement_tuned_checkpoint"] = _agreement(n16, "e2e_tuned_d22_384")
+        # the same trunk behind an EXACT prefix (stem + layer3 as f32 / float16x3 launches, 4.3 % of the FLOPs): the noise of
+        # the first layers is what every later layer amplifies
+        del pipe16
+        nxp = model.PoseProposalNet(getattr(drn, args.arch)(), insize=(S, S), outsize=(S // 16, S // 16),
+                                    compute_dtype="float16", exact_prefix=3).cuda(dev)
+        nxp.load_state_dict(net.state_dict())
+        pipex = rt.MultiLaneInference(nxp, B, (S, S), device=dev, lanes=lanes)
+        for _ in range(3 * lanes):
+            pipex.submit(frames)
+        dtx = _time_steps(lambda: pipex.submit(frames), dev, 20, warmup=3)
+        pipex.close()
+        xp = {"what": "float16 trunk, stem + layer3 exact (PoseProposalNet(compute_dtype='float16', exact_prefix=3))",
+              "images_per_sec": round(B / dtx, 1), "ms_per_step": round(dtx * 1e3, 3), "lanes": lanes}
+        if args.arch == "drn_d_22" and S == 384:
+            xp["agreement"] = _agreement(nxp, "e2e_d22_384")
+            xp["agreement_tuned_checkpoint"] = _agreement(nxp, "e2e_tuned_d22_384")
+        res["exact_prefix_3"] = xp
         return res
 
     def tile_policy_1():

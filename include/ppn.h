@@ -273,6 +273,10 @@ typedef struct ppn_conv_desc {
  * IEEE-half PREFIX in front of a bf16 trunk.  The bf16 mode runs the stem and layer3-4 (6.9 % of DRN-D-22's FLOPs) in half
  * since round 4: same kernels, same rate, and the rounding noise injected there is what every later layer amplifies. */
 #define PPN_CONV_OUT_BF16 4
+/* PPN_CONV_X3_PLAIN_OUT: a PPN_F16X3 launch stores out_raw / out_act as plain IEEE-half NHWC tensors [pixel][Cout] instead of
+ * half pairs -- the last launch of an exact (f32 + float16x3) PREFIX in front of a float16 trunk
+ * (PoseProposalNet(compute_dtype="float16", exact_prefix=3): stem + layer3 exact, 251 of the reference's 260 people). */
+#define PPN_CONV_X3_PLAIN_OUT 8
 
 /* GEMM-depth step / channel tile the packer must pad to for a conv of this shape and dtype, and the order of
  * the GEMM depth index in the packed weight rows:

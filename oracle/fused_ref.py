@@ -44,7 +44,7 @@ def _bf16(t):
 
 def fused_forward_ref(sd, x: torch.Tensor, arch: str = "drn_d_22", emulate_bf16: bool = False, taps=None,
                       fuse_stem=False, emulate_dtype=None, residual_dtype="same", fuse_shortcut: bool = True,
-                      stem_dtype=None, half_prefix: int = -1):
+                      stem_dtype=None, half_prefix: int = -1, exact_prefix: int = -1):
     """x f32 [B,3,H,W] (normalised) -> head f32 [B,C,H/16,W/16], walking the fused program.
     emulate_dtype=torch.float16 emulates the PPN_F16 mode's storage roundings the way emulate_bf16 does bf16's.
     residual_dtype (precision study, tests/precision_study.py): storage type of the tensors that are ONLY ever read as a
@@ -52,7 +52,9 @@ def fused_forward_ref(sd, x: torch.Tensor, arch: str = "drn_d_22", emulate_bf16:
     stem_dtype: the type the stem (layer0-2) computes in -- its weights, input patch and the tensors between its layers --
     while its outputs are stored in emulate_dtype (the bf16 mode's default since round 4: torch.float16).
     half_prefix: the launches of backbone.0 .. backbone.{half_prefix} compute and store in IEEE half, and a tensor is stored
-    in the type of the launches that read it (the bf16 mode's default since round 4: 4 = stem + layer3 + layer4)."""
+    in the type of the launches that read it (the bf16 mode's default since round 4: 4 = stem + layer3 + layer4).
+    exact_prefix: the launches of backbone.0 .. backbone.{exact_prefix} are exact (f32 / float16x3 on the GPU: no rounding
+    emulated); what they hand to the 16-bit trunk is rounded to its type (PoseProposalNet(exact_prefix=))."""
     ops = A.build_program(arch, fuse_stem=fuse_stem, fuse_shortcut=fuse_shortcut)
     if emulate_dtype is None and emulate_bf16:
         emulate_dtype = torch.bfloat16
@@ -66,11 +68,14 @@ def fused_forward_ref(sd, x: torch.Tensor, arch: str = "drn_d_22", emulate_bf16:
     half_names = tuple(f"backbone.{i}." for i in range(half_prefix + 1)) if (half_prefix >= 3 and emulate_dtype is not None) else ()
     q_half = lambda t: t.to(torch.float16).float()          # noqa: E731
     in_half = lambda o: bool(half_names) and o.name.startswith(half_names)          # noqa: E731
+    exact_names = tuple(f"backbone.{i}." for i in range(exact_prefix + 1)) if (exact_prefix >= 3 and emulate_dtype is not None) else ()
+    q_exact = lambda t: t                                   # noqa: E731
+    in_exact = lambda o: bool(exact_names) and o.name.startswith(exact_names)       # noqa: E731
     read_q = {}                                             # tensor -> rounding of the launches that read it
     for o in ops:
         for name in (o.src, o.residual, o.ds_src):
             if name:
-                read_q[name] = q_half if in_half(o) else q_trunk
+                read_q[name] = q_exact if in_exact(o) else (q_half if in_half(o) else q_trunk)
     qs = (lambda t: t.to(stem_dtype).float()) if (stem_dtype is not None and emulate_dtype is not None) else None
     stem_names = {o.name for o in ops[:3] if o.cin in (3, 16)} if qs is not None else set()
     tensors = {"input": x.float()}
@@ -79,7 +84,8 @@ def fused_forward_ref(sd, x: torch.Tensor, arch: str = "drn_d_22", emulate_bf16:
             # inside the stem: weights, patch and the tensors between its layers in stem_dtype; what LEAVES the stem (the
             # outputs of its last layer) in the trunk's type
             in_stem = op.name in stem_names
-            q = qs if in_stem else (q_half if in_half(op) else q_trunk)
+            q = q_exact if in_exact(op) else (qs if in_stem else (q_half if in_half(op) else q_trunk))
+            in_stem = in_stem and not in_exact(op)
             last_stem = in_stem and (op.next_s2 is not None or (op.cin == 16 and op.cout == 32))
             q_store = qs if (in_stem and not last_stem) else None      # None: the type of the launches that read the tensor
             src = tensors[op.src]

@@ -180,7 +180,7 @@ def build_program(arch: str = "drn_d_22", head_channels: Optional[int] = None, f
     the 16x384x384 tensor between them never goes to HBM (measured slower than the two launches, kept as an option).
     "all" -- layer0, layer1 and layer2 (3x3 stride 2 16->32) in one launch (csrc/stem012.hip, bf16 mode): neither
     16-channel full-resolution tensor goes to HBM; needs one conv per stem layer (every DRN-D variant has that)."""
-    # fuse_shortcut: a BasicBlock's 1x1 projection shortcut (+BN) becomes extra GEMM depth of its second conv
+    # fuse_shortcut (bool, or a predicate of the unit's prefix): a BasicBlock's 1x1 projection shortcut (+BN) becomes extra GEMM depth of its second conv
     # (no separate launch, no residual tensor) when its input width is a multiple of 64 and the block is narrow.
     hc = head_channels or cfg.lastsize()
     units = _units(arch)
@@ -241,7 +241,8 @@ def build_program(arch: str = "drn_d_22", head_channels: Optional[int] = None, f
             # worth 0-3 % of the step (their separate 1x1 launches under-fill the GPU); for the 512-wide blocks it
             # loses 6-30 us each (the two-source loader slows every K step of a launch that is already efficient)
             # -> fuse only up to 256 output channels
-            fuse_ds = u.downsample and fuse_shortcut and u.cin % 64 == 0 and 64 <= u.cout <= 256
+            fuse_ok = fuse_shortcut(u.prefix) if callable(fuse_shortcut) else fuse_shortcut
+            fuse_ds = u.downsample and fuse_ok and u.cin % 64 == 0 and 64 <= u.cout <= 256
             if u.downsample and not fuse_ds:
                 res = t(p.replace(".", "_") + "_ds")
                 ops.append(ConvOp(f"{p}.downsample", raw, f"{p}.downsample.0.weight", u.cin, u.cout, 1,

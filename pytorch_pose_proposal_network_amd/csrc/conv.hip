@@ -623,6 +623,9 @@ int ppn::conv_launch(const ppn_conv_desc* d, hipStream_t st, const char** kname)
     a.unary_ch = d->unary_channels;
     a.window = d->limb_window;
     a.lo_off = x3 ? d->cin * 2 : 0;                                   // source pixel = [hi(cin) | lo'(cin)] halves
+    a.out_plain = (d->flags & PPN_CONV_X3_PLAIN_OUT) ? 1 : 0;
+    if (a.out_plain && (!x3 || d->out_nchw_f32))
+        return ppn::fail(PPN_E_UNSUPPORTED, "PPN_CONV_X3_PLAIN_OUT: a PPN_F16X3 launch with NHWC outputs");
     a.out_bf16 = (d->flags & PPN_CONV_OUT_BF16) ? 1 : 0;
     if (a.out_bf16 && (d->dtype != PPN_F16 || !big || d->out_nchw_f32))
         return ppn::fail(PPN_E_UNSUPPORTED, "PPN_CONV_OUT_BF16: a PPN_F16 launch of the large-tile kernel with NHWC outputs");

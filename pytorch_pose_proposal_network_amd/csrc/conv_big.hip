@@ -583,7 +583,12 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
                         const f32x4 hi = *reinterpret_cast<const f32x4*>(ct + px * LD + cg * 8 + 4);
                         v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w;
                         v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
-                        const size_t off = moff[pass];
+                        // X3 launch that feeds a plain-half trunk (PPN_CONV_X3_PLAIN_OUT): the residual it READS is a half
+                        // pair tensor (row = 2 Cout halves), what it WRITES plain half rows (Cout halves)
+                        size_t off = moff[pass];
+                        if constexpr (X3) {
+                            if (a.out_plain) off = (size_t)mrow[pass] * lo_bytes + (size_t)c * ES;
+                        }
 #pragma unroll
                         for (int i = 0; i < 8; ++i) {
                             const float t1 = v[i] * s1[i] + b1[i];
@@ -593,7 +598,10 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
                         if (a.out_raw && v[0] == 12345.678f) store8<T>(a.out_raw + off, v);
 #else
                         if (a.out_raw) {
-                            if constexpr (X3) store8_x3(a.out_raw + off, lo_bytes, v);
+                            if constexpr (X3) {
+                                if (a.out_plain) store8<_Float16>(a.out_raw + off, v);
+                                else store8_x3(a.out_raw + off, lo_bytes, v);
+                            }
                             else if constexpr (std::is_same<T, _Float16>::value) {
                                 if (a.out_bf16) store8<__bf16>(a.out_raw + off, v);      // f16 launch feeding a bf16 trunk
                                 else store8<T>(a.out_raw + off, v);
@@ -607,7 +615,10 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
                                 const float t2 = v[i] * s2[i] + b2[i];
                                 u[i] = fmaxf(t2, t2 * slope2);
                             }
-                            if constexpr (X3) store8_x3(a.out_act + off, lo_bytes, u);
+                            if constexpr (X3) {
+                                if (a.out_plain) store8<_Float16>(a.out_act + off, u);
+                                else store8_x3(a.out_act + off, lo_bytes, u);
+                            }
                             else if constexpr (std::is_same<T, _Float16>::value) {
                                 if (a.out_bf16) store8<__bf16>(a.out_act + off, u);
                                 else store8<T>(a.out_act + off, u);

@@ -59,6 +59,7 @@ struct ConvKArgs {
     unsigned src2_bytes;
     int lo_off;                       // PPN_F16X3: bytes from a pixel's hi block to its lo' block in the SOURCE tensor
     int out_bf16;                     // PPN_F16 launch whose NHWC outputs are stored as bf16 (PPN_CONV_OUT_BF16)
+    int out_plain;                    // PPN_F16X3 launch whose NHWC outputs are stored as plain half (PPN_CONV_X3_PLAIN_OUT)
 };
 
 template <typename T>

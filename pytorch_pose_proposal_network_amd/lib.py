@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("PPN_LIB", os.path.join(_HERE, "csrc", "libppn.so"))  
 PPN_MAX_EDGES = 32
 PPN_MAX_KP = 32
 PPN_F32, PPN_BF16, PPN_F16, PPN_F16X3 = 0, 1, 2, 3
-PPN_CONV_NO_FILTER_BANK, PPN_CONV_SHARED_GPU, PPN_CONV_OUT_BF16 = 1, 2, 4          # ppn_conv_desc.flags
+PPN_CONV_NO_FILTER_BANK, PPN_CONV_SHARED_GPU, PPN_CONV_OUT_BF16, PPN_CONV_X3_PLAIN_OUT = 1, 2, 4, 8   # ppn_conv_desc.flags
 PPN_ACT_NONE, PPN_ACT_RELU, PPN_ACT_LRELU, PPN_ACT_SIGMOID = 0, 1, 2, 3
 
 

@@ -62,7 +62,7 @@ class PoseProposalNet:
     def __init__(self, backbone="drn_d_22", insize=(384, 384), outsize=(24, 24),
                  keypoint_names=cfg.KEYPOINT_NAMES, local_grid_size=(21, 21), edges=cfg.EDGES,
                  compute_dtype: str = "float32", fuse_stem=None, fuse_shortcut: Optional[bool] = None,
-                 stem_dtype: Optional[str] = None, half_prefix: Optional[int] = None):
+                 stem_dtype: Optional[str] = None, half_prefix: Optional[int] = None, exact_prefix: int = -1):
         self.arch = _arch_of(backbone)
         self.insize = insize
         self.outsize = outsize
@@ -105,6 +105,23 @@ class PoseProposalNet:
                 raise ValueError("half_prefix >= 3 needs the IEEE-half stem (stem_dtype='float16')")
             self.half_prefix = -1                              # an all-bf16 stem was asked for: pure bf16
         self._half_names = tuple(f"backbone.{i}." for i in range(self.half_prefix + 1)) if self.half_prefix >= 3 else ()
+        # float16 mode with an EXACT prefix (round 4): the launches of backbone.0 .. backbone.{exact_prefix} run as in the
+        # float16x3 mode (f32 where cin < 64, split-f16 elsewhere) and the last of them stores plain half for the f16 trunk
+        # (PPN_CONV_X3_PLAIN_OUT).  exact_prefix=3 (stem + layer3, 4.3 % of the FLOPs): 251 of the reference's 260 people
+        # where the plain f16 mode reproduces 233 (emulated: tests/precision_study_mixed.py).
+        self.exact_prefix = exact_prefix if self.compute_dtype == L.PPN_F16 else -1
+        if exact_prefix >= 0 and (self.compute_dtype != L.PPN_F16 or exact_prefix < 3):
+            raise ValueError("exact_prefix is an option of the float16 mode and covers at least backbone.0 .. backbone.3")
+        self._exact_names = tuple(f"backbone.{i}." for i in range(self.exact_prefix + 1)) if self.exact_prefix >= 3 else ()
+        if self._exact_names:
+            if fuse_stem not in (None, False, True):
+                raise ValueError("an exact prefix runs the stem as f32 launches (fuse_stem False / True)")
+            fuse_stem = bool(fuse_stem)
+            if fuse_shortcut is None:
+                fuse_shortcut = os.environ.get("PPN_FUSE_SHORTCUT", "1") != "0"
+            if fuse_shortcut and not callable(fuse_shortcut):
+                names = self._exact_names
+                fuse_shortcut = lambda prefix: not (prefix + ".").startswith(names)        # noqa: E731  (no fused shortcut in split launches)
         if fuse_stem is None:
             # bf16 mode: the three stem layers share one launch (csrc/stem012.hip; PPN_FUSE_STEM=0 keeps them apart);
             # the exact-f32 parity mode runs them layer by layer
@@ -118,7 +135,7 @@ class PoseProposalNet:
             fuse_stem, fuse_shortcut = False, False
         if fuse_stem == "all" and self.compute_dtype in (L.PPN_F32, L.PPN_F16X3):
             raise ValueError("fuse_stem='all' (csrc/stem012.hip) is a 16-bit-mode kernel")
-        if self.compute_dtype == L.PPN_F16 and fuse_stem != "all":
+        if self.compute_dtype == L.PPN_F16 and fuse_stem != "all" and not self._exact_names:
             raise ValueError("the float16 mode runs the stem through csrc/stem012.hip only (fuse_stem='all')")
         if fuse_stem != "all":                                # the half prefix starts with the fused stem's half outputs
             self._half_names, self.half_prefix = (), -1
@@ -326,7 +343,8 @@ class PoseProposalNet:
         kernel does not cover (cin not a multiple of 64: the stem and the first block's stride-2 convs) as exact f32."""
         if self.compute_dtype == L.PPN_BF16:
             return L.PPN_F16 if (self._half_names and op.name.startswith(self._half_names)) else L.PPN_BF16
-        if self.compute_dtype != L.PPN_F16X3:
+        exact = self.compute_dtype == L.PPN_F16X3 or (self._exact_names and op.name.startswith(self._exact_names))
+        if not exact:
             return self.compute_dtype
         return L.PPN_F16X3 if (op.k != 7 and op.cin % 64 == 0 and op.cout >= 64) else L.PPN_F32
 
@@ -353,49 +371,59 @@ class PoseProposalNet:
         tdt = self._tdt()
         shapes = A.tensor_shapes(self._ops, h, w)
         bufs: Dict[str, torch.Tensor] = {}
-        x3 = self.compute_dtype == L.PPN_F16X3
         producer = {}                                 # tensor name -> dtype of the launch that writes it
         for op in self._ops:
             for name in (op.out_raw, op.out_act):
                 if name:
                     producer[name] = self._op_dtype(op)
-        # storage type of every tensor = the type of the launches that READ it (bf16 mode with an IEEE-half prefix: the last
-        # half launch stores bf16 for the trunk); a tensor nobody reads as an operand keeps its producer's type
-        store_dt = dict(producer)
-        readers: Dict[str, set] = {}
+        readers: Dict[str, set] = {}                  # tensor name -> dtypes of the launches that read it
         for op in self._ops:
             for name in (op.src, op.residual, op.ds_src):
-                if name and name != "input" and not x3:
+                if name and name != "input":
                     readers.setdefault(name, set()).add(self._op_dtype(op))
-        for name, kinds in readers.items():
-            assert len(kinds) == 1, f"{name}: read by launches of different types {kinds}"
-            store_dt[name] = next(iter(kinds))
-        need_split = set()                            # f32-produced tensors a split-f16 launch reads (float16x3 mode)
-        if x3:
-            for op in self._ops:
-                if self._op_dtype(op) == L.PPN_F16X3:
-                    for name in (op.src, op.residual):
-                        if name and producer.get(name) == L.PPN_F32:
-                            need_split.add(name)
+        # Storage of every tensor.  f32 launches write f32 (plus a half-PAIR copy made by a split launch where a float16x3
+        # launch reads it); float16x3 launches write half pairs, or plain half when only float16 launches read the tensor
+        # (the last launch of an exact prefix); float16 launches write half, or bf16 when only bf16 launches read it (the
+        # last launch of the bf16 mode's half prefix).  A tensor is read by launches of ONE type (f32 + split excepted).
+        F32, BF16, F16, X3 = L.PPN_F32, L.PPN_BF16, L.PPN_F16, L.PPN_F16X3
+        store_dt, need_split = {}, set()
+        for name, p_ in producer.items():
+            rs = readers.get(name, set())
+            if p_ == F32:
+                assert rs <= {F32, X3}, f"{name}: an f32 tensor read by {rs}"
+                store_dt[name] = F32
+                if X3 in rs:
+                    need_split.add(name)
+            elif p_ == X3:
+                if rs and rs <= {F16}:
+                    store_dt[name] = F16                      # PPN_CONV_X3_PLAIN_OUT
                 else:
-                    assert op.src == "input" or producer[op.src] == L.PPN_F32, "an f32 launch cannot read a split tensor"
-                    assert not op.residual or producer[op.residual] == L.PPN_F32
+                    assert rs <= {X3}, f"{name}: a half-pair tensor read by {rs}"
+                    store_dt[name] = X3
+            elif p_ == F16:
+                if rs == {BF16}:
+                    store_dt[name] = BF16                     # PPN_CONV_OUT_BF16
+                else:
+                    assert rs <= {F16}, f"{name}: a half tensor read by {rs}"
+                    store_dt[name] = F16
+            else:
+                assert rs <= {BF16}, f"{name}: a bf16 tensor read by {rs}"
+                store_dt[name] = BF16
+        x3 = bool(need_split) or any(v == X3 for v in store_dt.values())       # the plan holds split launches
         for name, (th, tw, tc) in shapes.items():
             if name == "input":
                 continue
             if name == "head":
                 bufs[name] = torch.empty(batch, tc, th, tw, dtype=torch.float32, device=dev)
-            elif x3 and producer[name] == L.PPN_F16X3:
+            elif store_dt[name] == X3:
                 bufs[name] = torch.empty(batch, th, tw, 2 * tc, dtype=torch.float16, device=dev)   # [hi(C) | lo'(C)]
-            elif x3:
-                bufs[name] = torch.empty(batch, th, tw, tc, dtype=torch.float32, device=dev)
-                if name in need_split:
-                    bufs[name + "#x3"] = torch.empty(batch, th, tw, 2 * tc, dtype=torch.float16, device=dev)
             else:
                 bufs[name] = torch.empty(batch, th, tw, tc, dtype=self._tdt(store_dt[name]), device=dev)
+                if name in need_split:
+                    bufs[name + "#x3"] = torch.empty(batch, th, tw, 2 * tc, dtype=torch.float16, device=dev)
 
         def rd(name, odt):                            # the buffer a launch of dtype `odt` reads tensor `name` from
-            return bufs[name + "#x3"] if (odt == L.PPN_F16X3 and producer.get(name) == L.PPN_F32) else bufs[name]
+            return bufs[name + "#x3"] if (odt == L.PPN_F16X3 and store_dt.get(name) == L.PPN_F32) else bufs[name]
 
         def add_splits(op):                           # behind an f32 launch: convert the outputs split launches read
             for name in (op.out_raw, op.out_act):
@@ -438,12 +466,13 @@ class PoseProposalNet:
                 continue
             if op.k == 7 and op.next3x3 is not None:
                 assert op.src == "input" and op.out_act is None
-                L.check(lib.ppn_plan_add_stem01(handle, self.compute_dtype, 1 if src_is_u8 else 0, src.data_ptr(),
+                L.check(lib.ppn_plan_add_stem01(handle, odt, 1 if src_is_u8 else 0, src.data_ptr(),
                                                 batch, h, w, self._ptr(op.name + ".w"), self._ptr(op.name + ".s1"),
                                                 self._ptr(op.name + ".b1"), self._mean, self._std,
                                                 self._ptr(op.name + ".w1"), self._ptr(op.name + ".s1b"),
                                                 self._ptr(op.name + ".b1b"), bufs[op.out_raw].data_ptr()),
                         "ppn_plan_add_stem01")
+                add_splits(op)
                 continue
             if op.k == 7:
                 assert op.src == "input" and op.out_act is None
@@ -456,12 +485,17 @@ class PoseProposalNet:
             d = L.ConvDesc()
             d.dtype = odt
             d.flags = conv_flags
-            if not x3 and odt == L.PPN_F16:
-                outs = [store_dt[n] for n in (op.out_raw, op.out_act) if n and n in store_dt and n != "head"]
-                if outs and all(o == L.PPN_BF16 for o in outs):
+            outs = [store_dt[n] for n in (op.out_raw, op.out_act) if n and n in store_dt and n != "head"]
+            if odt == L.PPN_F16 and outs:
+                if all(o == L.PPN_BF16 for o in outs):
                     d.flags |= L.PPN_CONV_OUT_BF16                                   # last launch of the IEEE-half prefix
                 else:
                     assert all(o == L.PPN_F16 for o in outs), f"{op.name}: outputs of mixed storage types"
+            if odt == L.PPN_F16X3 and outs:
+                if all(o == L.PPN_F16 for o in outs):
+                    d.flags |= L.PPN_CONV_X3_PLAIN_OUT                               # last launch of an exact prefix
+                else:
+                    assert all(o == L.PPN_F16X3 for o in outs), f"{op.name}: outputs of mixed storage types"
             d.batch, d.in_h, d.in_w, d.cin = batch, ih, iw, op.cin
             d.out_h, d.out_w, d.cout = oh, ow, op.cout
             d.ksize, d.stride, d.dilation, d.pad = op.k, op.stride, op.dilation, op.pad
@@ -519,7 +553,7 @@ class PoseProposalNet:
                     entries.append((f"{name}[{lo}:{lo + n}]", flops * n // m_all))
                 continue
             L.check(lib.ppn_plan_add_conv(handle, C.byref(d)), f"ppn_plan_add_conv({op.name})")
-            if x3 and odt == L.PPN_F32:
+            if odt == L.PPN_F32:
                 add_splits(op)
         head = (bufs["unary"], bufs["keys"]) if fused else bufs["head"]
         return _Plan(handle, bufs, head, entries, A.conv_flops(self._ops, h, w) * batch, src)

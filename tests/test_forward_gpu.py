@@ -20,12 +20,15 @@ F32_TOL = 1e-4
 # E = |emulated oracle - fp32 reference| (what the storage policy itself costs on this checkpoint):
 #   |HIP - reference|        mean <= 1.25 x mean(E), 99.99th percentile <= 1.5 x that of E, max <= 2 x max(E)
 #                                                              -- the kernels add no error class of their own
-#   |HIP - emulated oracle|  mean <= mean(E), 99.99th percentile <= that of E, max <= 1.5 x max(E)
+#   |HIP - emulated oracle|  mean <= 1.5 x mean(E), 99.99th percentile <= 1.5 x that of E, max <= 2 x max(E)
 #                               -- two correct implementations of one policy differ by single flipped roundings
-#                               (summation order), amplified like the policy's own noise: their distance must stay
-#                               below the policy's distance to the reference
+#                               (summation order), amplified like the policy's own noise.  Where they share most of their
+#                               roundings (the plain modes) they end up CLOSER to each other than to the reference (measured
+#                               ~0.5 E); where the noise sources are independent (an exact prefix in front of a 16-bit tail)
+#                               two implementations that are each E from the reference are sqrt(2) E apart: the bound is
+#                               that independent case with 6 % of slack
 # (the maximum over 10^5..10^6 head elements is a tail statistic of two samples of one distribution: hence its own factor)
-REF_FACTORS, EMU_FACTORS = (1.25, 1.5, 2.0), (1.0, 1.0, 1.5)
+REF_FACTORS, EMU_FACTORS = (1.25, 1.5, 2.0), (1.5, 1.5, 2.0)
 
 
 def _assert_16bit(de, dr, dq, what):
