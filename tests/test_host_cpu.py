@@ -279,3 +279,36 @@ def test_ap_against_people_on_the_reference_fixture():
             one["bbox"][p, k] = [cy + k - 10, cx + 2 * k - 10, cy + k + 10, cx + 2 * k + 10]
         one["bbox"][p, 0] = [cy - 40, cx - 40, cy + 40, cx + 40]
     assert np.allclose(E.ap_against_people([one], [one]), 100.0)
+
+
+def test_per_launch_dtype_policies_of_the_inference_modes():
+    """Host logic of the mixed-precision inference modes (no GPU: constructing a PoseProposalNet only lowers the program):
+    which launches run in which type.  bf16 mode: stem + layer3-4 in IEEE half (half_prefix=4), everything else bf16;
+    float16x3: f32 where cin < 64, split-f16 elsewhere; float16 with exact_prefix=3: stem + layer3 as in float16x3, half
+    from layer4 on, no fused shortcut inside the prefix."""
+    from pytorch_pose_proposal_network_amd import lib as L, model
+    m = model.PoseProposalNet("drn_d_22", compute_dtype="bfloat16")
+    kinds = {o.name: m._op_dtype(o) for o in m._ops}
+    assert m.half_prefix == 4 and m.stem_dtype == L.PPN_F16
+    assert all(v == L.PPN_F16 for k, v in kinds.items() if k.startswith(("backbone.0", "backbone.3.", "backbone.4.")))
+    assert all(v == L.PPN_BF16 for k, v in kinds.items() if not k.startswith(("backbone.0", "backbone.3.", "backbone.4.")))
+    pure = model.PoseProposalNet("drn_d_22", compute_dtype="bfloat16", stem_dtype="bfloat16", half_prefix=-1)
+    assert {pure._op_dtype(o) for o in pure._ops} == {L.PPN_BF16}
+    with pytest.raises(ValueError):
+        model.PoseProposalNet("drn_d_22", compute_dtype="bfloat16", stem_dtype="bfloat16", half_prefix=4)
+    x3 = model.PoseProposalNet("drn_d_22", compute_dtype="float16x3")
+    for o in x3._ops:
+        want = L.PPN_F16X3 if (o.k != 7 and o.cin % 64 == 0) else L.PPN_F32
+        assert x3._op_dtype(o) == want, o.name
+    assert not any(o.ds_src for o in x3._ops)                         # no fused shortcut in split launches
+    xp = model.PoseProposalNet("drn_d_22", compute_dtype="float16", exact_prefix=3)
+    kinds = {o.name: xp._op_dtype(o) for o in xp._ops}
+    assert kinds["backbone.0.0"] == L.PPN_F32 and kinds["backbone.3.0.conv1"] == L.PPN_F32
+    assert kinds["backbone.3.0.conv2"] == kinds["backbone.3.1.conv2"] == L.PPN_F16X3
+    assert all(v == L.PPN_F16 for k, v in kinds.items() if not k.startswith(("backbone.0", "backbone.1", "backbone.2", "backbone.3.")))
+    assert any(o.ds_src for o in xp._ops if o.name.startswith("backbone.4."))      # the trunk keeps its fused shortcuts
+    with pytest.raises(ValueError):
+        model.PoseProposalNet("drn_d_22", compute_dtype="bfloat16", exact_prefix=3)
+    # Bottleneck trunks lower the same way
+    d54 = model.PoseProposalNet("drn_d_54", compute_dtype="bfloat16")
+    assert d54._op_dtype(d54._ops[-1]) == L.PPN_BF16 and d54._op_dtype(d54._ops[0]) == L.PPN_F16
