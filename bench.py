@@ -647,6 +647,9 @@ def main():
     ap.add_argument("--lanes", type=int, default=int(os.environ.get("PPN_LANES", "3")),
                     help="stream lanes successive steps alternate between (rt.MultiLaneInference); 1 = one lane with "
                          "the same kernels (what the rocprofv3 per-kernel durations are compared with)")
+    ap.add_argument("--shared-plan", action="store_true",
+                    help="with --lanes 1: run the MULTI-lane plan (generic 64 -> 64 kernel, no lone-launch tiles) with one launch in "
+                         "flight -- profiler runs, so that per-kernel durations describe the kernels the multi-lane headline runs")
     ap.add_argument("--first-order", action="store_true",
                     help="--workload train: model gradient = d loss/d theta only (skip d Lgrad/d theta of main.py:759)")
     ap.add_argument("--tile-policy", type=int, default=0, choices=[0, 1, 2],
@@ -704,7 +707,7 @@ def main():
     if fused and not args.no_pipeline:
         from pytorch_pose_proposal_network_amd import rt
         pipe = rt.MultiLaneInference(net, B, (S, S), device=dev, lanes=max(1, args.lanes),
-                                     tile_policy=args.tile_policy)
+                                     tile_policy=args.tile_policy, shared_plan=True if args.shared_plan else None)
 
     step_no = [0]
 
@@ -976,6 +979,11 @@ def main():
                                         "h2d_alone_ms": round(h2d_ms, 4),
                                         "h2d_alone_gbps": round(host.numel() / h2d_ms / 1e6, 2),
                                         "people": int(pcie_people),
+                                        "slow_mode": bool(B * n / dt1 < 0.75 * value),
+                                        "slow_mode_note": "true = this process ran the PCIe loop in the slow mode seen on some boxes / processes "
+                                                          "(< 0.75 of `value` although h2d_alone_gbps is normal: host submit or GPU-side "
+                                                          "wait 2-3x the usual, profiles/r03/pcie_modes_sdma.txt); `value` is unaffected "
+                                                          "(frames resident in HBM)",
                                         "note": "per step: H2D of the pinned u8 frames into the lane's input buffer, the "
                                                 "step, D2H of the compact result (first 64 people slots per image) into pinned "
                                                 "buffers, all queued on the lane's stream; the host unpacks a batch while the "

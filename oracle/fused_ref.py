@@ -44,7 +44,7 @@ def _bf16(t):
 
 def fused_forward_ref(sd, x: torch.Tensor, arch: str = "drn_d_22", emulate_bf16: bool = False, taps=None,
                       fuse_stem=False, emulate_dtype=None, residual_dtype="same", fuse_shortcut: bool = True,
-                      stem_dtype=None, half_prefix: int = -1, exact_prefix: int = -1):
+                      stem_dtype=None, half_prefix: int = -1, exact_prefix: int = -1, exact_input: bool = False):
     """x f32 [B,3,H,W] (normalised) -> head f32 [B,C,H/16,W/16], walking the fused program.
     emulate_dtype=torch.float16 emulates the PPN_F16 mode's storage roundings the way emulate_bf16 does bf16's.
     residual_dtype (precision study, tests/precision_study.py): storage type of the tensors that are ONLY ever read as a
@@ -53,6 +53,8 @@ def fused_forward_ref(sd, x: torch.Tensor, arch: str = "drn_d_22", emulate_bf16:
     while its outputs are stored in emulate_dtype (the bf16 mode's default since round 4: torch.float16).
     half_prefix: the launches of backbone.0 .. backbone.{half_prefix} compute and store in IEEE half, and a tensor is stored
     in the type of the launches that read it (the bf16 mode's default since round 4: 4 = stem + layer3 + layer4).
+    exact_input: the stem's input patch is not rounded (the u8 path of the fused half stem keeps the integer x - 128 and folds
+    the normalisation into layer 0's weights, csrc/stem012.hip; the f32-input path of model.forward() rounds the patch).
     exact_prefix: the launches of backbone.0 .. backbone.{exact_prefix} are exact (f32 / float16x3 on the GPU: no rounding
     emulated); what they hand to the 16-bit trunk is rounded to its type (PoseProposalNet(exact_prefix=))."""
     ops = A.build_program(arch, fuse_stem=fuse_stem, fuse_shortcut=fuse_shortcut)
@@ -91,7 +93,7 @@ def fused_forward_ref(sd, x: torch.Tensor, arch: str = "drn_d_22", emulate_bf16:
             src = tensors[op.src]
             w = _t(sd[op.weight]).float()
             if op.k == 7:
-                src_q, w_q = q(src), q(w)          # the stem stages a bf16 patch / bf16 weight fragments
+                src_q, w_q = (src if exact_input else q(src)), q(w)   # the stem stages a 16-bit patch / weight fragments
             else:
                 src_q, w_q = src, q(w)             # other inputs are already-stored (rounded) tensors
             acc = F.conv2d(src_q, w_q, None, op.stride, op.pad, op.dilation)

@@ -167,7 +167,7 @@ class MultiLaneInference:
     result hand-over are HIP events.  Results are bit-identical to the serial path."""
 
     def __init__(self, model: PoseProposalNet, batch: int, insize_hw, detection_thresh: float = 0.15, device=None,
-                 lanes: int = 2, tile_policy: int = 0):
+                 lanes: int = 2, tile_policy: int = 0, shared_plan: Optional[bool] = None):
         self.model = model
         dev = device if device is not None else model.device
         h, w = insize_hw[0] // 16, insize_hw[1] // 16
@@ -188,7 +188,10 @@ class MultiLaneInference:
         # vs 10.96 k images/s with three lanes).  The choice travels in THIS pipeline's plans (ppn_conv_desc.flags), so
         # other plans, trainers and pipelines of the process -- and a user's PPN_CONV64 setting -- are untouched;
         # results are bit-identical either way.
-        self._conv_flags = (L.PPN_CONV_NO_FILTER_BANK | L.PPN_CONV_SHARED_GPU) if lanes > 1 else 0
+        # shared_plan=True with ONE lane: the multi-lane plan (same kernels, same tiles) with one launch in flight -- what a
+        # profiler run needs so that its per-kernel durations describe the kernels the multi-lane headline ran
+        shared = lanes > 1 if shared_plan is None else bool(shared_plan)
+        self._conv_flags = (L.PPN_CONV_NO_FILTER_BANK | L.PPN_CONV_SHARED_GPU) if shared else 0
 
     def close(self):
         from . import lib as L

@@ -47,7 +47,7 @@ def emulate(sd, arch, size, u8, exp, mode, frames=None):
         # the shipped policy of the 16-bit modes: the fused stem computes in IEEE half; the bf16 mode also runs layer3-4 in
         # half (model.PoseProposalNet half_prefix=4), everything else in `mode`
         head = fused_ref.fused_forward_ref(sd, x[i:i + 1], arch, fuse_stem="all", emulate_dtype=MODES[mode],
-                                           stem_dtype=torch.float16, half_prefix=4 if mode == "bfloat16" else -1).numpy()
+                                           stem_dtype=torch.float16, exact_input=True, half_prefix=4 if mode == "bfloat16" else -1).numpy()
         d = np.abs(head - ref)
         emax, esum, n_el = max(emax, float(d.max())), esum + float(d.sum(dtype=np.float64)), n_el + d.size
         p = D.decode_ref(head[0], insize=(size, size))

@@ -6,13 +6,13 @@ R=${GRAFT_REPO_ROOT:-/root/repo}; T=${1:-r01}; O="$R/gpurun_out/$T"; rm -rf "$O"
 cd /tmp; export TMPDIR=/tmp
 echo "[1/6] bench (unprofiled, with per-launch table and CPU baseline)"
 python3 $R/bench.py --layers > $O/bench.json 2> $O/bench_layers.txt
-echo "[2/6] rocprofv3 kernel stats of bench.py: one lane (per-dispatch durations comparable with the HIP-event table) and the default two lanes"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras --no-verify --lanes 1 > $O/bench_profiled.json 2> $O/bench_profiled.err
+echo "[2/6] rocprofv3 kernel stats of bench.py: one lane on the multi-lane plan (--shared-plan: per-dispatch durations comparable with the HIP-event table of the headline) and the default lanes"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras --no-verify --lanes 1 --shared-plan > $O/bench_profiled.json 2> $O/bench_profiled.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats2 -o bench2 -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras --no-verify > $O/bench_profiled_2lanes.json 2> $O/bench_profiled_2lanes.err
 echo "[3/6] PMC pass FETCH_SIZE"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras --no-verify --lanes 1 > $O/fetch.json 2> $O/fetch.err
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras --no-verify --lanes 1 --shared-plan > $O/fetch.json 2> $O/fetch.err
 echo "[4/6] PMC pass WRITE_SIZE"
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras --no-verify --lanes 1 > $O/write.json 2> $O/write.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras --no-verify --lanes 1 --shared-plan > $O/write.json 2> $O/write.err
 echo "[5/6] training step (phases + JSON), bench.py --workload train"
 python3 $R/tools/bench_train.py --phases --first-order > $O/train_bench.txt 2>&1
 python3 $R/bench.py --workload train --steps 10 --warmup 2 > $O/bench_train.json 2> $O/bench_train.err
