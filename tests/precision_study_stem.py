@@ -1,9 +1,12 @@
+"""CPU precision study 3 (not a test): WHICH roundings of the 16-bit stem cost people -- its input patch, its weights, or the
+tensors between its layers -- with an f16 tail behind it (emulated on torch-CPU; python tests/precision_study_stem.py).
+Result (profiles/r04/precision_stem_roundings.txt): input and weights; the inner tensors do not matter."""
 import os, sys, numpy as np, torch, torch.nn.functional as F
-sys.path.insert(0, '/root/repo')
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 from oracle import decode_ref as D, forward_ref as Fr, fused_ref
 from pytorch_pose_proposal_network_amd import arch as A, decode, prng, synth
 torch.set_num_threads(8)
-ROOT='/root/repo'
 g = np.load(os.path.join(ROOT, "tests", "golden", "e2e_d22_384.npz"))
 arch, size, batch = str(g["arch"]), int(g["size"]), int(g["batch"])
 st = np.load(os.path.join(ROOT, "pytorch_pose_proposal_network_amd", "data", f"bn_calib_{arch}_seed0.npz"))
