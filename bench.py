@@ -992,6 +992,15 @@ def main():
             if pipe is not None:
                 pipe.close()
             result.update(extra_sections(args, dev, net, frames, dec))
+        # what `value` is worth in the TASK metric, right beside it: the timed mode's people against the reference pipeline's
+        # (8 calibrated frames, the reference's own matcher; `ap_vs_reference` / `bf16_agreement` hold the details)
+        apv, agr = result.get("ap_vs_reference", {}), result.get("bf16_agreement", {})
+        if args.dtype == "bf16" and "bf16" in apv and "reproduced_exactly" in agr:
+            result["value_fidelity"] = {"total_ap": apv["bf16"][-1], "ap_ceiling": apv["self"][-1],
+                                        "reference_people_reproduced_exactly": f"{agr['reproduced_exactly']}/{agr['reference_people']}",
+                                        "same_root": f"{agr['same_root']}/{agr['reference_people']}",
+                                        "task_equivalent": bool(agr["reproduced_exactly"] >= 0.97 * agr["reference_people"]),
+                                        "modes_that_are": "float16x3 (`f16x3_mode`), float32 (`f32_parity_mode`): all people, AP = ceiling"}
         if verified is not None:
             if "bf16_agreement" in result or "reference_agreement" in result:
                 ra = result.get("reference_agreement", result.get("bf16_agreement"))
