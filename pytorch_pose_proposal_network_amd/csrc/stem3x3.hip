@@ -36,7 +36,13 @@ struct Stem3Args {
 
 template <typename T, int COUT, int S>
 struct Geo {
-    static constexpr int TH = S == 1 ? 16 : 8, TW = 64;
+    // f32 tiles are halved (round 4): 8 x 64 x stride-2 f32 output pixels needed a 150 KB patch -- ONE workgroup per CU, single
+    // buffered -- and the stride-1 f32 patch 76 KB (two).  Same arithmetic per pixel: results unchanged.  Measured: 336 ->
+    // 315 us (16 -> 16) and 247 -> 245 us (16 -> 32 stride 2) at batch 32: occupancy was not what holds these kernels at ~40 %
+    // of the f32 MFMA rate (36 dependent ds_read_b32 + v_mfma_f32_16x16x4_f32 pairs per segment); they are the prefix of the
+    // float16x3 and exact-prefix modes (0.84 of 9.0 / 4.1 ms).
+    static constexpr bool F32 = sizeof(T) == 4;
+    static constexpr int TH = S == 1 ? (F32 ? 8 : 16) : 8, TW = (F32 && S == 2) ? 32 : 64;
     static constexpr int PH = TH * S + 2, PW = TW * S + 2;
     static constexpr int LDS_BYTES = PH * PW * CIN * (int)sizeof(T);
 };
@@ -194,10 +200,12 @@ int launch(const Stem3Args& a, hipStream_t st) {
         PPN_LDS_ONCE(max_lds_set, reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       G::LDS_BYTES);
     }
-    const int ntiles = a.tiles_x * a.tiles_y * a.B;
-    const int per_cu = G::LDS_BYTES <= 40 * 1024 ? 4 : (G::LDS_BYTES <= 80 * 1024 ? 2 : 1);
+    Stem3Args b = a;
+    b.tiles_x = (a.Wo + G::TW - 1) / G::TW; b.tiles_y = (a.Ho + G::TH - 1) / G::TH;
+    const int ntiles = b.tiles_x * b.tiles_y * a.B;
+    const int per_cu = G::LDS_BYTES <= 40 * 1024 ? 4 : (G::LDS_BYTES <= 53 * 1024 ? 3 : (G::LDS_BYTES <= 80 * 1024 ? 2 : 1));
     const int grid = ntiles < 256 * per_cu ? ntiles : 256 * per_cu;
-    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(256), G::LDS_BYTES, st, a);
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(256), G::LDS_BYTES, st, b);
     PPN_LAUNCH_CHECK();
     return PPN_OK;
 }
@@ -222,8 +230,7 @@ int stem3x3_launch(int dtype, const void* src, int batch, int h, int w, int cout
     a.out_raw = out_raw; a.out_act = out_act;
     a.B = batch; a.H = h; a.W = w;
     a.Ho = (h + 2 - 3) / stride + 1; a.Wo = (w + 2 - 3) / stride + 1;
-    const int th = stride == 1 ? 16 : 8;
-    a.tiles_x = (a.Wo + 63) / 64; a.tiles_y = (a.Ho + th - 1) / th;
+    a.tiles_x = a.tiles_y = 0;                            // per instantiation: launch<>()
     static char name[64];
     snprintf(name, sizeof(name), "stem3x3_kernel<%s, %d, %d>", dtype == PPN_F32 ? "float" : "__bf16", cout, stride);
     if (kname) *kname = name;
