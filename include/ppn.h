@@ -439,6 +439,24 @@ int ppn_pack_weight(int32_t dtype, const float* w, int32_t cout, int32_t cin, in
 int ppn_pack_weight_dgrad(int32_t dtype, const float* w, int32_t cout, int32_t cin, int32_t ksize, int32_t cout_pad,
                           int32_t k_total, int32_t k_order, int32_t k_step, void* out, void* stream);
 
+/* All weight packs of a training iteration in ONE launch (round 4: a DRN-D-22 step packed its ~86 weight views -- each
+ * layer's forward and input-gradient layout -- with one 8 us launch apiece, every optimiser step; the reference has no
+ * counterpart: cuDNN reads its [cout,cin,k,k] parameters directly, /root/reference/main.py:643-777).
+ * items (host): one entry per ppn_pack_weight / ppn_pack_weight_dgrad call it replaces, same arguments, same result.
+ * ppn_pack_table_build lays the entries out for the device: `table` (host, n * PPN_PACK_ITEM_BYTES bytes) is what the
+ * caller copies ONCE to device memory; total_blocks is the grid of ppn_pack_table_run, which re-packs every entry from
+ * the current values of its w on `stream`.  Pointers are captured: rebuild the table when a w or out moves. */
+typedef struct ppn_pack_item {
+    const float* w;      /* device, reference layout f32 */
+    void* out;           /* device, [cout_pad][k_total] of dtype (f32 for k_order 2) */
+    int32_t dtype, cout, cin, ksize, cout_pad, k_total, k_order, k_step;
+    int32_t transposed;  /* 1: ppn_pack_weight_dgrad's layout */
+    int32_t reserved_;
+} ppn_pack_item;
+#define PPN_PACK_ITEM_BYTES 64
+int ppn_pack_table_build(const ppn_pack_item* items, int32_t n, void* table, int32_t* total_blocks);
+int ppn_pack_table_run(const void* table_dev, int32_t n, int32_t total_blocks, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Training building blocks (main.py:623-777).  Activations are NHWC
  * [pixels][channels] in `dtype`, channels a multiple of 8 and a power of two <= 2048 (every BN of the

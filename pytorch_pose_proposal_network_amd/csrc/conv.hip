@@ -358,30 +358,102 @@ int ilog2_exact(int v) {
 }
 
 // weight packing: [cout,cin,k,k] f32 -> [cout_pad][k_total] T with k = (ky*ks+kx)*cin + ci
+__device__ __forceinline__ float pack_value(const float* __restrict__ w, size_t i, int cout, int cin, int ntaps, int ktot,
+                                            int korder, int kstep, int transposed) {
+    const int co = (int)(i / ktot), k = (int)(i % ktot);
+    if (co >= cout || k >= ntaps * cin) return 0.f;
+    int tap, ci;
+    if (korder == 0) {
+        tap = k / cin; ci = k % cin;
+    } else if (korder == 2) {                              // reference layout [cout][cin][k][k]
+        ci = k / ntaps; tap = k % ntaps;
+    } else {
+        const int blk = k / kstep, within = k % kstep;     // blk = cchunk*ntaps + tap
+        tap = blk % ntaps; ci = (blk / ntaps) * kstep + within;
+    }
+    // transposed: the input-gradient convolution's weight w'[co][ci][tap] = w[ci][co][last - tap] of the
+    // forward weight w [cin][cout][k][k] (channel roles swapped, filter rotated by 180 degrees)
+    return transposed ? w[((size_t)ci * cout + co) * ntaps + (ntaps - 1 - tap)] : w[((size_t)co * cin + ci) * ntaps + tap];
+}
+
 template <typename T>
 __global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ out, int cout, int cin, int ks,
                                    int cout_pad, int ktot, int korder, int kstep, int transposed) {
     const size_t n = (size_t)cout_pad * ktot;
     const int ntaps = ks * ks;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const int co = (int)(i / ktot), k = (int)(i % ktot);
-        float v = 0.f;
-        if (co < cout && k < ntaps * cin) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = (T)pack_value(w, i, cout, cin, ntaps, ktot, korder, kstep, transposed);
+}
+
+// ppn_pack_table_run: every pack of a training iteration in one launch.  A workgroup owns kPackChunk consecutive
+// elements of ONE entry; it finds the entry by bisection over the entries' first workgroup (uniform, scalar loads).
+struct PackItemDev {
+    const float* w;
+    void* out;
+    unsigned long long n;                 // cout_pad * k_total
+    int cout, cin, ntaps, ktot, korder, kstep, transposed, otype;   // otype: 0 f32, 1 bf16, 2 f16
+    int first_block, pad_;
+};
+static_assert(sizeof(PackItemDev) == PPN_PACK_ITEM_BYTES, "ppn.h: PPN_PACK_ITEM_BYTES");
+constexpr int kPackChunk = 2048;
+
+__global__ void __launch_bounds__(256) pack_table_kernel(const PackItemDev* __restrict__ tab, int n_items) {
+    int lo = 0, hi = n_items - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (tab[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const PackItemDev it = tab[lo];
+    const size_t base = (size_t)((int)blockIdx.x - it.first_block) * kPackChunk;
+    // 8 consecutive k of one output row share their tap when the channel index runs fastest over a multiple of 8 (every
+    // MFMA layer: k_order 1 with 64-channel chunks, k_order 0 with cin % 8 == 0): ONE index decomposition (six integer
+    // divisions by run-time values -- the per-element form is instruction-bound at ~0.2 ms for DRN-D-22's 33 M packed
+    // elements) and one 16- / 32-byte store per 8 elements.
+    const bool wide = it.ktot % 8 == 0 && ((it.korder == 1 && it.kstep % 8 == 0) || (it.korder == 0 && it.cin % 8 == 0));
+    if (wide) {
+        const size_t i = base + (size_t)threadIdx.x * 8;
+        if (i >= it.n) return;
+        const int co = (int)(i / it.ktot), k = (int)(i % it.ktot);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = 0.f;
+        if (co < it.cout && k < it.ntaps * it.cin) {
             int tap, ci;
-            if (korder == 0) {
-                tap = k / cin; ci = k % cin;
-            } else if (korder == 2) {                              // reference layout [cout][cin][k][k]
-                ci = k / ntaps; tap = k % ntaps;
+            if (it.korder == 0) {
+                tap = k / it.cin; ci = k % it.cin;
             } else {
-                const int blk = k / kstep, within = k % kstep;     // blk = cchunk*ntaps + tap
-                tap = blk % ntaps; ci = (blk / ntaps) * kstep + within;
+                const int blk = k / it.kstep, within = k % it.kstep;
+                tap = blk % it.ntaps; ci = (blk / it.ntaps) * it.kstep + within;
             }
-            // transposed: the input-gradient convolution's weight w'[co][ci][tap] = w[ci][co][last - tap] of the
-            // forward weight w [cin][cout][k][k] (channel roles swapped, filter rotated by 180 degrees)
-            v = transposed ? w[((size_t)ci * cout + co) * ntaps + (ntaps - 1 - tap)]
-                           : w[((size_t)co * cin + ci) * ntaps + tap];
+            const float* src = it.transposed ? it.w + ((size_t)ci * it.cout + co) * it.ntaps + (it.ntaps - 1 - tap)
+                                             : it.w + ((size_t)co * it.cin + ci) * it.ntaps + tap;
+            const size_t stride = it.transposed ? (size_t)it.cout * it.ntaps : (size_t)it.ntaps;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = src[j * stride];
         }
-        out[i] = (T)v;
+        if (it.otype == 0) {
+            float4* o = reinterpret_cast<float4*>(static_cast<float*>(it.out) + i);
+            o[0] = make_float4(v[0], v[1], v[2], v[3]);
+            o[1] = make_float4(v[4], v[5], v[6], v[7]);
+        } else if (it.otype == 1) {
+            ppnconv::store8<__bf16>(reinterpret_cast<char*>(static_cast<__bf16*>(it.out) + i), v);
+        } else {
+            typedef __attribute__((ext_vector_type(8))) _Float16 h8;
+            h8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (_Float16)v[j];     // as ppn_pack_weight converts (no clamp)
+            *reinterpret_cast<h8*>(static_cast<_Float16*>(it.out) + i) = o;
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < kPackChunk / 256; ++j) {
+        const size_t i = base + j * 256 + threadIdx.x;
+        if (i >= it.n) break;
+        const float v = pack_value(it.w, i, it.cout, it.cin, it.ntaps, it.ktot, it.korder, it.kstep, it.transposed);
+        if (it.otype == 0) static_cast<float*>(it.out)[i] = v;
+        else if (it.otype == 1) static_cast<__bf16*>(it.out)[i] = (__bf16)v;
+        else static_cast<_Float16*>(it.out)[i] = (_Float16)v;
     }
 }
 
@@ -708,4 +780,44 @@ extern "C" int ppn_pack_weight_dgrad(int32_t dtype, const float* w, int32_t cout
                                      int32_t cout_pad, int32_t k_total, int32_t k_order, int32_t k_step, void* out,
                                      void* stream) {
     return pack_weight_impl(dtype, w, cout, cin, ksize, cout_pad, k_total, k_order, k_step, out, stream, 1);
+}
+
+extern "C" int ppn_pack_table_build(const ppn_pack_item* items, int32_t n, void* table, int32_t* total_blocks) {
+    if (!items || !table || !total_blocks || n < 1) return ppn::fail(PPN_E_INVALID, "ppn_pack_table_build: bad arguments");
+    PackItemDev* t = static_cast<PackItemDev*>(table);
+    long long blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        const ppn_pack_item& s = items[i];
+        if (!s.w || !s.out || s.cout < 1 || s.cin < 1 || s.ksize < 1 || s.cout_pad < s.cout ||
+            s.k_total < s.ksize * s.ksize * s.cin)
+            return ppn::fail(PPN_E_INVALID, "ppn_pack_table_build: entry %d: bad arguments", i);
+        if (s.k_order == 2) {
+            if (s.cout_pad != s.cout || s.k_total != s.cin * s.ksize * s.ksize)
+                return ppn::fail(PPN_E_INVALID, "ppn_pack_table_build: entry %d: k_order 2 is unpadded", i);
+        } else if (s.k_order != 0 && (s.k_order != 1 || s.k_step < 1 || s.cin % s.k_step != 0)) {
+            return ppn::fail(PPN_E_INVALID, "ppn_pack_table_build: entry %d: k_order %d needs cin %% k_step == 0", i, s.k_order);
+        }
+        if (s.dtype != PPN_F32 && s.dtype != PPN_BF16 && s.dtype != PPN_F16)
+            return ppn::fail(PPN_E_INVALID, "ppn_pack_table_build: entry %d: bad dtype %d", i, s.dtype);
+        PackItemDev d;
+        d.w = s.w; d.out = s.out;
+        d.n = (unsigned long long)s.cout_pad * (unsigned long long)s.k_total;
+        d.cout = s.cout; d.cin = s.cin; d.ntaps = s.ksize * s.ksize; d.ktot = s.k_total; d.korder = s.k_order;
+        d.kstep = s.k_step > 0 ? s.k_step : 1; d.transposed = s.transposed ? 1 : 0;
+        d.otype = (s.k_order == 2 || s.dtype == PPN_F32) ? 0 : (s.dtype == PPN_BF16 ? 1 : 2);   // k_order 2 stays f32
+        d.first_block = (int)blocks; d.pad_ = 0;
+        blocks += (long long)((d.n + kPackChunk - 1) / kPackChunk);
+        if (blocks > 0x7fffffffLL) return ppn::fail(PPN_E_UNSUPPORTED, "ppn_pack_table_build: too many elements");
+        t[i] = d;
+    }
+    *total_blocks = (int32_t)blocks;
+    return PPN_OK;
+}
+
+extern "C" int ppn_pack_table_run(const void* table_dev, int32_t n, int32_t total_blocks, void* stream) {
+    if (!table_dev || n < 1 || total_blocks < 1) return ppn::fail(PPN_E_INVALID, "ppn_pack_table_run: bad arguments");
+    hipLaunchKernelGGL(pack_table_kernel, dim3(total_blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const PackItemDev*>(table_dev), n);
+    PPN_LAUNCH_CHECK();
+    return PPN_OK;
 }

@@ -25,6 +25,15 @@
 // (v_mfma_f32_16x16x32_bf16: 7 + 5 + 2x5 per 16 pixels); intermediate activations are rounded to bf16 exactly where
 // the layer-by-layer kernels (stem.hip, stem3x3.hip) round them, and the MFMA sequences are the same, so the results
 // are bit-identical to theirs (tests/test_conv_gpu.py::test_fused_stem_equals_layer_by_layer).
+// Round 4 (tools/bench_stem.py, batch 32): 176 -> 159 us.  (1) the weights reach the lanes through LDS (the guarded per-lane
+// global loads of the 7x7 fragments were 66 serialised L2 round trips at the head of every workgroup: -11 us); (2) layer 0 /
+// layer 1 read the operands of segment s+1 under the MFMA chain of segment s (-6 us); layer 2's 32 BN constants wait in LDS.
+// Measured and dropped: converting the exact input without the table, all reads of a thread's five rows issued together
+// (unaligned ds_read_u16 + integer conversion): +15 us.  Phase by phase (timing-only builds, -DPPN_S012_SKIP): convert 25,
+// layer 0 47, layer 1 43, layer 2 31, input requests 21 us -- additive, no unit saturated (SQ counters of the 159 us
+// kernel: MFMA pipe 25 %, VALU issue 39 %, LDS 45 % of which a fifth bank conflicts, 36 % of the wave cycles in s_waitcnt):
+// with two waves per SIMD (223 VGPRs: the three weight sets) the kernel is latency-bound; the step change needs
+// wave-specialised producers / consumers under 128 VGPRs each.
 #include <hip/hip_bf16.h>
 
 #include <cstdlib>
@@ -37,6 +46,7 @@
 #ifndef PPN_S012_SKIP
 #define PPN_S012_SKIP 0
 #endif
+
 
 namespace {
 
@@ -63,7 +73,8 @@ constexpr int WI = W1 + 8;              // input columns held:   xi = 2*C2 - 5 +
 constexpr int R0 = 6, R1 = 5, RI = 10;  // ring / patch rows
 constexpr int RAWS = 368;               // raw u8 row: 120 px x 3 B = 360 B (+ alignment slack), a multiple of 16
 constexpr int LDS_IN = RI * WI * 8, LDS_L0 = R0 * W0 * 32, LDS_L1 = R1 * W1 * 32, LDS_RAW = RI * RAWS, LDS_LUT = 3 * 256 * 2;
-constexpr int LDS_BYTES = LDS_IN + LDS_L0 + LDS_L1 + LDS_RAW + LDS_LUT;
+constexpr int LDS_CST = 4 * 32 * 4;      // layer-2 epilogue constants [scale2 | shift2 | scale3 | shift3][32] f32
+constexpr int LDS_BYTES = LDS_IN + LDS_L0 + LDS_L1 + LDS_RAW + LDS_LUT + LDS_CST;
 
 struct Stem012Args {
     const void* src;                    // u8 [B,H,W,3] or f32 [B,3,H,W]
@@ -155,51 +166,82 @@ __global__ void __launch_bounds__(256, 2) stem012_kernel(Stem012Args a) {
     hx8 wa1[5];           // k-step kk: k = 8g+i -> tap 2kk + (g>>1), ci = (g&1)*8 + i
     hx8 wa2[2][5];
     {
-        const float* wc = a.w0 + (size_t)ch * 3 * 49;
+        // The three weight sets go through LDS once per workgroup: coalesced dword loads by all 256 threads (36 each, one
+        // wait), then every lane picks its fragment elements with UNCONDITIONAL LDS reads (clamped index, value masked
+        // afterwards).  Reading them per lane from global memory with guarded loads compiled to one branch +
+        // global_load + s_waitcnt vmcnt(0) each -- 66 serialised L2 round trips at the head of every workgroup.
+        float* wl = reinterpret_cast<float*>(smem);      // [16*147 | 16*144 | 32*144] f32 over the not-yet-used patch + rings
+        constexpr int N0 = 16 * 147, N1 = 16 * 144, N2 = 32 * 144;
+        static_assert((N0 + N1 + N2) * 4 <= LDS_IN + LDS_L0 + LDS_L1, "weight staging must fit below the raw rows / LUT");
+        for (int i = tid; i < N0; i += 256) wl[i] = a.w0[i];
+        for (int i = tid; i < N1; i += 256) wl[N0 + i] = a.w1[i];
+        for (int i = tid; i < N2; i += 256) wl[N0 + N1 + i] = a.w2[i];
+        __syncthreads();
+        const float* wc = wl + ch * 3 * 49;
 #pragma unroll
         for (int dy = 0; dy < 7; ++dy)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int dx = 2 * g + (i >> 2), c = i & 3;
+            for (int hf = 0; hf < 2; ++hf) {
+                const int dx = 2 * g + hf;
+                const bool ok = dx < 7;
+                const int dxc = ok ? dx : 6;
+                float w3[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) w3[c] = wc[(c * 7 + dy) * 7 + dxc];
                 if constexpr (kExactIn) {
                     float v = 0.f;
-                    if (dx < 7 && c < 3) v = wc[(c * 7 + dy) * 7 + dx] / a.stdv[c];
-                    if (dx < 7 && c == 3)
-                        for (int cc = 0; cc < 3; ++cc) v += wc[(cc * 7 + dy) * 7 + dx] * ((128.f - a.mean[cc]) / a.stdv[cc]);
-                    wa0[dy][i] = (H)v;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        wa0[dy][4 * hf + c] = (H)(ok ? w3[c] / a.stdv[c] : 0.f);
+                        v += w3[c] * ((128.f - a.mean[c]) / a.stdv[c]);
+                    }
+                    wa0[dy][4 * hf + 3] = (H)(ok ? v : 0.f);
                 } else {
-                    wa0[dy][i] = (H)((dx < 7 && c < 3) ? wc[(c * 7 + dy) * 7 + dx] : 0.f);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) wa0[dy][4 * hf + c] = (H)(ok ? w3[c] : 0.f);
+                    wa0[dy][4 * hf + 3] = (H)0.f;
                 }
             }
-        const float* wd = a.w1 + (size_t)ch * 16 * 9;
+        const float* wd = wl + N0 + ch * 16 * 9;
 #pragma unroll
         for (int kk = 0; kk < 5; ++kk) {
-            const int tap = 2 * kk + (g >> 1);
+            const int tap = 2 * kk + (g >> 1), tapc = tap < 9 ? tap : 8;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) wa1[kk][i] = (H)(tap < 9 ? wd[((g & 1) * 8 + i) * 9 + tap] : 0.f);
+            for (int i = 0; i < 8; ++i) {
+                const float v = wd[((g & 1) * 8 + i) * 9 + tapc];
+                wa1[kk][i] = (H)(tap < 9 ? v : 0.f);
+            }
         }
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
-            const float* we = a.w2 + (size_t)(ct * 16 + ch) * 16 * 9;
+            const float* we = wl + N0 + N1 + (ct * 16 + ch) * 16 * 9;
 #pragma unroll
             for (int kk = 0; kk < 5; ++kk) {
-                const int tap = 2 * kk + (g >> 1);
+                const int tap = 2 * kk + (g >> 1), tapc = tap < 9 ? tap : 8;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) wa2[ct][kk][i] = (H)(tap < 9 ? we[((g & 1) * 8 + i) * 9 + tap] : 0.f);
+                for (int i = 0; i < 8; ++i) {
+                    const float v = we[((g & 1) * 8 + i) * 9 + tapc];
+                    wa2[ct][kk][i] = (H)(tap < 9 ? v : 0.f);
+                }
             }
         }
     }
-    float sc0[4], sh0[4], sc1[4], sh1[4], sc2[2][4], sh2[2][4], sc3[2][4], sh3[2][4];
+    // layer 0 / 1 constants in registers; layer 2's (used once per 16 output pixels, 32 registers) wait in LDS
+    float sc0[4], sh0[4], sc1[4], sh1[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         sc0[r] = a.s0[4 * g + r]; sh0[r] = a.b0[4 * g + r];
         sc1[r] = a.s1[4 * g + r]; sh1[r] = a.b1[4 * g + r];
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
-            const int c = ct * 16 + 4 * g + r;
-            sc2[ct][r] = a.s2[c]; sh2[ct][r] = a.b2[c];
-            sc3[ct][r] = a.s3 ? a.s3[c] : 1.f; sh3[ct][r] = a.b3 ? a.b3[c] : 0.f;
-        }
+    }
+    float* cst_p = reinterpret_cast<float*>(smem + LDS_IN + LDS_L0 + LDS_L1 + LDS_RAW + LDS_LUT);
+    if (tid < 128) {
+        const int c = tid & 31, which = tid >> 5;
+        float v;
+        if (which == 0) v = a.s2[c];
+        else if (which == 1) v = a.b2[c];
+        else if (which == 2) v = a.s3 ? a.s3[c] : 1.f;
+        else v = a.b3 ? a.b3[c] : 0.f;
+        cst_p[tid] = v;
     }
     if constexpr (U8) {
         // normalisation table: image.float().sub_(mean).div_(std) (rt_test.py:99-101) of every u8 value, rounded to
@@ -299,20 +341,31 @@ __global__ void __launch_bounds__(256, 2) stem012_kernel(Stem012Args a) {
             const bool rowok = gy >= 0 && gy < a.H;
             const unsigned rd = smem_base + (unsigned)((wave * WI + col + 2 * g) * 8);            // patch (row, col + 2g)
             char* wr = l0_p + ((size_t)(((gy + 2 * R0) % R0) * 4 + g) * W0 + col) * 8;
-            sfor<NS>([&](auto sgc) {
-                constexpr int sg = decltype(sgc)::value;
-                u32x2 lo[7], hi[7];
+            // software pipeline: the 14 reads of segment sg + 1 are in flight under the MFMA chain of segment sg (LDS ops
+            // complete in order, so "at most 14 outstanding" = segment sg's operands and the previous ds_write are done)
+            u32x2 lo[2][7], hi[2][7];
+            auto fetch = [&](auto sgc, auto setc) {
+                constexpr int sg = decltype(sgc)::value, st = decltype(setc)::value;
                 sfor<7>([&](auto dyc) {                  // immediate offsets: no address arithmetic per read
                     constexpr int dy = decltype(dyc)::value;
-                    lo[dy] = lds_read64<dy * WI * 8 + sg * 128>(rd);
-                    hi[dy] = lds_read64<dy * WI * 8 + sg * 128 + 8>(rd);
+                    lo[st][dy] = lds_read64<dy * WI * 8 + sg * 128>(rd);
+                    hi[st][dy] = lds_read64<dy * WI * 8 + sg * 128 + 8>(rd);
                 });
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            };
+            fetch(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+            sfor<NS>([&](auto sgc) {
+                constexpr int sg = decltype(sgc)::value, cur = sg & 1;
+                if constexpr (sg + 1 < NS) {
+                    fetch(std::integral_constant<int, sg + 1>{}, std::integral_constant<int, cur ^ 1>{});
+                    asm volatile("s_waitcnt lgkmcnt(14)" ::: "memory");
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int dy = 0; dy < 7; ++dy) {
-                    const u32x4 xb = {lo[dy].x, lo[dy].y, hi[dy].x, hi[dy].y};
+                    const u32x4 xb = {lo[cur][dy].x, lo[cur][dy].y, hi[cur][dy].x, hi[cur][dy].y};
                     acc = mfma16(wa0[dy], __builtin_bit_cast(hx8, xb), acc, 0, 0, 0);
                 }
                 const int gx = x0b + sg * 16 + col;
@@ -335,20 +388,29 @@ __global__ void __launch_bounds__(256, 2) stem012_kernel(Stem012Args a) {
                 rd[kk] = smem_base + (unsigned)(LDS_IN + ((s * 4 + 2 * (g & 1)) * W0 + col + tdx[kk]) * 8);
             }
             char* wr = l1_p + ((size_t)(((gy + 2 * R1) % R1) * 4 + g) * W1 + col) * 8;
-            sfor<NS>([&](auto sgc) {
-                constexpr int sg = decltype(sgc)::value;
-                u32x2 lo[5], hi[5];
+            u32x2 lo[2][5], hi[2][5];
+            auto fetch = [&](auto sgc, auto setc) {
+                constexpr int sg = decltype(sgc)::value, st = decltype(setc)::value;
 #pragma unroll
                 for (int kk = 0; kk < 5; ++kk) {
-                    lo[kk] = lds_read64<sg * 128>(rd[kk]);
-                    hi[kk] = lds_read64<sg * 128 + W0 * 8>(rd[kk]);
+                    lo[st][kk] = lds_read64<sg * 128>(rd[kk]);
+                    hi[st][kk] = lds_read64<sg * 128 + W0 * 8>(rd[kk]);
                 }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            };
+            fetch(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+            sfor<NS>([&](auto sgc) {
+                constexpr int sg = decltype(sgc)::value, cur = sg & 1;
+                if constexpr (sg + 1 < NS) {
+                    fetch(std::integral_constant<int, sg + 1>{}, std::integral_constant<int, cur ^ 1>{});
+                    asm volatile("s_waitcnt lgkmcnt(10)" ::: "memory");
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int kk = 0; kk < 5; ++kk) {
-                    const u32x4 xb = {lo[kk].x, lo[kk].y, hi[kk].x, hi[kk].y};
+                    const u32x4 xb = {lo[cur][kk].x, lo[cur][kk].y, hi[cur][kk].x, hi[cur][kk].y};
                     acc = mfma16(wa1[kk], __builtin_bit_cast(hx8, xb), acc, 0, 0, 0);
                 }
                 const int gx = x1b + sg * 16 + col;
@@ -394,12 +456,16 @@ __global__ void __launch_bounds__(256, 2) stem012_kernel(Stem012Args a) {
                     const size_t pix = ((size_t)b * a.Ho + oy) * a.Wo + ox;
 #pragma unroll
                     for (int ct = 0; ct < 2; ++ct) {
+                        const f32x4 sc2 = *reinterpret_cast<const f32x4*>(cst_p + ct * 16 + 4 * g);
+                        const f32x4 sh2 = *reinterpret_cast<const f32x4*>(cst_p + 32 + ct * 16 + 4 * g);
+                        const f32x4 sc3 = *reinterpret_cast<const f32x4*>(cst_p + 64 + ct * 16 + 4 * g);
+                        const f32x4 sh3 = *reinterpret_cast<const f32x4*>(cst_p + 96 + ct * 16 + 4 * g);
                         hox4 ov, ou;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const float t = acc[ct][r] * sc2[ct][r] + sh2[ct][r];
+                            const float t = acc[ct][r] * sc2[r] + sh2[r];
                             const float v = t > 0.f ? t : 0.f;               // BN + ReLU (drn.py:198-200)
-                            const float w2 = v * sc3[ct][r] + sh3[ct][r];
+                            const float w2 = v * sc3[r] + sh3[r];
                             ov[r] = to_store<HO>(v);
                             ou[r] = to_store<HO>(w2 > 0.f ? w2 : 0.f);          // next block's relu(bn1(x)) (drn.py:45-46)
                         }

@@ -508,7 +508,8 @@ int geometry(const ppn_wgrad_desc* d, Geom* g) {
     if (!d) return ppn::fail(PPN_E_INVALID, "ppn_conv_wgrad: NULL descriptor");
     if (d->dtype != PPN_F32 && d->dtype != PPN_BF16) return ppn::fail(PPN_E_INVALID, "bad dtype %d", d->dtype);
     const int epc = d->dtype == PPN_F32 ? 4 : 8;
-    if (d->batch <= 0 || d->cin <= 0 || d->cout <= 0 || d->cin % epc || d->cout % epc)
+    // (the dedicated stem kernels bring their own shapes: layer 0 on a 4-channel input)
+    if (d->batch <= 0 || d->cin <= 0 || d->cout <= 0 || ((d->cin % epc || d->cout % epc) && !ppn::stem_wgrad_supported(d)))
         return ppn::fail(PPN_E_UNSUPPORTED, "ppn_conv_wgrad: cin (%d) and cout (%d) must be multiples of %d", d->cin,
                          d->cout, epc);
     if (d->ksize < 1 || d->ksize > 7 || d->stride < 1 || d->dilation < 1 || d->pad < 0)

@@ -42,6 +42,15 @@ class ConvDesc(C.Structure):
     ]
 
 
+class PackItem(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("out", C.c_void_p)] + [
+        (n, C.c_int32) for n in ("dtype", "cout", "cin", "ksize", "cout_pad", "k_total", "k_order", "k_step",
+                                 "transposed", "reserved_")]
+
+
+PPN_PACK_ITEM_BYTES = 64
+
+
 class LossCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("K", "E", "sH", "sW", "H", "W", "inH", "inW")]
 
@@ -134,6 +143,8 @@ _SIGNATURES = {
                                   C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "ppn_pack_weight_dgrad": (C.c_int, [C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                   C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "ppn_pack_table_build": (C.c_int, [C.POINTER(PackItem), C.c_int32, C.c_void_p, C.POINTER(C.c_int32)]),
+    "ppn_pack_table_run": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
 }
 
 _SIGNATURES.update({

@@ -13,6 +13,7 @@ Activations are NHWC `[N, H, W, C]` (or any `[..., C]` contiguous tensor) in f32
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional
 
 import torch
@@ -300,7 +301,10 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, stride: int = 1, dilation: int
         pack = lib.ppn_pack_weight_dgrad if dgrad_of else lib.ppn_pack_weight
         L.check(pack(dt, w.data_ptr(), cout, cin, k, cpad, ktot, korder, kstep, buf.data_ptr(), st), "ppn_pack_weight")
         if key is not None:
-            _pack_cache[key] = (_param_version[0], buf, sp)
+            if packed is None:
+                _pack_tables.clear()                # a new entry: repack_all() rebuilds its table
+            _pack_cache[key] = (_param_version[0], buf, sp,
+                                (w.data_ptr(), buf.data_ptr(), dt, cout, cin, k, cpad, ktot, korder, kstep, 1 if dgrad_of else 0, 0))
         packed = (_param_version[0], buf)
     packed = packed[1]
     if nchw_f32:                                  # the head tensor the loss / decode kernels read (model.py:134-136)
@@ -349,11 +353,51 @@ def unregister_param_storage(sp):
     _param_storages.pop(sp, None)
     for key in [k for k, v in _pack_cache.items() if v[2] == sp]:
         del _pack_cache[key]
+    _pack_tables.clear()
 
 
 def bump_param_version():
     """Parameters changed (optimiser step, load_state_dict): packed weights of older versions are stale."""
     _param_version[0] += 1
+
+
+_pack_tables: dict = {}             # device -> (device table, entries, grid, keys): rebuilt when the cache gains a key
+_BATCHED_PACK = os.environ.get("PPN_TRAIN_BATCHED_PACK", "1") != "0"
+
+
+def repack_all(device) -> int:
+    """Refresh EVERY cached packed weight on `device` from the current parameter values with one launch on the current
+    stream (ppn_pack_table_run) and stamp them with the current parameter version; returns the number of entries.
+    conv2d_nhwc packs a weight view the first time it meets it and on every parameter version after that -- ~86 launches
+    of ~8 us per DRN-D-22 iteration (each layer's forward and input-gradient layout); called at the head of a pass (after
+    bump_param_version, when every consumer of the previous copies has finished: the trainer joins its side streams
+    before the optimiser step) the same work is one ~50 us launch.  Entries packed for another stream are refreshed too:
+    their consumers wait for an event of this stream before they run (PPNTrainer._on_side, the probe stream)."""
+    if not _BATCHED_PACK:
+        return 0
+    device = torch.device(device)
+    if device.index is None:
+        device = torch.device(device.type, torch.cuda.current_device())
+    keys = [k for k, v in _pack_cache.items() if v[1].device == device]
+    if not keys:
+        return 0
+    lib = L.load()
+    tab = _pack_tables.get(device)
+    if tab is None or tab[3] != keys:
+        items = (L.PackItem * len(keys))()
+        for it, k in zip(items, keys):
+            (it.w, it.out, it.dtype, it.cout, it.cin, it.ksize, it.cout_pad, it.k_total, it.k_order, it.k_step,
+             it.transposed, it.reserved_) = _pack_cache[k][3]
+        host = torch.empty(len(keys) * L.PPN_PACK_ITEM_BYTES, dtype=torch.uint8)
+        grid = C.c_int32(0)
+        L.check(lib.ppn_pack_table_build(items, len(keys), host.data_ptr(), C.byref(grid)), "ppn_pack_table_build")
+        tab = _pack_tables[device] = (host.to(device), len(keys), grid.value, keys)
+    L.check(lib.ppn_pack_table_run(tab[0].data_ptr(), tab[1], tab[2], L.current_stream_ptr()), "ppn_pack_table_run")
+    ver = _param_version[0]
+    for k in keys:
+        v = _pack_cache[k]
+        _pack_cache[k] = (ver,) + v[1:]
+    return len(keys)
 
 
 

@@ -96,6 +96,9 @@ class PPNTrainer:
         # for the four probe passes, which take 0.5 ms each beside the head backward and 0.23 ms alone: no measurable
         # change, 1.48 vs 1.52 ms from the end of the loss to the fourth probe; tools/host_timeline.py.)
         self._stacked_probes = os.environ.get("PPN_TRAIN_STACKED_PROBES", "1") != "0"
+        # second-order tail: enqueue its forward-mode half before the host reads the probe norms (A/B: =0)
+        self._speculate_tail = os.environ.get("PPN_TRAIN_SPECULATE_TAIL", "1") != "0"
+        self._so_pin = None
         self._tail_wgrad_side = os.environ.get("PPN_TRAIN_TAIL_WGRAD_SIDE", "1") != "0"
         pri = int(os.environ.get("PPN_TRAIN_PROBE_PRIORITY", "0"))
         self._probe_stream = torch.cuda.Stream(device=self.device, priority=pri) if self._side is not None else None
@@ -267,9 +270,11 @@ class PPNTrainer:
         x = x.contiguous()
         B, _, H, W = x.shape
         T.bump_param_version()        # parameters may have been edited in place since the last pass: repack once per forward
+        T.repack_all(self.device)     # ... every weight view the previous passes met, in one launch
         tape = []
-        # the 7x7 stem reads NCHW f32; its weight gradient reads an 8-channel NHWC copy (channels 3..7 zero)
-        xin8 = torch.zeros(B, H, W, 8, dtype=self.tdt, device=self.device)
+        # the 7x7 stem reads NCHW f32; its weight gradient reads an NHWC copy padded with zero channels: 4 channels for
+        # the dedicated bf16 kernel (csrc/stem_wgrad.hip: two MFMAs per filter row), 8 for the generic f32 kernel
+        xin8 = torch.zeros(B, H, W, 4 if self.tdt == torch.bfloat16 else 8, dtype=self.tdt, device=self.device)
         xin8[..., :3] = x.permute(0, 2, 3, 1)
         cur = None
         for u in self.units:
@@ -426,11 +431,29 @@ class PPNTrainer:
         # C_i / signs: ONE kernel pass over the five weight-sized tensors and ONE host read-back (the 5 x 9.4 MB tensors
         # went through ~45 tiny torch launches and three read-backs, each draining the queue: 0.8 ms of an idle GPU per
         # iteration, tools/train_timeline.py).
+        # Round 4: that read-back no longer idles the GPU either.  The forward-mode half of the tail (tangents through
+        # bn0_2 .. conv3) is linear in the unit directions v_i = g_i / ||g_i|| and needs none of the host values (kappa
+        # and the list of active streams only enter at the loss), so it is ENQUEUED FIRST, for all five streams, with
+        # v_i divided on the device; the host then waits for the 17 floats (pinned, asynchronous copy) while the GPU
+        # works through ~1.5 ms of tangent convolutions, and enqueues the reverse half behind them.  If the host values
+        # say otherwise (a stream inactive, the limb remainder untrusted: rare), the speculative tensors are dropped and
+        # the tangents are rebuilt for the streams that are active -- the results are those of the non-speculative order.
         total = self.G["conv1.weight"]
         trusted = coeff[4] > 1e-3 * max(coeff)
+        spec = None
         if trusted:
             gw4, st = T.probe_stats(gw, total.contiguous(), coeff)
-            host = torch.cat([st, so["losses"].reshape(5), self.base.reshape(5)]).tolist()
+            dev_vec = torch.cat([st, so["losses"].reshape(5), self.base.reshape(5)])
+            if self._so_pin is None:
+                self._so_pin = torch.empty(17, dtype=torch.float32, pin_memory=True)
+            self._so_pin.copy_(dev_vec, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(main)
+            if self._speculate_tail:
+                gn_dev = torch.sqrt(st[:5])
+                spec = self._tail_tangents(c, [(g / gn_dev[i]) for i, g in enumerate(gw + [gw4])], list(range(5)))
+            ev.synchronize()
+            host = self._so_pin.tolist()
             if self.compute_dtype != L.PPN_F32:
                 # bf16: `total` and the unary probes come from differently rounded passes (relative noise ~2^-8 each);
                 # a remainder that is not clearly above that noise cannot be trusted (see _limb_probe)
@@ -439,6 +462,7 @@ class PPNTrainer:
             ss = host[:5]
             gw.append(gw4)
         else:
+            spec = None
             _, g4 = self.criterion.forward_backward(head, targets, coeff=[0.0, 0.0, 0.0, 0.0, 1.0])
             gw.append(self.probe_grad(g4))
             host = torch.cat([torch.cat([T.sumsq(g.contiguous().view(-1)) for g in gw]), so["losses"].reshape(5),
@@ -463,7 +487,9 @@ class PPNTrainer:
         if not act:
             return None, None
         n = len(act)
-        vs = [(gw[i] / gn_h[i]).contiguous() for i in act]                       # unit directions on W
+        if spec is None or act != [0, 1, 2, 3, 4]:
+            spec = self._tail_tangents(c, [(gw[i] / gn_h[i]).contiguous() for i in act], act)
+        vs, u2, TH2, TA3, TC2, TH3, tz_groups = spec
 
         def chunks(t):                                                            # [n*B, ...] -> n views [B, ...]
             return [t[j * B:(j + 1) * B] for j in range(n)]
@@ -471,30 +497,12 @@ class PPNTrainer:
         def ssum(t):                                                              # sum over the stacked streams
             return t if n == 1 else t.view(n, B, *t.shape[1:]).sum(0)
 
-        # ---- forward-mode tangents through the tail.  Every stream is linear in its tangent, so the streams are
-        # stacked along the batch dimension for the convolutions (one launch for all of them); the BN tangents need
-        # per-stream batch statistics and run stream by stream.
-        u2 = [T.conv2d_nhwc(c["h1"], v, 1, 1, 1) for v in vs]
-        TH2 = torch.empty(n * B, *c["a2"].shape[1:], dtype=self.tdt, device=self.device)
-        for u, dst in zip(u2, chunks(TH2)):
-            T.bn_tangent(c["a2"], u, P["bn0_2.weight"], P["bn0_2.bias"], c["s2"], "lrelu", out=dst)
-        TA3 = T.conv2d_nhwc(TH2, P["conv1x1_2.weight"])
-        TC2 = T.conv2d_nhwc(TA3, P["conv2.weight"], 1, 1, 1)
-        TH3 = torch.empty_like(TC2)
-        for t, dst in zip(chunks(TC2), chunks(TH3)):
-            T.bn_tangent(c["c2"], t, P["bn2.weight"], P["bn2.bias"], c["s3"], "lrelu", out=dst)
         # ---- head space per stream: gradient and Hessian-vector product of loss i through the sigmoid.  The unary
         # losses only touch the first 6K channels: their streams share 128-channel conv3 launches.
         H3bar = torch.empty_like(TH3)
         TH3bar = torch.empty_like(TH3)
-        groups = [([j for j, i in enumerate(act) if i < 4], k6), ([j for j, i in enumerate(act) if i == 4], Ch)]
-        for js, used in groups:
-            if not js:
-                continue
+        for js, used, w3u, th3, t_z in tz_groups:                                 # t_z: logit tangents [m*B, used, H, W]
             m = len(js)
-            w3u = P["conv3.weight"] if used == Ch else P["conv3.weight"][:used].contiguous()
-            th3 = TH3[js[0] * B:(js[-1] + 1) * B]                                 # the group's streams are adjacent
-            t_z = T.conv2d_nhwc(th3, w3u, nchw_f32=True)                          # logit tangents [m*B, used, H, W]
             if used == Ch and self.tdt in (torch.float32, torch.bfloat16):
                 # the limb stream (one stream, the whole head): dual seeds, relayout and the pixel sums of zbar in
                 # one pass -- no f32 head-layout zbar / tzbar (2 x 541 MB written and re-read at batch 32)
@@ -560,6 +568,37 @@ class PPNTrainer:
         h1_bar = h1_bar + T.conv_dgrad(a2sum, P["conv1.weight"], (Ho, Wo), 1, 1, 1)
         r_bar = a3sum
         return h1_bar, r_bar
+
+    def _tail_tangents(self, c, vs, act):
+        """Forward-mode half of the second-order tail for the streams `act` with unit directions `vs` on W = conv1.weight:
+        tangents through bn0_2 -> conv1x1_2 -> conv2 -> bn2 -> conv3.  Every stream is linear in its tangent, so the
+        streams are stacked along the batch dimension for the convolutions (one launch for all of them); the BN tangents
+        need per-stream batch statistics and run stream by stream.  The unary losses only touch the first 6K head
+        channels: their streams share 128-channel conv3 launches.  Needs no host value (see _second_order_tail)."""
+        P = self.P
+        n = len(act)
+        B = c["h1"].shape[0]
+        Ch = c["head"].shape[1]
+        k6 = 6 * cfg.K
+        vs = [v.contiguous() for v in vs]
+        u2 = [T.conv2d_nhwc(c["h1"], v, 1, 1, 1) for v in vs]
+        TH2 = torch.empty(n * B, *c["a2"].shape[1:], dtype=self.tdt, device=self.device)
+        for j, u in enumerate(u2):
+            T.bn_tangent(c["a2"], u, P["bn0_2.weight"], P["bn0_2.bias"], c["s2"], "lrelu", out=TH2[j * B:(j + 1) * B])
+        TA3 = T.conv2d_nhwc(TH2, P["conv1x1_2.weight"])
+        TC2 = T.conv2d_nhwc(TA3, P["conv2.weight"], 1, 1, 1)
+        TH3 = torch.empty_like(TC2)
+        for j in range(n):
+            T.bn_tangent(c["c2"], TC2[j * B:(j + 1) * B], P["bn2.weight"], P["bn2.bias"], c["s3"], "lrelu",
+                         out=TH3[j * B:(j + 1) * B])
+        tz_groups = []
+        for js, used in (([j for j, i in enumerate(act) if i < 4], k6), ([j for j, i in enumerate(act) if i == 4], Ch)):
+            if not js:
+                continue
+            w3u = P["conv3.weight"] if used == Ch else P["conv3.weight"][:used].contiguous()
+            th3 = TH3[js[0] * B:(js[-1] + 1) * B]                                 # the group's streams are adjacent
+            tz_groups.append((js, used, w3u, th3, T.conv2d_nhwc(th3, w3u, nchw_f32=True)))
+        return vs, u2, TH2, TA3, TC2, TH3, tz_groups
 
     def _unit_offset(self, kind, u) -> int:
         """First element of the flat buffer that belongs to this unit (its parameters are contiguous)."""
@@ -633,7 +672,7 @@ class PPNTrainer:
                 dy = self._bn_bwd(c["y"], g, bnp, "relu", c["saved"])
                 if u.k == 7:
                     def wg0(x8=c["x"], dy=dy, wn=wn):
-                        dw8 = T.conv_wgrad(x8, dy, 7, 1, 1, 3)            # [16, 8, 7, 7]; input channels 3..7 are zero
+                        dw8 = T.conv_wgrad(x8, dy, 7, 1, 1, 3)            # [16, 4 | 8, 7, 7]; input channels 3.. are zero
                         self.G[wn].copy_(dw8[:, :3])
                     self._on_side(wg0, c["x"], dy)
                     g = None                                               # the input needs no gradient

@@ -601,3 +601,34 @@ def test_train_step_bitwise_reproducible_at_full_size():
     assert torch.isfinite(h0).all() and torch.isfinite(p0).all()
     assert torch.equal(h0, h1) and torch.equal(p0, p1)
     assert float(h0[-1, 4]) < float(h0[0, 4])                      # and it trains: the limb loss falls
+
+
+def test_batched_weight_pack_leaves_the_step_bitwise_unchanged(monkeypatch):
+    """train.repack_all (one ppn_pack_table_run launch at the head of every pass, round 4) against the per-view packs
+    of conv2d_nhwc (PPN_TRAIN_BATCHED_PACK=0): four steps at 192 x 192, every loss, task weight and parameter bitwise
+    equal -- also after an in-place edit of a parameter between two steps (the next pass must see it)."""
+    from pytorch_pose_proposal_network_amd import lib as L, synth, prng, targets, train as T
+    from pytorch_pose_proposal_network_amd.trainer import PPNTrainer
+    dev = torch.device("cuda")
+    size, B = 192, 4
+    x = torch.from_numpy(synth.normalized_frames(prng.u8_frames(31, B, (size, size)))).to(dev)
+    tg = targets.synthetic_targets(32, B, (size, size), device=dev)
+    runs = []
+    for batched in (False, True):
+        monkeypatch.setattr(T, "_BATCHED_PACK", batched)
+        tr = PPNTrainer("drn_d_22", synth.make_state_dict("drn_d_22", 7), compute_dtype=L.PPN_BF16, insize=(size, size),
+                        lr=2e-4)
+        hist, packed = [], []
+        for it in range(4):
+            if it == 2:
+                tr.P["conv2.weight"].mul_(1.01)                                  # in-place edit between two passes
+            losses, w = tr.train_step(x, tg)
+            hist.append(torch.cat([losses, w]).clone())
+            packed.append(T.repack_all(dev) if batched else 0)
+        torch.cuda.synchronize()
+        runs.append((torch.stack(hist).cpu(), tr.flat.clone().cpu()))
+        if batched:
+            assert packed[0] >= 60 and packed[-1] == packed[0], packed           # every weight view of the step is in the table
+        del tr
+    (h0, p0), (h1, p1) = runs
+    assert torch.isfinite(h0).all() and torch.equal(h0, h1) and torch.equal(p0, p1)

@@ -1,5 +1,7 @@
-"""Micro-benchmark of the stem kernels at batch 32, 384x384 u8 frames, bf16 (one-launch stem012 vs three launches).
-PPN_LIB selects a diagnostic build (tools/build_variant.py NAME stem012.hip -DPPN_S012_SKIP=mask)."""
+"""Micro-benchmark of the one-launch stem (stem012) at batch 32, 384x384 u8 frames, in the variant the bf16 plan runs:
+IEEE-half internals with the exact integer input, bf16 outputs (PPN_STEM_IO(PPN_F16, PPN_BF16)); STEM_DTYPE=bf16 times the
+all-bf16 variant.  Arguments: names of diagnostic builds under tools/bin (tools/build_variant.py NAME stem012.hip
+-DPPN_S012_SKIP=mask), "default" = the in-tree library."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -22,12 +24,13 @@ def main():
     for n in names:
         path = L.LIB_PATH if n == "default" else os.path.join(os.path.dirname(os.path.abspath(__file__)), "bin", f"libppn_{n}.so")
         lib = C.CDLL(path)
-        lib.ppn_stem012.restype, lib.ppn_stem012.argtypes = L._SIGNATURES["ppn_stem012"]
+        lib.ppn_stem012_dt.restype, lib.ppn_stem012_dt.argtypes = L._SIGNATURES["ppn_stem012_dt"]
         libs.append((n, lib))
+    dt = L.PPN_BF16 if os.environ.get("STEM_DTYPE") == "bf16" else (L.PPN_F16 | ((L.PPN_BF16 + 1) << 8))
     def run(lib):
-        rc = lib.ppn_stem012(1, frames.data_ptr(), B, H, W, w0.data_ptr(), s[0].data_ptr(), b[0].data_ptr(), m3, s3,
-                             w1.data_ptr(), s[1].data_ptr(), b[1].data_ptr(), w2.data_ptr(), s[2].data_ptr(), b[2].data_ptr(),
-                             s[3].data_ptr(), b[3].data_ptr(), raw.data_ptr(), act.data_ptr(), st)
+        rc = lib.ppn_stem012_dt(dt, 1, frames.data_ptr(), B, H, W, w0.data_ptr(), s[0].data_ptr(), b[0].data_ptr(), m3, s3,
+                                w1.data_ptr(), s[1].data_ptr(), b[1].data_ptr(), w2.data_ptr(), s[2].data_ptr(), b[2].data_ptr(),
+                                s[3].data_ptr(), b[3].data_ptr(), raw.data_ptr(), act.data_ptr(), st)
         assert rc == 0
     for n, lib in libs:
         for _ in range(3): run(lib)

@@ -15,6 +15,7 @@ CASES = [  # name, B, cin, cout, H (input), k, stride, dil, pad
     ("head conv3 1x1 512->7616 @24", 32, 512, 7616, 24, 1, 1, 1, 0),
     ("layer1 3x3 16->16 @384", 32, 16, 16, 384, 3, 1, 1, 1),
     ("layer0 7x7 8->16 @384", 32, 8, 16, 384, 7, 1, 1, 3),
+    ("layer0 7x7 4->16 @384", 32, 4, 16, 384, 7, 1, 1, 3),
     ("layer2 3x3 16->32 s2 @384", 32, 16, 32, 384, 3, 2, 1, 1),
     ("head block 3x3 512->512 @24", 32, 512, 512, 24, 3, 1, 1, 1),
     ("layer6.0 3x3 256->512 d4 @48", 32, 256, 512, 48, 3, 1, 4, 4),

@@ -56,6 +56,13 @@ def st(*a, **k):
     e2 = torch.cuda.Event(enable_timing=True); e2.record(); gpu.setdefault("tail_end", []).append(e2)
     return r
 tr._second_order_tail = st
+from pytorch_pose_proposal_network_amd import train as _T
+_ps = _T.probe_stats
+def ps(*a, **k):
+    # the main stream has just waited for the side (weight-gradient) and probe streams: how long did it sit there?
+    e = torch.cuda.Event(enable_timing=True); e.record(); gpu.setdefault("joined", []).append(e)
+    return _ps(*a, **k)
+_T.probe_stats = ps
 for _ in range(3):
     tr.train_step(x, tg)
 torch.cuda.synchronize()
@@ -81,4 +88,4 @@ for i in range(3):
     pr = gpu["probe"][4 * i:4 * i + 4]
     print(f"iteration {i}: GPU time after the end of the loss: first probe starts +{le.elapsed_time(pr[0]):.3f} ms, fourth probe starts "
           f"+{le.elapsed_time(pr[3]):.3f}, main stream reaches the second-order tail +{le.elapsed_time(gpu['tail'][i]):.3f}, "
-          f"tail done +{le.elapsed_time(gpu['tail_end'][i]):.3f}")
+          f"side + probe streams joined +{le.elapsed_time(gpu['joined'][i]):.3f}, tail done +{le.elapsed_time(gpu['tail_end'][i]):.3f}")

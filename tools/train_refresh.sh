@@ -1,6 +1,8 @@
 #!/bin/bash
+# Training-step evidence only (a subset of refresh_profiles.sh): bench, rocprofv3 kernel stats of the first- and
+# second-order step, the main-stream timeline and the host timeline.  tools/train_refresh.sh TAG -> gpurun_out/TAG/
 set -e
-R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/r03t; mkdir -p $O
+R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/${1:-r04t}; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 python3 $R/tools/bench_train.py --phases --first-order > $O/train_bench.txt 2>&1
 python3 $R/bench.py --workload train --steps 10 --warmup 2 > $O/bench_train.json 2> $O/bench_train.err
