@@ -632,3 +632,38 @@ def test_batched_weight_pack_leaves_the_step_bitwise_unchanged(monkeypatch):
         del tr
     (h0, p0), (h1, p1) = runs
     assert torch.isfinite(h0).all() and torch.equal(h0, h1) and torch.equal(p0, p1)
+
+
+@pytest.mark.parametrize("zero_task", [None, 2])
+def test_speculative_tail_equals_the_read_back_first_order(zero_task):
+    """The second-order tail enqueues its forward-mode half (tangents through bn0_2 .. conv3, all five streams, unit
+    directions divided on the device) BEFORE the host has read the probe norms, and keeps it when the host values agree
+    (PPN_TRAIN_SPECULATE_TAIL, round 4).  Against the read-back-first order (speculation off) on the same trainer state:
+    * all five streams active: every gradient within 1e-5 of its scale (the only difference is v_i = g_i / ||g_i|| divided
+      by a device scalar instead of multiplied by a host reciprocal), losses identical;
+    * one task weight exactly zero (kappa_i = 0: that stream is inactive): the speculative tensors are dropped and the
+      tangents rebuilt for the four active streams -- bitwise the same gradients as without speculation."""
+    from pytorch_pose_proposal_network_amd import lib as L, synth, prng, targets
+    from pytorch_pose_proposal_network_amd.trainer import PPNTrainer
+    dev = torch.device("cuda")
+    size, B = 192, 4
+    x = torch.from_numpy(synth.normalized_frames(prng.u8_frames(41, B, (size, size)))).to(dev)
+    tg = targets.synthetic_targets(42, B, (size, size), device=dev)
+    out = []
+    for spec in (False, True):
+        tr = PPNTrainer("drn_d_22", synth.make_state_dict("drn_d_22", 7), compute_dtype=L.PPN_F32, insize=(size, size))
+        tr._speculate_tail = spec
+        tr.base = torch.tensor([1.0, 0.8, 1.2, 0.9, 1.1], device=dev)
+        if zero_task is not None:
+            tr.task.w[zero_task] = 0.0
+            tr.task.touched()
+        losses, gn, _ = tr.local_pass(x, tg)
+        torch.cuda.synchronize()
+        out.append((losses.cpu(), gn.cpu(), tr.grad.clone().cpu()))
+        del tr
+    (l0, g0, p0), (l1, g1, p1) = out
+    assert torch.equal(l0, l1) and torch.equal(g0, g1) and torch.isfinite(p0).all() and float(p0.abs().max()) > 0
+    if zero_task is not None:
+        assert torch.equal(p0, p1)
+    else:
+        assert float((p0 - p1).abs().max()) <= 1e-5 * float(p0.abs().max())
