@@ -25,11 +25,11 @@
 // (v_mfma_f32_16x16x32_bf16: 7 + 5 + 2x5 per 16 pixels); intermediate activations are rounded to bf16 exactly where
 // the layer-by-layer kernels (stem.hip, stem3x3.hip) round them, and the MFMA sequences are the same, so the results
 // are bit-identical to theirs (tests/test_conv_gpu.py::test_fused_stem_equals_layer_by_layer).
-// Round 4 (tools/bench_stem.py, batch 32): 176 -> 159 us.  (1) the weights reach the lanes through LDS (the guarded per-lane
+// Round 4 (tools/bench_stem.py, batch 32): 176 -> 155 us.  (1) the weights reach the lanes through LDS (the guarded per-lane
 // global loads of the 7x7 fragments were 66 serialised L2 round trips at the head of every workgroup: -11 us); (2) layer 0 /
 // layer 1 read the operands of segment s+1 under the MFMA chain of segment s (-6 us); layer 2's 32 BN constants wait in LDS.
-// Measured and dropped: converting the exact input without the table, all reads of a thread's five rows issued together
-// (unaligned ds_read_u16 + integer conversion): +15 us.  Phase by phase (timing-only builds, -DPPN_S012_SKIP): convert 25,
+// (3) convert_input issues the byte reads of a thread's five rows together (-5 us; with the compiler's merged, unaligned
+// ds_read_u16 the same change cost +15 us).  Phase by phase (timing-only builds, -DPPN_S012_SKIP): convert 25,
 // layer 0 47, layer 1 43, layer 2 31, input requests 21 us -- additive, no unit saturated (SQ counters of the 159 us
 // kernel: MFMA pipe 25 %, VALU issue 39 %, LDS 45 % of which a fifth bank conflicts, 36 % of the wave cycles in s_waitcnt):
 // with two waves per SIMD (223 VGPRs: the three weight sets) the kernel is latency-bound; the step change needs
@@ -243,12 +243,12 @@ __global__ void __launch_bounds__(256, 2) stem012_kernel(Stem012Args a) {
         else v = a.b3 ? a.b3[c] : 0.f;
         cst_p[tid] = v;
     }
-    if constexpr (U8) {
+    if constexpr (U8 && !kExactIn) {
         // normalisation table: image.float().sub_(mean).div_(std) (rt_test.py:99-101) of every u8 value, rounded to
         // bf16 as the patch stores it -- the same expression stem.hip evaluates per pixel
         for (int i = tid; i < 3 * 256; i += 256) {
             const int c = i >> 8;
-            const H v = kExactIn ? (H)((float)(i & 255) - 128.f) : (H)(((float)(i & 255) - a.mean[c]) / a.stdv[c]);
+            const H v = (H)(((float)(i & 255) - a.mean[c]) / a.stdv[c]);
             lut_p[i] = __builtin_bit_cast(unsigned short, v);
         }
     }
@@ -305,28 +305,72 @@ __global__ void __launch_bounds__(256, 2) stem012_kernel(Stem012Args a) {
             const int prow = tid >= WI ? 1 : 0, px = tid - prow * WI;
             const int gx = xib + px;
             const bool colok = gx >= 0 && gx < a.W;
+            if constexpr (U8) {
+                // The 15 byte reads of a thread's five rows are issued together, UNCONDITIONALLY (a row or column outside
+                // the image reads stale bytes that are masked below), then -- unless the patch holds the exact integer --
+                // the 15 table look-ups together: two LDS round trips per call instead of ten (-5 us per launch).  Single
+                // ds_read_u8 on purpose: the compiler merges two of a pixel's bytes into an UNALIGNED ds_read_u16, which
+                // cost 15 us per launch.
+                const unsigned base = smem_base + (unsigned)(LDS_IN + LDS_L0 + LDS_L1) + prow * RAWS + (colok ? (gx - xs) * 3 : 0);
+                const unsigned sh0 = (((unsigned)b * a.H + (unsigned)(yi0 + prow)) * a.W + xs) * 3u;   // low 2 bits: S & 3 of row `prow`
+                const unsigned dsh = 2u * a.W * 3u;                                                     // ... and per two rows
+                unsigned v[RI / 2][3];
 #pragma unroll
-            for (int k = 0; k < RI / 2; ++k) {
-                const int py = prow + 2 * k;
-                if (py >= nrows) break;
-                const int gy = yi0 + py;
-                u32x2 o = {0u, 0u};
-                if (colok && gy >= 0 && gy < a.H) {
-                    if constexpr (U8) {
-                        const unsigned sh = ((((unsigned)b * a.H + gy) * a.W + xs) * 3u) & 3u;   // S & 3 of this row
-                        const unsigned char* s = reinterpret_cast<const unsigned char*>(raw_p) + py * RAWS + sh + (gx - xs) * 3;
-                        const unsigned v0 = lut_p[s[0]], v1 = lut_p[256 + s[1]], v2 = lut_p[512 + s[2]];
-                        o.x = v0 | (v1 << 16);
-                        o.y = kExactIn ? (v2 | (0x3C00u << 16)) : v2;                 // fourth channel: half(1.0) = inside the image
-                    } else {
-                        const float* s = static_cast<const float*>(a.src) + ((size_t)b * 3 * a.H + gy) * a.W + gx;
+                for (int k = 0; k < RI / 2; ++k) {
+                    const unsigned ad = base + 2 * k * RAWS + ((sh0 + k * dsh) & 3u);
+                    asm volatile("ds_read_u8 %0, %1" : "=v"(v[k][0]) : "v"(ad));
+                    asm volatile("ds_read_u8 %0, %1 offset:1" : "=v"(v[k][1]) : "v"(ad));
+                    asm volatile("ds_read_u8 %0, %1 offset:2" : "=v"(v[k][2]) : "v"(ad));
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if constexpr (!kExactIn) {
+                    const unsigned lb = smem_base + (unsigned)(LDS_IN + LDS_L0 + LDS_L1 + LDS_RAW);
+#pragma unroll
+                    for (int k = 0; k < RI / 2; ++k)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            const unsigned ad = lb + 512 * c + 2 * v[k][c];
+                            asm volatile("ds_read_u16 %0, %1" : "=v"(v[k][c]) : "v"(ad));
+                        }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+#pragma unroll
+                for (int k = 0; k < RI / 2; ++k) {
+                    const int py = prow + 2 * k;
+                    if (py >= nrows) break;
+                    const int gy = yi0 + py;
+                    u32x2 o = {0u, 0u};
+                    if (colok && gy >= 0 && gy < a.H) {
+                        if constexpr (kExactIn) {
+                            // the patch holds the integer x - 128, exact in half; fourth channel: half(1.0) = inside the image
+                            hx4 t;
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) t[c] = (H)(float)((int)v[k][c] - 128);
+                            t[3] = (H)1.f;
+                            o = __builtin_bit_cast(u32x2, t);
+                        } else {
+                            o.x = v[k][0] | (v[k][1] << 16);
+                            o.y = v[k][2];
+                        }
+                    }
+                    *reinterpret_cast<u32x2*>(in_p + ((size_t)py * WI + px) * 8) = o;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < RI / 2; ++k) {
+                    const int py = prow + 2 * k;
+                    if (py >= nrows) break;
+                    const int gy = yi0 + py;
+                    u32x2 o = {0u, 0u};
+                    if (colok && gy >= 0 && gy < a.H) {
+                        const float* sp = static_cast<const float*>(a.src) + ((size_t)b * 3 * a.H + gy) * a.W + gx;
                         const size_t plane = (size_t)a.H * a.W;
                         hx4 t;
-                        t[0] = (H)s[0]; t[1] = (H)s[plane]; t[2] = (H)s[2 * plane]; t[3] = (H)0.f;
+                        t[0] = (H)sp[0]; t[1] = (H)sp[plane]; t[2] = (H)sp[2 * plane]; t[3] = (H)0.f;
                         o = __builtin_bit_cast(u32x2, t);
                     }
+                    *reinterpret_cast<u32x2*>(in_p + ((size_t)py * WI + px) * 8) = o;
                 }
-                *reinterpret_cast<u32x2*>(in_p + ((size_t)py * WI + px) * 8) = o;
             }
         };
         // every wave's requests have landed (and its earlier stores have been acknowledged), for all waves
