@@ -637,6 +637,17 @@ int ppn_bn_act_mask(const ppn_bn_bwd_desc* d, void* stream);
 size_t ppn_bn_dual_workspace_bytes(int32_t channels);
 int ppn_bn_dual_bwd(const ppn_bn_bwd_desc* d, const void* xdot, float* dgamma_tan, void* stream);
 
+/* The three calls above for `nstreams` gradient / tangent streams over the SAME x in one set of launches (round 4: the
+ * second-order tail of the GradNorm step pushes five tangent streams -- one per loss, /root/reference/main.py:700-759 --
+ * through two train-mode BNs; stream by stream that was ~160 launches of ~8 us per iteration).  Every per-pixel tensor
+ * other than x (dy, dx, dx_add, xdot) holds the streams back to back: [nstreams][pixels][channels]; d->pixels is ONE
+ * stream's pixel count; dgamma, dbeta, dgamma_tan are [nstreams][channels]; d->workspace >= nstreams *
+ * ppn_bn_workspace_bytes (ppn_bn_dual_workspace_bytes for the dual call).  Stream s's results are bit-identical to the
+ * single-stream call on its slices. */
+int ppn_bn_train_bwd_streams(const ppn_bn_bwd_desc* d, int32_t nstreams, void* stream);
+int ppn_bn_act_mask_streams(const ppn_bn_bwd_desc* d, int32_t nstreams, void* stream);
+int ppn_bn_dual_bwd_streams(const ppn_bn_bwd_desc* d, const void* xdot, float* dgamma_tan, int32_t nstreams, void* stream);
+
 /* Head-space seeds for one coefficient vector c (HOST, 5 floats): with s = head, sdot = s(1-s)*tz,
  *     tzbar = sdot_bar * sig'          sdot_bar = d(sum c_i L_i)/ds
  *     zbar  = s_bar*sig' + sdot_bar*sig''*tz,   s_bar = (d2(sum c_i L_i)/ds2) sdot   (dual-number evaluation)

@@ -46,7 +46,12 @@ __global__ void __launch_bounds__(kThreads) bn_reduce_kernel(const T* __restrict
                                                              const float* __restrict__ beta,
                                                              const float* __restrict__ mean,
                                                              const float* __restrict__ rstd, int act, long long P,
-                                                             int C, Slab s, double* __restrict__ partial) {
+                                                             int C, Slab s, double* __restrict__ partial,
+                                                             long long sstride = 0, long long pstride = 0) {
+    // blockIdx.y: one of several gradient streams over the SAME x (the second-order tail's stacked tangents / adjoints):
+    // dy and the partials move by a stream stride, everything per-channel is shared
+    dy += (size_t)blockIdx.y * sstride;
+    partial += (size_t)blockIdx.y * pstride;
     __shared__ double red[kThreads][17];
     const int t = threadIdx.x;
     const int col = t % s.cc, roff = t / s.cc;
@@ -183,7 +188,11 @@ __global__ void __launch_bounds__(kThreads) bn_apply_kernel(const T* __restrict_
 __global__ void bn_bwd_finalize_kernel(const double* __restrict__ partial, int nblocks, int C, long long P,
                                        const float* __restrict__ gamma, const float* __restrict__ mean,
                                        const float* __restrict__ rstd, float* __restrict__ dgamma,
-                                       float* __restrict__ dbeta, float* __restrict__ coef) {
+                                       float* __restrict__ dbeta, float* __restrict__ coef, long long pstride = 0) {
+    partial += (size_t)blockIdx.y * pstride;           // stream blockIdx.y: its own partials, dgamma / dbeta rows, coefficients
+    dgamma += (size_t)blockIdx.y * C;
+    dbeta += (size_t)blockIdx.y * C;
+    coef += (size_t)blockIdx.y * 3 * C;
     const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (c >= C) return;
@@ -214,7 +223,12 @@ __global__ void __launch_bounds__(kThreads) bn_bwd_apply_kernel(const T* __restr
                                                                 const float* __restrict__ mean,
                                                                 const float* __restrict__ rstd,
                                                                 const float* __restrict__ coef, int act,
-                                                                long long P, int C, Slab s, T* __restrict__ dx) {
+                                                                long long P, int C, Slab s, T* __restrict__ dx,
+                                                                long long sstride = 0) {
+    dy += (size_t)blockIdx.y * sstride;                // stream blockIdx.y (see bn_reduce_kernel)
+    dx += (size_t)blockIdx.y * sstride;
+    if (add) add += (size_t)blockIdx.y * sstride;
+    coef += (size_t)blockIdx.y * 3 * C;
     const int t = threadIdx.x;
     const int col = t % s.cc, roff = t / s.cc;
     const long long p0 = (long long)blockIdx.x * s.slab;
@@ -490,7 +504,9 @@ __global__ void __launch_bounds__(kThreads) bn_act_mask_kernel(const T* __restri
                                                                const float* __restrict__ beta,
                                                                const float* __restrict__ mean,
                                                                const float* __restrict__ rstd, int act, long long P,
-                                                               int C, Slab s, T* __restrict__ out) {
+                                                               int C, Slab s, T* __restrict__ out, long long sstride = 0) {
+    in += (size_t)blockIdx.y * sstride;                // stream blockIdx.y (see bn_reduce_kernel)
+    out += (size_t)blockIdx.y * sstride;
     const int t = threadIdx.x;
     const int col = t % s.cc, roff = t / s.cc;
     const long long p0 = (long long)blockIdx.x * s.slab;
@@ -524,7 +540,11 @@ __global__ void __launch_bounds__(kThreads) bn_dual_reduce_kernel(const T* __res
                                                                   const float* __restrict__ mean,
                                                                   const float* __restrict__ rstd, int act,
                                                                   long long P, int C, Slab s,
-                                                                  double* __restrict__ partial) {
+                                                                  double* __restrict__ partial, long long sstride = 0,
+                                                                  long long pstride = 0) {
+    xdot += (size_t)blockIdx.y * sstride;              // stream blockIdx.y (see bn_reduce_kernel)
+    dyt += (size_t)blockIdx.y * sstride;
+    partial += (size_t)blockIdx.y * pstride;
     __shared__ double red[kThreads][9];
     const int t = threadIdx.x;
     const int col = t % s.cc, roff = t / s.cc;
@@ -573,7 +593,10 @@ __global__ void __launch_bounds__(kThreads) bn_dual_reduce_kernel(const T* __res
 // coef[c][0..3]: dx_tan = c0*xhat + c1*q + c2*xdot + c3   (xhat = (x-mean)*rstd), dgamma_tan[c] = A*rstd
 __global__ void bn_dual_finalize_kernel(const double* __restrict__ partial, int nblocks, int C, long long P,
                                         const float* __restrict__ gamma, const float* __restrict__ rstd,
-                                        float* __restrict__ coef, float* __restrict__ dgamma_tan) {
+                                        float* __restrict__ coef, float* __restrict__ dgamma_tan, long long pstride = 0) {
+    partial += (size_t)blockIdx.y * pstride;
+    coef += (size_t)blockIdx.y * 4 * C;
+    dgamma_tan += (size_t)blockIdx.y * C;
     const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (c >= C) return;
@@ -605,7 +628,11 @@ __global__ void __launch_bounds__(kThreads) bn_dual_apply_kernel(const T* __rest
                                                                  const float* __restrict__ mean,
                                                                  const float* __restrict__ rstd,
                                                                  const float* __restrict__ coef, int act, long long P,
-                                                                 int C, Slab s, T* __restrict__ dx) {
+                                                                 int C, Slab s, T* __restrict__ dx, long long sstride = 0) {
+    xdot += (size_t)blockIdx.y * sstride;              // stream blockIdx.y (see bn_reduce_kernel)
+    dyt += (size_t)blockIdx.y * sstride;
+    dx += (size_t)blockIdx.y * sstride;
+    coef += (size_t)blockIdx.y * 4 * C;
     const int t = threadIdx.x;
     const int col = t % s.cc, roff = t / s.cc;
     const long long p0 = (long long)blockIdx.x * s.slab;
@@ -742,41 +769,50 @@ int ppn_bn_train_fwd(const ppn_bn_desc* d, void* stream) {
     return PPN_OK;
 }
 
-int ppn_bn_train_bwd(const ppn_bn_bwd_desc* d, void* stream) {
+static int bn_train_bwd_impl(const ppn_bn_bwd_desc* d, int nstreams, void* stream) {
     if (!d || !d->x || !d->dy || !d->gamma || !d->beta || !d->save_mean || !d->save_rstd || !d->dgamma ||
         !d->dbeta || !d->dx || !d->workspace)
         return ppn::fail(PPN_E_INVALID, "ppn_bn_train_bwd: NULL argument");
     if (d->dtype != PPN_F32 && d->dtype != PPN_BF16) return ppn::fail(PPN_E_INVALID, "bad dtype %d", d->dtype);
     if (d->act < PPN_ACT_NONE || d->act > PPN_ACT_LRELU) return ppn::fail(PPN_E_UNSUPPORTED, "bad act %d", d->act);
+    if (nstreams < 1 || nstreams > 64) return ppn::fail(PPN_E_INVALID, "ppn_bn_train_bwd_streams: 1 <= nstreams <= 64");
     Slab s;
     if (int rc = make_slab(d->channels, d->pixels, &s)) return rc;
     hipStream_t st = (hipStream_t)stream;
     const int C = d->channels;
+    const long long pstride = (long long)kMaxBlocks * C * 2, sstride = d->pixels * C;
     double* partial = reinterpret_cast<double*>(d->workspace);
     float* coef = reinterpret_cast<float*>(reinterpret_cast<char*>(d->workspace) +
-                                           (size_t)kMaxBlocks * C * 2 * sizeof(double));
+                                           (size_t)nstreams * pstride * sizeof(double));
+    const dim3 grid(s.nblocks, nstreams), fgrid((C + 3) / 4, nstreams);
     if (d->dtype == PPN_F32)
-        bn_reduce_kernel<float, 1><<<s.nblocks, kThreads, 0, st>>>((const float*)d->x, (const float*)d->dy, d->gamma,
-                                                                   d->beta, d->save_mean, d->save_rstd, d->act,
-                                                                   d->pixels, C, s, partial);
+        bn_reduce_kernel<float, 1><<<grid, kThreads, 0, st>>>((const float*)d->x, (const float*)d->dy, d->gamma,
+                                                              d->beta, d->save_mean, d->save_rstd, d->act,
+                                                              d->pixels, C, s, partial, sstride, pstride);
     else
-        bn_reduce_kernel<__bf16, 1><<<s.nblocks, kThreads, 0, st>>>((const __bf16*)d->x, (const __bf16*)d->dy,
-                                                                    d->gamma, d->beta, d->save_mean, d->save_rstd,
-                                                                    d->act, d->pixels, C, s, partial);
+        bn_reduce_kernel<__bf16, 1><<<grid, kThreads, 0, st>>>((const __bf16*)d->x, (const __bf16*)d->dy,
+                                                               d->gamma, d->beta, d->save_mean, d->save_rstd,
+                                                               d->act, d->pixels, C, s, partial, sstride, pstride);
     PPN_LAUNCH_CHECK();
-    bn_bwd_finalize_kernel<<<(C + 3) / 4, 256, 0, st>>>(partial, s.nblocks, C, d->pixels, d->gamma, d->save_mean,
-                                                         d->save_rstd, d->dgamma, d->dbeta, coef);
+    bn_bwd_finalize_kernel<<<fgrid, 256, 0, st>>>(partial, s.nblocks, C, d->pixels, d->gamma, d->save_mean,
+                                                   d->save_rstd, d->dgamma, d->dbeta, coef, pstride);
     PPN_LAUNCH_CHECK();
     if (d->dtype == PPN_F32)
-        bn_bwd_apply_kernel<float><<<s.nblocks, kThreads, 0, st>>>(
+        bn_bwd_apply_kernel<float><<<grid, kThreads, 0, st>>>(
             (const float*)d->x, (const float*)d->dy, (const float*)d->dx_add, d->gamma, d->beta, d->save_mean,
-            d->save_rstd, coef, d->act, d->pixels, C, s, (float*)d->dx);
+            d->save_rstd, coef, d->act, d->pixels, C, s, (float*)d->dx, sstride);
     else
-        bn_bwd_apply_kernel<__bf16><<<s.nblocks, kThreads, 0, st>>>(
+        bn_bwd_apply_kernel<__bf16><<<grid, kThreads, 0, st>>>(
             (const __bf16*)d->x, (const __bf16*)d->dy, (const __bf16*)d->dx_add, d->gamma, d->beta, d->save_mean,
-            d->save_rstd, coef, d->act, d->pixels, C, s, (__bf16*)d->dx);
+            d->save_rstd, coef, d->act, d->pixels, C, s, (__bf16*)d->dx, sstride);
     PPN_LAUNCH_CHECK();
     return PPN_OK;
+}
+
+int ppn_bn_train_bwd(const ppn_bn_bwd_desc* d, void* stream) { return bn_train_bwd_impl(d, 1, stream); }
+
+int ppn_bn_train_bwd_streams(const ppn_bn_bwd_desc* d, int32_t nstreams, void* stream) {
+    return bn_train_bwd_impl(d, nstreams, stream);
 }
 
 int ppn_colsum(int32_t dtype, const void* x, int64_t pixels, int32_t channels, float* out, void* workspace,
@@ -842,24 +878,32 @@ int ppn_nchw_to_nhwc(int32_t dtype, const float* src, int32_t batch, int32_t cha
     return PPN_OK;
 }
 
-int ppn_bn_act_mask(const ppn_bn_bwd_desc* d, void* stream) {
+static int bn_act_mask_impl(const ppn_bn_bwd_desc* d, int nstreams, void* stream) {
     // uses x, dy (= the tensor to mask), gamma, beta, save_mean, save_rstd, act, dx (= output)
     if (!d || !d->x || !d->dy || !d->gamma || !d->beta || !d->save_mean || !d->save_rstd || !d->dx)
         return ppn::fail(PPN_E_INVALID, "ppn_bn_act_mask: NULL argument");
+    if (nstreams < 1 || nstreams > 64) return ppn::fail(PPN_E_INVALID, "ppn_bn_act_mask_streams: 1 <= nstreams <= 64");
     Slab s;
     if (int rc = make_slab(d->channels, d->pixels, &s)) return rc;
     hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(s.nblocks, nstreams);
+    const long long sstride = d->pixels * d->channels;
     if (d->dtype == PPN_F32)
-        bn_act_mask_kernel<float><<<s.nblocks, kThreads, 0, st>>>((const float*)d->x, (const float*)d->dy, d->gamma, d->beta,
-                                                                  d->save_mean, d->save_rstd, d->act, d->pixels,
-                                                                  d->channels, s, (float*)d->dx);
+        bn_act_mask_kernel<float><<<grid, kThreads, 0, st>>>((const float*)d->x, (const float*)d->dy, d->gamma, d->beta,
+                                                             d->save_mean, d->save_rstd, d->act, d->pixels,
+                                                             d->channels, s, (float*)d->dx, sstride);
     else if (d->dtype == PPN_BF16)
-        bn_act_mask_kernel<__bf16><<<s.nblocks, kThreads, 0, st>>>((const __bf16*)d->x, (const __bf16*)d->dy, d->gamma,
-                                                                   d->beta, d->save_mean, d->save_rstd, d->act,
-                                                                   d->pixels, d->channels, s, (__bf16*)d->dx);
+        bn_act_mask_kernel<__bf16><<<grid, kThreads, 0, st>>>((const __bf16*)d->x, (const __bf16*)d->dy, d->gamma,
+                                                              d->beta, d->save_mean, d->save_rstd, d->act,
+                                                              d->pixels, d->channels, s, (__bf16*)d->dx, sstride);
     else return ppn::fail(PPN_E_INVALID, "bad dtype %d", d->dtype);
     PPN_LAUNCH_CHECK();
     return PPN_OK;
+}
+
+int ppn_bn_act_mask(const ppn_bn_bwd_desc* d, void* stream) { return bn_act_mask_impl(d, 1, stream); }
+int ppn_bn_act_mask_streams(const ppn_bn_bwd_desc* d, int32_t nstreams, void* stream) {
+    return bn_act_mask_impl(d, nstreams, stream);
 }
 
 size_t ppn_bn_dual_workspace_bytes(int32_t channels) {
@@ -867,44 +911,54 @@ size_t ppn_bn_dual_workspace_bytes(int32_t channels) {
     return (size_t)kMaxBlocks * channels * 5 * sizeof(double) + (size_t)4 * channels * sizeof(float);
 }
 
-int ppn_bn_dual_bwd(const ppn_bn_bwd_desc* d, const void* xdot, float* dgamma_tan, void* stream) {
+static int bn_dual_bwd_impl(const ppn_bn_bwd_desc* d, const void* xdot, float* dgamma_tan, int nstreams, void* stream) {
     // d->dy = adjoint arriving at the (activated) tangent output, d->dx is ACCUMULATED into, d->workspace >=
-    // ppn_bn_dual_workspace_bytes(channels); d->dgamma / dbeta / dx_add are not used
+    // nstreams * ppn_bn_dual_workspace_bytes(channels); d->dgamma / dbeta / dx_add are not used
     if (!d || !d->x || !d->dy || !xdot || !d->gamma || !d->beta || !d->save_mean || !d->save_rstd || !d->dx ||
         !d->workspace || !dgamma_tan)
         return ppn::fail(PPN_E_INVALID, "ppn_bn_dual_bwd: NULL argument");
     if (d->dtype != PPN_F32 && d->dtype != PPN_BF16) return ppn::fail(PPN_E_INVALID, "bad dtype %d", d->dtype);
+    if (nstreams < 1 || nstreams > 64) return ppn::fail(PPN_E_INVALID, "ppn_bn_dual_bwd_streams: 1 <= nstreams <= 64");
     Slab s;
     if (int rc = make_slab(d->channels, d->pixels, &s)) return rc;
     hipStream_t st = (hipStream_t)stream;
     const int C = d->channels;
+    const long long pstride = (long long)kMaxBlocks * C * 5, sstride = d->pixels * C;
     double* partial = reinterpret_cast<double*>(d->workspace);
-    float* coef = reinterpret_cast<float*>(reinterpret_cast<char*>(d->workspace) + (size_t)kMaxBlocks * C * 5 * sizeof(double));
+    float* coef = reinterpret_cast<float*>(reinterpret_cast<char*>(d->workspace) + (size_t)nstreams * pstride * sizeof(double));
+    const dim3 grid(s.nblocks, nstreams), fgrid((C + 3) / 4, nstreams);
     if (d->dtype == PPN_F32)
-        bn_dual_reduce_kernel<float><<<s.nblocks, kThreads, 0, st>>>((const float*)d->x, (const float*)xdot,
-                                                                     (const float*)d->dy, d->gamma, d->beta, d->save_mean,
-                                                                     d->save_rstd, d->act, d->pixels, C, s, partial);
+        bn_dual_reduce_kernel<float><<<grid, kThreads, 0, st>>>((const float*)d->x, (const float*)xdot,
+                                                                (const float*)d->dy, d->gamma, d->beta, d->save_mean,
+                                                                d->save_rstd, d->act, d->pixels, C, s, partial, sstride, pstride);
     else
-        bn_dual_reduce_kernel<__bf16><<<s.nblocks, kThreads, 0, st>>>((const __bf16*)d->x, (const __bf16*)xdot,
-                                                                      (const __bf16*)d->dy, d->gamma, d->beta,
-                                                                      d->save_mean, d->save_rstd, d->act, d->pixels, C, s,
-                                                                      partial);
+        bn_dual_reduce_kernel<__bf16><<<grid, kThreads, 0, st>>>((const __bf16*)d->x, (const __bf16*)xdot,
+                                                                 (const __bf16*)d->dy, d->gamma, d->beta,
+                                                                 d->save_mean, d->save_rstd, d->act, d->pixels, C, s,
+                                                                 partial, sstride, pstride);
     PPN_LAUNCH_CHECK();
-    bn_dual_finalize_kernel<<<(C + 3) / 4, 256, 0, st>>>(partial, s.nblocks, C, d->pixels, d->gamma, d->save_rstd, coef,
-                                                         dgamma_tan);
+    bn_dual_finalize_kernel<<<fgrid, 256, 0, st>>>(partial, s.nblocks, C, d->pixels, d->gamma, d->save_rstd, coef,
+                                                    dgamma_tan, pstride);
     PPN_LAUNCH_CHECK();
     if (d->dtype == PPN_F32)
-        bn_dual_apply_kernel<float><<<s.nblocks, kThreads, 0, st>>>((const float*)d->x, (const float*)xdot,
-                                                                    (const float*)d->dy, d->gamma, d->beta, d->save_mean,
-                                                                    d->save_rstd, coef, d->act, d->pixels, C, s,
-                                                                    (float*)d->dx);
+        bn_dual_apply_kernel<float><<<grid, kThreads, 0, st>>>((const float*)d->x, (const float*)xdot,
+                                                               (const float*)d->dy, d->gamma, d->beta, d->save_mean,
+                                                               d->save_rstd, coef, d->act, d->pixels, C, s,
+                                                               (float*)d->dx, sstride);
     else
-        bn_dual_apply_kernel<__bf16><<<s.nblocks, kThreads, 0, st>>>((const __bf16*)d->x, (const __bf16*)xdot,
-                                                                     (const __bf16*)d->dy, d->gamma, d->beta,
-                                                                     d->save_mean, d->save_rstd, coef, d->act, d->pixels,
-                                                                     C, s, (__bf16*)d->dx);
+        bn_dual_apply_kernel<__bf16><<<grid, kThreads, 0, st>>>((const __bf16*)d->x, (const __bf16*)xdot,
+                                                                (const __bf16*)d->dy, d->gamma, d->beta,
+                                                                d->save_mean, d->save_rstd, coef, d->act, d->pixels,
+                                                                C, s, (__bf16*)d->dx, sstride);
     PPN_LAUNCH_CHECK();
     return PPN_OK;
+}
+
+int ppn_bn_dual_bwd(const ppn_bn_bwd_desc* d, const void* xdot, float* dgamma_tan, void* stream) {
+    return bn_dual_bwd_impl(d, xdot, dgamma_tan, 1, stream);
+}
+int ppn_bn_dual_bwd_streams(const ppn_bn_bwd_desc* d, const void* xdot, float* dgamma_tan, int32_t nstreams, void* stream) {
+    return bn_dual_bwd_impl(d, xdot, dgamma_tan, nstreams, stream);
 }
 
 int ppn_add_relu(int32_t dtype, const void* z, const void* r, int64_t n, void* out, void* stream) {

@@ -40,11 +40,11 @@ def _f32(t: torch.Tensor, n: int, name: str) -> int:
 _ws_cache = {}
 
 
-def _workspace(channels: int, device) -> torch.Tensor:
-    key = (channels, str(device), torch.cuda.current_stream(device).cuda_stream)     # one per stream (partial sums)
+def _workspace(channels: int, device, nstreams: int = 1) -> torch.Tensor:
+    key = (channels, str(device), torch.cuda.current_stream(device).cuda_stream, nstreams)   # one per stream (partial sums)
     ws = _ws_cache.get(key)
     if ws is None:
-        ws = torch.empty(L.load().ppn_bn_workspace_bytes(channels), dtype=torch.uint8, device=device)
+        ws = torch.empty(nstreams * L.load().ppn_bn_workspace_bytes(channels), dtype=torch.uint8, device=device)
         _ws_cache[key] = ws
     return ws
 
@@ -87,32 +87,44 @@ def bn_train_forward(x: torch.Tensor, gamma, beta, running_mean=None, running_va
     return y, saved
 
 
+def _stacked(x: torch.Tensor, t: torch.Tensor, nstreams: int, name: str):
+    """t holds `nstreams` tensors of x's shape back to back along the batch dimension."""
+    if (t.shape[0] != nstreams * x.shape[0] or t.shape[1:] != x.shape[1:] or t.dtype != x.dtype or
+            not t.is_contiguous()):
+        raise ValueError(f"{name} must be {nstreams} x-shaped tensors stacked along dim 0")
+
+
 def bn_train_backward(x: torch.Tensor, dy: torch.Tensor, gamma, beta, saved: BnSaved, act: str = "none",
                       dx_add: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-                      dgamma: Optional[torch.Tensor] = None, dbeta: Optional[torch.Tensor] = None):
+                      dgamma: Optional[torch.Tensor] = None, dbeta: Optional[torch.Tensor] = None, nstreams: int = 1):
     """Returns (dx, dgamma, dbeta) for y = act(batch_norm(x)); dx_add (same shape) is added to dx.
-    dgamma / dbeta: optional f32[C] destinations (e.g. views of the flat gradient buffer), overwritten."""
+    dgamma / dbeta: optional f32[C] destinations (e.g. views of the flat gradient buffer), overwritten.
+    nstreams > 1: dy (dx, dx_add) hold that many gradient streams over the SAME x, stacked along dim 0; one set of
+    launches (ppn_bn_train_bwd_streams); dgamma / dbeta are [nstreams, C]; stream s == the single call on its slices."""
     lib = L.load()
     c = x.shape[-1]
-    if dy.shape != x.shape or dy.dtype != x.dtype or not dy.is_contiguous():
-        raise ValueError("dy must match x")
+    _stacked(x, dy, nstreams, "dy")
     if dgamma is None:
-        dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
+        dgamma = torch.empty(nstreams * c, dtype=torch.float32, device=x.device)
     if dbeta is None:
-        dbeta = torch.empty(c, dtype=torch.float32, device=x.device)
-    dx = out if out is not None else torch.empty_like(x)
+        dbeta = torch.empty(nstreams * c, dtype=torch.float32, device=x.device)
+    dx = out if out is not None else torch.empty_like(dy)
+    _stacked(x, dx, nstreams, "out")
     d = L.BnBwdDesc()
     d.dtype, d.channels, d.pixels, d.act = _dtype_code(x), c, x.numel() // c, ACT[act]
     d.x, d.dy = x.data_ptr(), dy.data_ptr()
     if dx_add is not None:
-        if dx_add.shape != x.shape or dx_add.dtype != x.dtype or not dx_add.is_contiguous():
-            raise ValueError("dx_add must match x")
+        _stacked(x, dx_add, nstreams, "dx_add")
         d.dx_add = dx_add.data_ptr()
     d.gamma, d.beta = _f32(gamma, c, "gamma"), _f32(beta, c, "beta")
     d.save_mean, d.save_rstd = saved.mean.data_ptr(), saved.rstd.data_ptr()
-    d.dgamma, d.dbeta, d.dx = _f32(dgamma, c, "dgamma"), _f32(dbeta, c, "dbeta"), dx.data_ptr()
-    d.workspace = _workspace(c, x.device).data_ptr()
-    L.check(lib.ppn_bn_train_bwd(C.byref(d), L.current_stream_ptr()), "ppn_bn_train_bwd")
+    d.dgamma, d.dbeta, d.dx = _f32(dgamma, nstreams * c, "dgamma"), _f32(dbeta, nstreams * c, "dbeta"), dx.data_ptr()
+    d.workspace = _workspace(c, x.device, nstreams).data_ptr()
+    if nstreams == 1:
+        L.check(lib.ppn_bn_train_bwd(C.byref(d), L.current_stream_ptr()), "ppn_bn_train_bwd")
+    else:
+        L.check(lib.ppn_bn_train_bwd_streams(C.byref(d), nstreams, L.current_stream_ptr()), "ppn_bn_train_bwd_streams")
+        dgamma, dbeta = dgamma.view(nstreams, c), dbeta.view(nstreams, c)
     return dx, dgamma, dbeta
 
 
@@ -272,7 +284,7 @@ class GradNormWeights:
 
 def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, stride: int = 1, dilation: int = 1, pad: int = 0,
                 add: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None, act: int = 0,
-                nchw_f32: bool = False, dgrad_of: bool = False) -> torch.Tensor:
+                nchw_f32: bool = False, dgrad_of: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Raw convolution (no folded BN: train mode keeps BN separate) of an NHWC tensor with a reference-layout
     f32 weight [cout,cin,k,k] on the device, + `add` (NHWC, the residual).  Packs the weight for the MFMA
     kernels on the fly: in training the weights change every step anyway."""
@@ -307,10 +319,11 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, stride: int = 1, dilation: int
                                 (w.data_ptr(), buf.data_ptr(), dt, cout, cin, k, cpad, ktot, korder, kstep, 1 if dgrad_of else 0, 0))
         packed = (_param_version[0], buf)
     packed = packed[1]
-    if nchw_f32:                                  # the head tensor the loss / decode kernels read (model.py:134-136)
-        out = torch.empty(B, cout, Ho, Wo, dtype=torch.float32, device=x.device)
-    else:
-        out = torch.empty(B, Ho, Wo, cout, dtype=x.dtype, device=x.device)
+    oshape, odt = ((B, cout, Ho, Wo), torch.float32) if nchw_f32 else ((B, Ho, Wo, cout), x.dtype)
+    if out is None:                               # nchw_f32: the head tensor the loss / decode kernels read (model.py:134-136)
+        out = torch.empty(oshape, dtype=odt, device=x.device)
+    elif tuple(out.shape) != oshape or out.dtype != odt or not out.is_contiguous():
+        raise ValueError("conv2d_nhwc: `out` must be a contiguous tensor of the output's shape and type")
     zero = _zero_page(x.device)
     d = L.ConvDesc()
     d.dtype, d.batch, d.in_h, d.in_w, d.cin = dt, B, H, W, cin
@@ -591,36 +604,60 @@ def _bwd_desc(x, dy, gamma, beta, saved, act, dx):
     return d
 
 
-def bn_tangent(x, xdot, gamma, beta, saved: BnSaved, act: str, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Forward-mode image of y = act(bn_train(x)) for an input tangent xdot: act'(z) * gamma*rstd*P(xdot)."""
+def bn_tangent(x, xdot, gamma, beta, saved: BnSaved, act: str, out: Optional[torch.Tensor] = None,
+               nstreams: int = 1) -> torch.Tensor:
+    """Forward-mode image of y = act(bn_train(x)) for an input tangent xdot: act'(z) * gamma*rstd*P(xdot).
+    nstreams > 1: xdot / out hold that many tangents of the same x stacked along dim 0 (4 launches for all of them)."""
     lib = L.load()
-    jvp, _, _ = bn_train_backward(x, xdot, gamma, beta, saved, act="none")      # the BN tangent IS the backward formula
+    jvp, _, _ = bn_train_backward(x, xdot, gamma, beta, saved, act="none", nstreams=nstreams)   # the BN tangent IS the backward formula
     if out is None:
-        out = torch.empty_like(x)
+        out = torch.empty_like(xdot)
+    _stacked(x, out, nstreams, "out")
     d = _bwd_desc(x, jvp, gamma, beta, saved, act, out)
-    L.check(lib.ppn_bn_act_mask(C.byref(d), L.current_stream_ptr()), "ppn_bn_act_mask")
+    if nstreams == 1:
+        L.check(lib.ppn_bn_act_mask(C.byref(d), L.current_stream_ptr()), "ppn_bn_act_mask")
+    else:
+        L.check(lib.ppn_bn_act_mask_streams(C.byref(d), nstreams, L.current_stream_ptr()), "ppn_bn_act_mask_streams")
     return out
 
 
 _dual_ws = {}
 
 
-def bn_dual_backward(x, xdot, dy, dyt, gamma, beta, saved: BnSaved, act: str, out_dx=None, out_dxdot=None):
+def bn_dual_backward(x, xdot, dy, dyt, gamma, beta, saved: BnSaved, act: str, out_dx=None, out_dxdot=None,
+                     nstreams: int = 1, dy_dyt: Optional[torch.Tensor] = None, out_both: Optional[torch.Tensor] = None):
     """Adjoint of the pair (y, ydot) = (act(bn(x)), bn_tangent(x, xdot)) for adjoints (dy, dyt).
-    Returns (dx, dxdot, dgamma, dbeta): the ordinary backward of dy plus the tangent stream's contributions."""
+    Returns (dx, dxdot, dgamma, dbeta): the ordinary backward of dy plus the tangent stream's contributions.
+    nstreams > 1: xdot, dy, dyt (and the outputs) hold that many streams over the same x stacked along dim 0; dgamma /
+    dbeta come back as [nstreams, C].  dy_dyt: ONE tensor [dy streams | dyt streams] (2 * nstreams stacked; dy / dyt are
+    then ignored) -- with out_both of the same layout the two ordinary backward passes are a single set of launches."""
     lib = L.load()
     c = x.shape[-1]
-    dx, dgamma, dbeta = bn_train_backward(x, dy, gamma, beta, saved, act=act, out=out_dx)
-    dxdot, _, _ = bn_train_backward(x, dyt, gamma, beta, saved, act=act, out=out_dxdot)   # (gamma*rstd) P(dyt * act')
-    key = (c, str(x.device), torch.cuda.current_stream(x.device).cuda_stream)
+    B = x.shape[0]
+    if dy_dyt is not None:
+        _stacked(x, dy_dyt, 2 * nstreams, "dy_dyt")
+        both, dgb, dbb = bn_train_backward(x, dy_dyt, gamma, beta, saved, act=act, out=out_both, nstreams=2 * nstreams)
+        dx, dxdot = both[:nstreams * B], both[nstreams * B:]
+        dyt = dy_dyt[nstreams * B:]
+        dgamma, dbeta = dgb.view(2 * nstreams, c)[:nstreams], dbb.view(2 * nstreams, c)[:nstreams]
+    else:
+        dx, dgamma, dbeta = bn_train_backward(x, dy, gamma, beta, saved, act=act, out=out_dx, nstreams=nstreams)
+        dxdot, _, _ = bn_train_backward(x, dyt, gamma, beta, saved, act=act, out=out_dxdot, nstreams=nstreams)   # (gamma*rstd) P(dyt * act')
+    _stacked(x, xdot, nstreams, "xdot")
+    key = (c, str(x.device), torch.cuda.current_stream(x.device).cuda_stream, nstreams)
     ws = _dual_ws.get(key)
     if ws is None:
-        ws = _dual_ws[key] = torch.empty(lib.ppn_bn_dual_workspace_bytes(c), dtype=torch.uint8, device=x.device)
-    dg_tan = torch.empty(c, dtype=torch.float32, device=x.device)
+        ws = _dual_ws[key] = torch.empty(nstreams * lib.ppn_bn_dual_workspace_bytes(c), dtype=torch.uint8, device=x.device)
+    dg_tan = torch.empty(nstreams * c, dtype=torch.float32, device=x.device)
     d = _bwd_desc(x, dyt, gamma, beta, saved, act, dx)
     d.workspace = ws.data_ptr()
-    L.check(lib.ppn_bn_dual_bwd(C.byref(d), xdot.data_ptr(), dg_tan.data_ptr(), L.current_stream_ptr()),
-            "ppn_bn_dual_bwd")
+    if nstreams == 1:
+        L.check(lib.ppn_bn_dual_bwd(C.byref(d), xdot.data_ptr(), dg_tan.data_ptr(), L.current_stream_ptr()),
+                "ppn_bn_dual_bwd")
+    else:
+        L.check(lib.ppn_bn_dual_bwd_streams(C.byref(d), xdot.data_ptr(), dg_tan.data_ptr(), nstreams,
+                                            L.current_stream_ptr()), "ppn_bn_dual_bwd_streams")
+        dg_tan = dg_tan.view(nstreams, c)
     return dx, dxdot, dgamma + dg_tan, dbeta
 
 

@@ -491,16 +491,13 @@ class PPNTrainer:
             spec = self._tail_tangents(c, [(gw[i] / gn_h[i]).contiguous() for i in act], act)
         vs, u2, TH2, TA3, TC2, TH3, tz_groups = spec
 
-        def chunks(t):                                                            # [n*B, ...] -> n views [B, ...]
-            return [t[j * B:(j + 1) * B] for j in range(n)]
-
         def ssum(t):                                                              # sum over the stacked streams
             return t if n == 1 else t.view(n, B, *t.shape[1:]).sum(0)
 
         # ---- head space per stream: gradient and Hessian-vector product of loss i through the sigmoid.  The unary
         # losses only touch the first 6K channels: their streams share 128-channel conv3 launches.
-        H3bar = torch.empty_like(TH3)
-        TH3bar = torch.empty_like(TH3)
+        HB = torch.empty(2 * n * B, *TH3.shape[1:], dtype=self.tdt, device=self.device)     # [primal adj | tangent adj] at h3
+        H3bar, TH3bar = HB[:n * B], HB[n * B:]
         for js, used, w3u, th3, t_z in tz_groups:                                 # t_z: logit tangents [m*B, used, H, W]
             m = len(js)
             if used == Ch and self.tdt in (torch.float32, torch.bfloat16):
@@ -532,13 +529,14 @@ class PPNTrainer:
             H3bar[js[0] * B:(js[-1] + 1) * B] = T.conv_dgrad(zb, w3p, (Ho, Wo))
             TH3bar[js[0] * B:(js[-1] + 1) * B] = T.conv_dgrad(tzb, w3p, (Ho, Wo))
         # ---- reverse pass over the dual tail --------------------------------------------------------------------------
+        # Every BN adjoint covers all streams in one set of launches (the stream is a grid dimension; the two ordinary
+        # backward passes -- of the primal and of the tangent adjoint -- are 2n streams of one call): 9 launches per BN
+        # layer where the stream-by-stream form took 12 per stream.
         both = torch.empty(2 * n * B, *TC2.shape[1:], dtype=self.tdt, device=self.device)   # [primal adj | tangent adj]
-        C2bar, TC2bar = both[:n * B], both[n * B:]
-        for t_c2, h3b, th3b, ox, oxd in zip(chunks(TC2), chunks(H3bar), chunks(TH3bar), chunks(C2bar), chunks(TC2bar)):
-            _, _, dg, db = T.bn_dual_backward(c["c2"], t_c2, h3b, th3b, P["bn2.weight"], P["bn2.bias"], c["s3"], "lrelu",
-                                              out_dx=ox, out_dxdot=oxd)
-            Gd["bn2.weight"] += dg
-            Gd["bn2.bias"] += db
+        C2bar, TC2bar, dg, db = T.bn_dual_backward(c["c2"], TC2, None, None, P["bn2.weight"], P["bn2.bias"], c["s3"], "lrelu",
+                                                   nstreams=n, dy_dyt=HB, out_both=both)
+        Gd["bn2.weight"] += dg.sum(0)
+        Gd["bn2.bias"] += db.sum(0)
         c2sum = ssum(C2bar)
         Gd["conv2.bias"] += c2sum.float().sum((0, 1, 2))
         def wg2(c2sum=c2sum, TC2bar=TC2bar):
@@ -552,20 +550,19 @@ class PPNTrainer:
             T.conv_wgrad(c["h2"], a3sum, 1, out=Gd["conv1x1_2.weight"], accumulate=True)
             T.conv_wgrad(TH2, TA3bar, 1, out=Gd["conv1x1_2.weight"], accumulate=True)
         self._tail_side(wg12, c["h2"], a3sum, TH2, TA3bar)
-        both = T.conv_dgrad(both, P["conv1x1_2.weight"], (Ho, Wo))
-        H2bar, TH2bar = both[:n * B], both[n * B:]
-        a2sum, h1_bar = None, None
-        for u, h2b, th2b, v in zip(u2, chunks(H2bar), chunks(TH2bar), vs):
-            x_bar, u_bar, dg, db = T.bn_dual_backward(c["a2"], u, h2b, th2b, P["bn0_2.weight"], P["bn0_2.bias"],
-                                                      c["s2"], "lrelu")
-            Gd["bn0_2.weight"] += dg
-            Gd["bn0_2.bias"] += db
-            a2sum = x_bar if a2sum is None else a2sum + x_bar
-            hb = T.conv_dgrad(u_bar, v, (Ho, Wo), 1, 1, 1)                        # through u = conv(h1, v_i)
-            h1_bar = hb if h1_bar is None else h1_bar + hb
+        both = T.conv_dgrad(both, P["conv1x1_2.weight"], (Ho, Wo))                # [H2bar | TH2bar]
+        X_bar, U_bar, dg, db = T.bn_dual_backward(c["a2"], u2, None, None, P["bn0_2.weight"], P["bn0_2.bias"], c["s2"],
+                                                  "lrelu", nstreams=n, dy_dyt=both)
+        Gd["bn0_2.weight"] += dg.sum(0)
+        Gd["bn0_2.bias"] += db.sum(0)
+        a2sum = ssum(X_bar)
         self._tail_side(lambda: T.conv_wgrad(c["h1"], a2sum, 3, 1, 1, 1, out=Gd["conv1.weight"], accumulate=True),
                         c["h1"], a2sum)
-        h1_bar = h1_bar + T.conv_dgrad(a2sum, P["conv1.weight"], (Ho, Wo), 1, 1, 1)
+        # adjoint at h1: through W (primal) and through u_i = conv(h1, v_i) per stream; every convolution adds the sum so
+        # far in its epilogue (f32, one rounding) instead of a separate elementwise pass
+        h1_bar = T.conv_dgrad(a2sum, P["conv1.weight"], (Ho, Wo), 1, 1, 1)
+        for j, v in enumerate(vs):
+            h1_bar = T.conv_dgrad(U_bar[j * B:(j + 1) * B], v, (Ho, Wo), 1, 1, 1, add=h1_bar)
         r_bar = a3sum
         return h1_bar, r_bar
 
@@ -573,7 +570,7 @@ class PPNTrainer:
         """Forward-mode half of the second-order tail for the streams `act` with unit directions `vs` on W = conv1.weight:
         tangents through bn0_2 -> conv1x1_2 -> conv2 -> bn2 -> conv3.  Every stream is linear in its tangent, so the
         streams are stacked along the batch dimension for the convolutions (one launch for all of them); the BN tangents
-        need per-stream batch statistics and run stream by stream.  The unary losses only touch the first 6K head
+        need per-stream batch statistics: the stream is a grid dimension of their kernels.  The unary losses only touch the first 6K head
         channels: their streams share 128-channel conv3 launches.  Needs no host value (see _second_order_tail)."""
         P = self.P
         n = len(act)
@@ -581,16 +578,14 @@ class PPNTrainer:
         Ch = c["head"].shape[1]
         k6 = 6 * cfg.K
         vs = [v.contiguous() for v in vs]
-        u2 = [T.conv2d_nhwc(c["h1"], v, 1, 1, 1) for v in vs]
-        TH2 = torch.empty(n * B, *c["a2"].shape[1:], dtype=self.tdt, device=self.device)
-        for j, u in enumerate(u2):
-            T.bn_tangent(c["a2"], u, P["bn0_2.weight"], P["bn0_2.bias"], c["s2"], "lrelu", out=TH2[j * B:(j + 1) * B])
+        u2 = torch.empty(n * B, *c["a2"].shape[1:], dtype=self.tdt, device=self.device)   # the streams back to back
+        for j, v in enumerate(vs):
+            T.conv2d_nhwc(c["h1"], v, 1, 1, 1, out=u2[j * B:(j + 1) * B])
+        # the BN tangents of all streams in one set of launches (ppn_bn_*_streams: per-stream batch statistics, shared x)
+        TH2 = T.bn_tangent(c["a2"], u2, P["bn0_2.weight"], P["bn0_2.bias"], c["s2"], "lrelu", nstreams=n)
         TA3 = T.conv2d_nhwc(TH2, P["conv1x1_2.weight"])
         TC2 = T.conv2d_nhwc(TA3, P["conv2.weight"], 1, 1, 1)
-        TH3 = torch.empty_like(TC2)
-        for j in range(n):
-            T.bn_tangent(c["c2"], TC2[j * B:(j + 1) * B], P["bn2.weight"], P["bn2.bias"], c["s3"], "lrelu",
-                         out=TH3[j * B:(j + 1) * B])
+        TH3 = T.bn_tangent(c["c2"], TC2, P["bn2.weight"], P["bn2.bias"], c["s3"], "lrelu", nstreams=n)
         tz_groups = []
         for js, used in (([j for j, i in enumerate(act) if i < 4], k6), ([j for j, i in enumerate(act) if i == 4], Ch)):
             if not js:

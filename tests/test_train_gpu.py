@@ -327,3 +327,39 @@ def test_batched_weight_pack_equals_the_single_packs(dtype_name):
     # bad entries are refused on the host
     items[0].cout_pad = 1
     assert lib.ppn_pack_table_build(items, len(cases), host.data_ptr(), C.byref(grid)) != 0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_bn_streams_equal_the_stream_by_stream_calls(dtype):
+    """ppn_bn_train_bwd_streams / ppn_bn_act_mask_streams / ppn_bn_dual_bwd_streams (the stream is a grid dimension; the
+    second-order tail's five tangent streams share x): every stream's dx, tangent, adjoints, dgamma and dbeta bitwise equal
+    to the single-stream calls on its slices, including the [dy | dyt] form that runs both ordinary backward passes as 2n
+    streams of one call."""
+    from pytorch_pose_proposal_network_amd import train as T
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(11)
+    n, B, H, C = 3, 4, 12, 128
+    x = torch.randn(B, H, H, C, generator=g).to(dtype).to(dev)
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).to(dev), (torch.randn(C, generator=g) * 0.2).to(dev)
+    _, saved = T.bn_train_forward(x, gamma, beta, act="lrelu")
+    xdot, dy, dyt = [torch.randn(n * B, H, H, C, generator=g).to(dtype).to(dev) for _ in range(3)]
+    sl = [slice(j * B, (j + 1) * B) for j in range(n)]
+    # backward with a skip gradient
+    add = torch.randn(n * B, H, H, C, generator=g).to(dtype).to(dev)
+    dx_m, dg_m, db_m = T.bn_train_backward(x, dy, gamma, beta, saved, act="lrelu", dx_add=add, nstreams=n)
+    for j in range(n):
+        dx, dg, db = T.bn_train_backward(x, dy[sl[j]], gamma, beta, saved, act="lrelu", dx_add=add[sl[j]])
+        assert torch.equal(dx, dx_m[sl[j]]) and torch.equal(dg, dg_m[j]) and torch.equal(db, db_m[j])
+    # tangent
+    t_m = T.bn_tangent(x, xdot, gamma, beta, saved, "lrelu", nstreams=n)
+    for j in range(n):
+        assert torch.equal(T.bn_tangent(x, xdot[sl[j]], gamma, beta, saved, "lrelu"), t_m[sl[j]])
+    # dual adjoint, both forms
+    a_m = T.bn_dual_backward(x, xdot, dy, dyt, gamma, beta, saved, "lrelu", nstreams=n)
+    b_m = T.bn_dual_backward(x, xdot, None, None, gamma, beta, saved, "lrelu", nstreams=n, dy_dyt=torch.cat([dy, dyt]))
+    for j in range(n):
+        ref = T.bn_dual_backward(x, xdot[sl[j]], dy[sl[j]], dyt[sl[j]], gamma, beta, saved, "lrelu")
+        for m in (a_m, b_m):
+            assert torch.equal(ref[0], m[0][sl[j]]) and torch.equal(ref[1], m[1][sl[j]])
+            assert torch.equal(ref[2], m[2][j]) and torch.equal(ref[3], m[3][j])
+    torch.cuda.synchronize()
