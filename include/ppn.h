@@ -647,6 +647,11 @@ int ppn_bn_dual_bwd(const ppn_bn_bwd_desc* d, const void* xdot, float* dgamma_ta
 int ppn_bn_train_bwd_streams(const ppn_bn_bwd_desc* d, int32_t nstreams, void* stream);
 int ppn_bn_act_mask_streams(const ppn_bn_bwd_desc* d, int32_t nstreams, void* stream);
 int ppn_bn_dual_bwd_streams(const ppn_bn_bwd_desc* d, const void* xdot, float* dgamma_tan, int32_t nstreams, void* stream);
+/* ... with ONE d->dx [pixels][channels] that accumulates the term of every stream, in stream order (what the tail needs is
+ * the adjoint at x summed over the streams: the ordinary backward is linear in dy, so its streams are summed BEFORE the
+ * convolutions in front of it -- the primal adjoint chain of the second-order tail is a single stream). */
+int ppn_bn_dual_bwd_streams_sum(const ppn_bn_bwd_desc* d, const void* xdot, float* dgamma_tan, int32_t nstreams,
+                                void* stream);
 
 /* Head-space seeds for one coefficient vector c (HOST, 5 floats): with s = head, sdot = s(1-s)*tz,
  *     tzbar = sdot_bar * sig'          sdot_bar = d(sum c_i L_i)/ds

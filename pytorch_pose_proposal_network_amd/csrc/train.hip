@@ -911,7 +911,8 @@ size_t ppn_bn_dual_workspace_bytes(int32_t channels) {
     return (size_t)kMaxBlocks * channels * 5 * sizeof(double) + (size_t)4 * channels * sizeof(float);
 }
 
-static int bn_dual_bwd_impl(const ppn_bn_bwd_desc* d, const void* xdot, float* dgamma_tan, int nstreams, void* stream) {
+static int bn_dual_bwd_impl(const ppn_bn_bwd_desc* d, const void* xdot, float* dgamma_tan, int nstreams, void* stream,
+                            bool shared_dx = false) {
     // d->dy = adjoint arriving at the (activated) tangent output, d->dx is ACCUMULATED into, d->workspace >=
     // nstreams * ppn_bn_dual_workspace_bytes(channels); d->dgamma / dbeta / dx_add are not used
     if (!d || !d->x || !d->dy || !xdot || !d->gamma || !d->beta || !d->save_mean || !d->save_rstd || !d->dx ||
@@ -940,6 +941,27 @@ static int bn_dual_bwd_impl(const ppn_bn_bwd_desc* d, const void* xdot, float* d
     bn_dual_finalize_kernel<<<fgrid, 256, 0, st>>>(partial, s.nblocks, C, d->pixels, d->gamma, d->save_rstd, coef,
                                                     dgamma_tan, pstride);
     PPN_LAUNCH_CHECK();
+    if (shared_dx) {
+        // every stream's term accumulates into the SAME dx (the caller only needs the sum over the streams): one launch per
+        // stream, in stream order (stream order = summation order: reproducible)
+        const size_t es = d->dtype == PPN_F32 ? 4 : 2;
+        for (int g = 0; g < nstreams; ++g) {
+            const char* xd = static_cast<const char*>(xdot) + (size_t)g * sstride * es;
+            const char* dyt = static_cast<const char*>(d->dy) + (size_t)g * sstride * es;
+            const float* cf = coef + (size_t)g * 4 * C;
+            if (d->dtype == PPN_F32)
+                bn_dual_apply_kernel<float><<<s.nblocks, kThreads, 0, st>>>((const float*)d->x, (const float*)xd, (const float*)dyt,
+                                                                            d->gamma, d->beta, d->save_mean, d->save_rstd, cf,
+                                                                            d->act, d->pixels, C, s, (float*)d->dx, 0);
+            else
+                bn_dual_apply_kernel<__bf16><<<s.nblocks, kThreads, 0, st>>>((const __bf16*)d->x, (const __bf16*)xd,
+                                                                             (const __bf16*)dyt, d->gamma, d->beta, d->save_mean,
+                                                                             d->save_rstd, cf, d->act, d->pixels, C, s,
+                                                                             (__bf16*)d->dx, 0);
+            PPN_LAUNCH_CHECK();
+        }
+        return PPN_OK;
+    }
     if (d->dtype == PPN_F32)
         bn_dual_apply_kernel<float><<<grid, kThreads, 0, st>>>((const float*)d->x, (const float*)xdot,
                                                                (const float*)d->dy, d->gamma, d->beta, d->save_mean,
@@ -959,6 +981,10 @@ int ppn_bn_dual_bwd(const ppn_bn_bwd_desc* d, const void* xdot, float* dgamma_ta
 }
 int ppn_bn_dual_bwd_streams(const ppn_bn_bwd_desc* d, const void* xdot, float* dgamma_tan, int32_t nstreams, void* stream) {
     return bn_dual_bwd_impl(d, xdot, dgamma_tan, nstreams, stream);
+}
+int ppn_bn_dual_bwd_streams_sum(const ppn_bn_bwd_desc* d, const void* xdot, float* dgamma_tan, int32_t nstreams,
+                                void* stream) {
+    return bn_dual_bwd_impl(d, xdot, dgamma_tan, nstreams, stream, true);
 }
 
 int ppn_add_relu(int32_t dtype, const void* z, const void* r, int64_t n, void* out, void* stream) {

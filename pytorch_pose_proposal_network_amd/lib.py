@@ -180,6 +180,7 @@ _SIGNATURES.update({
     "ppn_bn_train_bwd_streams": (C.c_int, [C.POINTER(BnBwdDesc), C.c_int32, C.c_void_p]),
     "ppn_bn_act_mask_streams": (C.c_int, [C.POINTER(BnBwdDesc), C.c_int32, C.c_void_p]),
     "ppn_bn_dual_bwd_streams": (C.c_int, [C.POINTER(BnBwdDesc), C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "ppn_bn_dual_bwd_streams_sum": (C.c_int, [C.POINTER(BnBwdDesc), C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "ppn_loss_limb_dual_nhwc": (C.c_int, [C.POINTER(LossCfg), C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                           C.c_float, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_void_p]),

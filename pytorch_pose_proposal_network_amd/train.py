@@ -422,7 +422,7 @@ def _zero_page(device) -> torch.Tensor:
 
 
 def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, in_hw, stride: int = 1, dilation: int = 1, pad: int = 0,
-               add: Optional[torch.Tensor] = None) -> torch.Tensor:
+               add: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """dL/dx of y = conv2d(x, w, stride, dilation, pad) given dy (NHWC): the same implicit-GEMM kernel run on dy
     with the weights transposed (cin <-> cout) and flipped; a strided convolution first spreads dy over a
     zero-filled grid (the transposed-convolution identity).  `add` (NHWC like x) is added (skip-path gradient)."""
@@ -438,13 +438,15 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, in_hw, stride: int = 1, dilati
     if (_S2_PARITY and stride == 2 and dilation == 1 and pad == k // 2 and (k == 1 or (k == 3 and cin <= 16)) and
             (add is None or dy.dtype == torch.float32) and
             Ho == (H + 2 * pad - k) // 2 + 1 and Wo == (W + 2 * pad - k) // 2 + 1):
+        if out is not None:
+            raise ValueError("conv_dgrad: `out` is for the stride-1 form")
         return _dgrad_stride2(dy, w, H, W, add)
     hup, wup = H + 2 * pad - eff + 1, W + 2 * pad - eff + 1
     if stride > 1 or (hup, wup) != (Ho, Wo):
         up = torch.zeros(B, hup, wup, cout, dtype=dy.dtype, device=dy.device)
         up[:, ::stride, ::stride][:, :Ho, :Wo] = dy
         dy = up
-    return conv2d_nhwc(dy, w, 1, dilation, eff - 1 - pad, add=add, dgrad_of=True)
+    return conv2d_nhwc(dy, w, 1, dilation, eff - 1 - pad, add=add, dgrad_of=True, out=out)
 
 
 import os as _os
@@ -659,6 +661,32 @@ def bn_dual_backward(x, xdot, dy, dyt, gamma, beta, saved: BnSaved, act: str, ou
                                             L.current_stream_ptr()), "ppn_bn_dual_bwd_streams")
         dg_tan = dg_tan.view(nstreams, c)
     return dx, dxdot, dgamma + dg_tan, dbeta
+
+
+def bn_dual_backward_summed(x, xdot, dysum_dyt, gamma, beta, saved: BnSaved, act: str, nstreams: int,
+                            out_both: Optional[torch.Tensor] = None):
+    """bn_dual_backward for `nstreams` streams when only the SUM over the streams of the adjoint at x is needed (it is: the
+    tail adds the streams' adjoints).  The ordinary backward is linear in dy, so the caller passes the primal adjoints
+    ALREADY SUMMED: dysum_dyt = [sum_i dy_i | dyt_0 .. dyt_{n-1}] (1 + nstreams tensors of x's shape stacked along dim 0).
+    Returns (dx_sum [x's shape] = BNbwd(sum dy) + sum_i dual_i, dxdot [nstreams stacked], dgamma f32[C], dbeta f32[C]).
+    One ordinary backward over 1 + n streams, one dual reduce / finalize, n accumulating dual applies (stream order)."""
+    lib = L.load()
+    c, B = x.shape[-1], x.shape[0]
+    _stacked(x, dysum_dyt, 1 + nstreams, "dysum_dyt")
+    _stacked(x, xdot, nstreams, "xdot")
+    both, dgb, dbb = bn_train_backward(x, dysum_dyt, gamma, beta, saved, act=act, out=out_both, nstreams=1 + nstreams)
+    dx, dxdot = both[:B], both[B:]
+    key = (c, str(x.device), torch.cuda.current_stream(x.device).cuda_stream, nstreams)
+    ws = _dual_ws.get(key)
+    if ws is None:
+        ws = _dual_ws[key] = torch.empty(nstreams * lib.ppn_bn_dual_workspace_bytes(c), dtype=torch.uint8, device=x.device)
+    dg_tan = torch.empty(nstreams * c, dtype=torch.float32, device=x.device)
+    d = _bwd_desc(x, dysum_dyt[B:], gamma, beta, saved, act, dx)
+    d.workspace = ws.data_ptr()
+    L.check(lib.ppn_bn_dual_bwd_streams_sum(C.byref(d), xdot.data_ptr(), dg_tan.data_ptr(), nstreams,
+                                            L.current_stream_ptr()), "ppn_bn_dual_bwd_streams_sum")
+    dgb, dbb = dgb.view(1 + nstreams, c), dbb.view(1 + nstreams, c)
+    return dx, dxdot, dgb[0] + dg_tan.view(nstreams, c).sum(0), dbb[0]
 
 
 def nchw_to_nhwc(src: torch.Tensor, dtype: torch.dtype, channels_used=None) -> torch.Tensor:

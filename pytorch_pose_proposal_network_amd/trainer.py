@@ -491,13 +491,15 @@ class PPNTrainer:
             spec = self._tail_tangents(c, [(gw[i] / gn_h[i]).contiguous() for i in act], act)
         vs, u2, TH2, TA3, TC2, TH3, tz_groups = spec
 
-        def ssum(t):                                                              # sum over the stacked streams
-            return t if n == 1 else t.view(n, B, *t.shape[1:]).sum(0)
-
         # ---- head space per stream: gradient and Hessian-vector product of loss i through the sigmoid.  The unary
         # losses only touch the first 6K channels: their streams share 128-channel conv3 launches.
-        HB = torch.empty(2 * n * B, *TH3.shape[1:], dtype=self.tdt, device=self.device)     # [primal adj | tangent adj] at h3
-        H3bar, TH3bar = HB[:n * B], HB[n * B:]
+        # The PRIMAL adjoint chain is a single stream: everything between the loss and h1 that the primal adjoints pass
+        # through is linear in them (convolutions, the ordinary BN backward) and the tail only needs their sum over the
+        # streams, so they are summed where they are born (zsum: the weight gradient needs it anyway) and travel as ONE
+        # batch-B tensor beside the n tangent adjoints: (1 + n) B rows per convolution instead of 2 n B.
+        HB = torch.empty((1 + n) * B, *TH3.shape[1:], dtype=self.tdt, device=self.device)   # [sum of primal adj | tangent adj] at h3
+        H3sum, TH3bar = HB[:B], HB[B:]
+        first_group = True
         for js, used, w3u, th3, t_z in tz_groups:                                 # t_z: logit tangents [m*B, used, H, W]
             m = len(js)
             if used == Ch and self.tdt in (torch.float32, torch.bfloat16):
@@ -526,36 +528,34 @@ class PPNTrainer:
                 Gd["conv3.weight"][:used] += dw3[:used]
             self._tail_side(wg3, c["h3"], zsum, th3, tzb)
             Gd["conv3.bias"][:used] += zbias
-            H3bar[js[0] * B:(js[-1] + 1) * B] = T.conv_dgrad(zb, w3p, (Ho, Wo))
+            T.conv_dgrad(zsum, w3p, (Ho, Wo), add=None if first_group else H3sum, out=H3sum)
+            first_group = False
             TH3bar[js[0] * B:(js[-1] + 1) * B] = T.conv_dgrad(tzb, w3p, (Ho, Wo))
         # ---- reverse pass over the dual tail --------------------------------------------------------------------------
-        # Every BN adjoint covers all streams in one set of launches (the stream is a grid dimension; the two ordinary
-        # backward passes -- of the primal and of the tangent adjoint -- are 2n streams of one call): 9 launches per BN
-        # layer where the stream-by-stream form took 12 per stream.
-        both = torch.empty(2 * n * B, *TC2.shape[1:], dtype=self.tdt, device=self.device)   # [primal adj | tangent adj]
-        C2bar, TC2bar, dg, db = T.bn_dual_backward(c["c2"], TC2, None, None, P["bn2.weight"], P["bn2.bias"], c["s3"], "lrelu",
-                                                   nstreams=n, dy_dyt=HB, out_both=both)
-        Gd["bn2.weight"] += dg.sum(0)
-        Gd["bn2.bias"] += db.sum(0)
-        c2sum = ssum(C2bar)
+        # Every BN adjoint covers all streams in one set of launches (the stream is a grid dimension; the ordinary backward
+        # of the summed primal adjoint and of the n tangent adjoints are 1 + n streams of one call; the n dual terms
+        # accumulate into the one primal result): 8 + n launches per BN layer where the stream-by-stream form took 12 n.
+        both = torch.empty((1 + n) * B, *TC2.shape[1:], dtype=self.tdt, device=self.device)   # [sum of primal adj | tangent adj]
+        c2sum, TC2bar, dg, db = T.bn_dual_backward_summed(c["c2"], TC2, HB, P["bn2.weight"], P["bn2.bias"], c["s3"], "lrelu",
+                                                          n, out_both=both)
+        Gd["bn2.weight"] += dg
+        Gd["bn2.bias"] += db
         Gd["conv2.bias"] += c2sum.float().sum((0, 1, 2))
         def wg2(c2sum=c2sum, TC2bar=TC2bar):
             T.conv_wgrad(c["a3"], c2sum, 3, 1, 1, 1, out=Gd["conv2.weight"], accumulate=True)
             T.conv_wgrad(TA3, TC2bar, 3, 1, 1, 1, out=Gd["conv2.weight"], accumulate=True)
         self._tail_side(wg2, c["a3"], c2sum, TA3, TC2bar)
         both = T.conv_dgrad(both, P["conv2.weight"], (Ho, Wo), 1, 1, 1)
-        A3bar, TA3bar = both[:n * B], both[n * B:]
-        a3sum = ssum(A3bar)
+        a3sum, TA3bar = both[:B], both[B:]
         def wg12(a3sum=a3sum, TA3bar=TA3bar):
             T.conv_wgrad(c["h2"], a3sum, 1, out=Gd["conv1x1_2.weight"], accumulate=True)
             T.conv_wgrad(TH2, TA3bar, 1, out=Gd["conv1x1_2.weight"], accumulate=True)
         self._tail_side(wg12, c["h2"], a3sum, TH2, TA3bar)
-        both = T.conv_dgrad(both, P["conv1x1_2.weight"], (Ho, Wo))                # [H2bar | TH2bar]
-        X_bar, U_bar, dg, db = T.bn_dual_backward(c["a2"], u2, None, None, P["bn0_2.weight"], P["bn0_2.bias"], c["s2"],
-                                                  "lrelu", nstreams=n, dy_dyt=both)
-        Gd["bn0_2.weight"] += dg.sum(0)
-        Gd["bn0_2.bias"] += db.sum(0)
-        a2sum = ssum(X_bar)
+        both = T.conv_dgrad(both, P["conv1x1_2.weight"], (Ho, Wo))                # [sum of H2bar | TH2bar]
+        a2sum, U_bar, dg, db = T.bn_dual_backward_summed(c["a2"], u2, both, P["bn0_2.weight"], P["bn0_2.bias"], c["s2"],
+                                                         "lrelu", n)
+        Gd["bn0_2.weight"] += dg
+        Gd["bn0_2.bias"] += db
         self._tail_side(lambda: T.conv_wgrad(c["h1"], a2sum, 3, 1, 1, 1, out=Gd["conv1.weight"], accumulate=True),
                         c["h1"], a2sum)
         # adjoint at h1: through W (primal) and through u_i = conv(h1, v_i) per stream; every convolution adds the sum so

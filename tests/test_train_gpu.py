@@ -363,3 +363,25 @@ def test_bn_streams_equal_the_stream_by_stream_calls(dtype):
             assert torch.equal(ref[0], m[0][sl[j]]) and torch.equal(ref[1], m[1][sl[j]])
             assert torch.equal(ref[2], m[2][j]) and torch.equal(ref[3], m[3][j])
     torch.cuda.synchronize()
+
+
+def test_bn_dual_backward_summed_equals_the_sum_of_the_streams():
+    """bn_dual_backward_summed (the primal adjoints arrive already summed, the dual terms accumulate into the one result):
+    in f32 the adjoint at x equals the sum over the streams of bn_dual_backward's per-stream results to rounding (the
+    ordinary backward is linear in dy), the tangent adjoints are bitwise the per-stream ones, dgamma / dbeta the sums."""
+    from pytorch_pose_proposal_network_amd import train as T
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(12)
+    n, B, H, C = 5, 2, 10, 64
+    x = torch.randn(B, H, H, C, generator=g).to(dev)
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).to(dev), (torch.randn(C, generator=g) * 0.2).to(dev)
+    _, saved = T.bn_train_forward(x, gamma, beta, act="lrelu")
+    xdot, dy, dyt = [torch.randn(n * B, H, H, C, generator=g).to(dev) for _ in range(3)]
+    ref = T.bn_dual_backward(x, xdot, dy, dyt, gamma, beta, saved, "lrelu", nstreams=n)
+    dysum = dy.view(n, B, H, H, C).sum(0)
+    dx, dxdot, dgam, dbet = T.bn_dual_backward_summed(x, xdot, torch.cat([dysum, dyt]), gamma, beta, saved, "lrelu", n)
+    torch.cuda.synchronize()
+    want = ref[0].view(n, B, H, H, C).double().sum(0)
+    assert float((dx.double() - want).abs().max()) <= 2e-5 * float(want.abs().max())
+    assert torch.equal(dxdot, ref[1])
+    assert torch.allclose(dgam, ref[2].sum(0), rtol=1e-4, atol=1e-4) and torch.allclose(dbet, ref[3].sum(0), rtol=1e-4, atol=1e-4)
