@@ -541,6 +541,20 @@ int ppn_head_grad(int32_t dtype, const float* head, const float* grad_head, int3
 int ppn_add_relu(int32_t dtype, const void* z, const void* r, int64_t n, void* out, void* stream);
 int ppn_relu_mask(int32_t dtype, const void* out, const void* dout, const void* add, int64_t n, void* dz, void* stream);
 
+/* Data movement of the stride-2 input gradients and of the 7x7 layer's weight-gradient input in ONE pass each (torch did a
+ * fill + a strided copy_, or four strided copies; main.py:677-683 leaves all of it to autograd / cuDNN):
+ * ppn_upsample_zero:     dst [B][dst_h][dst_w][C] = src [B][src_h][src_w][C] at the pixels (y, x) = stride * (i, j), 0 elsewhere
+ *                        (a pixel = a multiple of 16 bytes);
+ * ppn_interleave_parity: dx [B][h][w][C] from the four parity sub-convolutions o_{py,px} [B][Ho+1][Wo+1][C] (Ho = (h+2-3)/2+1)
+ *                        of a stride-2 3x3 input gradient: dx[y][x] = o_{y&1,x&1}[(y + (y&1)) / 2][(x + (x&1)) / 2];
+ * ppn_image_to_nhwc:     f32 NCHW [B][3][h][w] -> NHWC [B][h][w][channels_pad] of dtype (channels_pad 4 or 8, channels 3.. zero). */
+int ppn_upsample_zero(int32_t dtype, const void* src, int32_t batch, int32_t src_h, int32_t src_w, int32_t channels,
+                      int32_t stride, int32_t dst_h, int32_t dst_w, void* dst, void* stream);
+int ppn_interleave_parity(int32_t dtype, const void* o00, const void* o01, const void* o10, const void* o11, int32_t batch,
+                          int32_t h, int32_t w, int32_t channels, void* dx, void* stream);
+int ppn_image_to_nhwc(int32_t dtype, const float* src, int32_t batch, int32_t h, int32_t w, int32_t channels_pad, void* dst,
+                      void* stream);
+
 /*
  * A15: one torch.optim.Adam step (main.py:278-279: betas (0.9, 0.999), eps 1e-8, weight_decay 0, no amsgrad)
  * over a flat f32 buffer -- the whole model is one launch.  `step` is the 1-based step count.

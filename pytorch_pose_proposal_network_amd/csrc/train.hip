@@ -699,6 +699,65 @@ __global__ void __launch_bounds__(kThreads) relu_mask_kernel(const T* __restrict
     }
 }
 
+// ---- stride-2 input gradients without torch's strided copies ----------------------------------------------------------
+// dst[b][y][x][:] = src[b][y/s][x/s][:] where y, x are multiples of s inside src, 0 elsewhere: the zero-upsampled dy of the
+// transposed-convolution identity (train.conv_dgrad) and the even-pixel scatter of a 1x1 stride-2 projection's input
+// gradient, written in ONE pass (torch: a fill + a strided copy_, 16 + 26 us for a 150 MB tensor).  16-byte items.
+__global__ void __launch_bounds__(kThreads) upsample_zero_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int B,
+                                                                 int Hs, int Ws, int Hd, int Wd, int c16, int s) {
+    const long long n = (long long)B * Hd * Wd * c16;
+    const long long stride = (long long)gridDim.x * kThreads;
+    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
+        const int c = (int)(i % c16);
+        long long p = i / c16;
+        const int x = (int)(p % Wd); p /= Wd;
+        const int y = (int)(p % Hd);
+        const int b = (int)(p / Hd);
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (y % s == 0 && x % s == 0 && y / s < Hs && x / s < Ws)
+            v = src[(((size_t)b * Hs + y / s) * Ws + x / s) * c16 + c];
+        dst[i] = v;
+    }
+}
+// dx[b][y][x][:] = o_{y&1, x&1}[b][(y + (y&1)) >> 1][(x + (x&1)) >> 1][:]: the four parity sub-convolutions of a stride-2
+// 3x3 input gradient (train._dgrad_stride2) interleaved in one pass instead of four strided copies.
+__global__ void __launch_bounds__(kThreads) interleave_parity_kernel(const uint4* __restrict__ o00, const uint4* __restrict__ o01,
+                                                                     const uint4* __restrict__ o10, const uint4* __restrict__ o11,
+                                                                     uint4* __restrict__ dx, int B, int H, int W, int Ho1,
+                                                                     int Wo1, int c16) {
+    const long long n = (long long)B * H * W * c16;
+    const long long stride = (long long)gridDim.x * kThreads;
+    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
+        const int c = (int)(i % c16);
+        long long p = i / c16;
+        const int x = (int)(p % W); p /= W;
+        const int y = (int)(p % H);
+        const int b = (int)(p / H);
+        const int py = y & 1, px = x & 1;
+        const uint4* o = py ? (px ? o11 : o10) : (px ? o01 : o00);
+        dx[i] = o[(((size_t)b * Ho1 + ((y + py) >> 1)) * Wo1 + ((x + px) >> 1)) * c16 + c];
+    }
+}
+// f32 NCHW image [B][3][H][W] -> NHWC [B][H][W][cpad] (cpad 4 or 8, channels 3.. zero): the copy of the input the 7x7
+// layer's weight gradient reads (torch: zeros + a strided permute-copy).
+template <typename T, int CP>
+__global__ void __launch_bounds__(kThreads) image_to_nhwc_kernel(const float* __restrict__ src, T* __restrict__ dst, int B,
+                                                                 long long HW) {
+    const long long n = (long long)B * HW;
+    const long long stride = (long long)gridDim.x * kThreads;
+    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
+        const long long b = i / HW, p = i % HW;
+        const float* s0 = src + (size_t)b * 3 * HW + p;
+        T v[CP];
+#pragma unroll
+        for (int c = 0; c < CP; ++c) v[c] = (T)0.f;
+        v[0] = (T)s0[0]; v[1] = (T)s0[HW]; v[2] = (T)s0[2 * HW];
+        T* d = dst + (size_t)i * CP;
+#pragma unroll
+        for (int c = 0; c < CP; ++c) d[c] = v[c];
+    }
+}
+
 int make_slab(int C, long long P, Slab* s) {
     if (C < 8 || C > 2048 || (C & (C - 1)) != 0)
         return ppn::fail(PPN_E_UNSUPPORTED, "BatchNorm channels must be a power of two in [8, 2048], got %d", C);
@@ -1010,6 +1069,61 @@ int ppn_relu_mask(int32_t dtype, const void* out, const void* dout, const void* 
         relu_mask_kernel<float><<<(int)blocks, kThreads, 0, st>>>((const float*)out, (const float*)dout, (const float*)add, n / 8, (float*)dz);
     else if (dtype == PPN_BF16)
         relu_mask_kernel<__bf16><<<(int)blocks, kThreads, 0, st>>>((const __bf16*)out, (const __bf16*)dout, (const __bf16*)add, n / 8, (__bf16*)dz);
+    else return ppn::fail(PPN_E_INVALID, "bad dtype %d", dtype);
+    PPN_LAUNCH_CHECK();
+    return PPN_OK;
+}
+
+int ppn_upsample_zero(int32_t dtype, const void* src, int32_t batch, int32_t src_h, int32_t src_w, int32_t channels,
+                      int32_t stride, int32_t dst_h, int32_t dst_w, void* dst, void* stream) {
+    if (!src || !dst || batch < 1 || src_h < 1 || src_w < 1 || dst_h < 1 || dst_w < 1 || stride < 1 || channels < 1)
+        return ppn::fail(PPN_E_INVALID, "ppn_upsample_zero: bad arguments");
+    if (dtype != PPN_F32 && dtype != PPN_BF16 && dtype != PPN_F16) return ppn::fail(PPN_E_INVALID, "bad dtype %d", dtype);
+    const int es = dtype == PPN_F32 ? 4 : 2;
+    if ((channels * es) % 16) return ppn::fail(PPN_E_UNSUPPORTED, "ppn_upsample_zero: a pixel must be a multiple of 16 bytes");
+    if ((long long)(src_h - 1) * stride >= dst_h || (long long)(src_w - 1) * stride >= dst_w)
+        return ppn::fail(PPN_E_INVALID, "ppn_upsample_zero: the source does not fit the destination");
+    const int c16 = channels * es / 16;
+    const long long n = (long long)batch * dst_h * dst_w * c16;
+    long long blocks = (n + kThreads - 1) / kThreads;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    upsample_zero_kernel<<<(int)blocks, kThreads, 0, (hipStream_t)stream>>>((const uint4*)src, (uint4*)dst, batch, src_h, src_w,
+                                                                            dst_h, dst_w, c16, stride);
+    PPN_LAUNCH_CHECK();
+    return PPN_OK;
+}
+
+int ppn_interleave_parity(int32_t dtype, const void* o00, const void* o01, const void* o10, const void* o11, int32_t batch,
+                          int32_t h, int32_t w, int32_t channels, void* dx, void* stream) {
+    if (!o00 || !o01 || !o10 || !o11 || !dx || batch < 1 || h < 1 || w < 1 || channels < 1)
+        return ppn::fail(PPN_E_INVALID, "ppn_interleave_parity: bad arguments");
+    if (dtype != PPN_F32 && dtype != PPN_BF16 && dtype != PPN_F16) return ppn::fail(PPN_E_INVALID, "bad dtype %d", dtype);
+    const int es = dtype == PPN_F32 ? 4 : 2;
+    if ((channels * es) % 16) return ppn::fail(PPN_E_UNSUPPORTED, "ppn_interleave_parity: a pixel must be a multiple of 16 bytes");
+    const int c16 = channels * es / 16;
+    const int Ho1 = (h + 2 - 3) / 2 + 2, Wo1 = (w + 2 - 3) / 2 + 2;       // the sub-convolutions' output: (Ho + 1) x (Wo + 1)
+    const long long n = (long long)batch * h * w * c16;
+    long long blocks = (n + kThreads - 1) / kThreads;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    interleave_parity_kernel<<<(int)blocks, kThreads, 0, (hipStream_t)stream>>>((const uint4*)o00, (const uint4*)o01,
+                                                                                (const uint4*)o10, (const uint4*)o11, (uint4*)dx,
+                                                                                batch, h, w, Ho1, Wo1, c16);
+    PPN_LAUNCH_CHECK();
+    return PPN_OK;
+}
+
+int ppn_image_to_nhwc(int32_t dtype, const float* src, int32_t batch, int32_t h, int32_t w, int32_t channels_pad, void* dst,
+                      void* stream) {
+    if (!src || !dst || batch < 1 || h < 1 || w < 1 || (channels_pad != 4 && channels_pad != 8))
+        return ppn::fail(PPN_E_INVALID, "ppn_image_to_nhwc: bad arguments (channels_pad 4 or 8)");
+    const long long HW = (long long)h * w, n = (long long)batch * HW;
+    long long blocks = (n + kThreads - 1) / kThreads;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == PPN_F32 && channels_pad == 8) image_to_nhwc_kernel<float, 8><<<(int)blocks, kThreads, 0, st>>>(src, (float*)dst, batch, HW);
+    else if (dtype == PPN_F32) image_to_nhwc_kernel<float, 4><<<(int)blocks, kThreads, 0, st>>>(src, (float*)dst, batch, HW);
+    else if (dtype == PPN_BF16 && channels_pad == 8) image_to_nhwc_kernel<__bf16, 8><<<(int)blocks, kThreads, 0, st>>>(src, (__bf16*)dst, batch, HW);
+    else if (dtype == PPN_BF16) image_to_nhwc_kernel<__bf16, 4><<<(int)blocks, kThreads, 0, st>>>(src, (__bf16*)dst, batch, HW);
     else return ppn::fail(PPN_E_INVALID, "bad dtype %d", dtype);
     PPN_LAUNCH_CHECK();
     return PPN_OK;

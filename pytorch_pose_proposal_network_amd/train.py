@@ -443,10 +443,24 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, in_hw, stride: int = 1, dilati
         return _dgrad_stride2(dy, w, H, W, add)
     hup, wup = H + 2 * pad - eff + 1, W + 2 * pad - eff + 1
     if stride > 1 or (hup, wup) != (Ho, Wo):
-        up = torch.zeros(B, hup, wup, cout, dtype=dy.dtype, device=dy.device)
-        up[:, ::stride, ::stride][:, :Ho, :Wo] = dy
-        dy = up
+        dy = upsample_zero(dy, stride, hup, wup)
     return conv2d_nhwc(dy, w, 1, dilation, eff - 1 - pad, add=add, dgrad_of=True, out=out)
+
+
+def upsample_zero(src: torch.Tensor, stride: int, dst_h: int, dst_w: int) -> torch.Tensor:
+    """dst [B, dst_h, dst_w, C]: src [B, h, w, C] at the pixels stride * (i, j), zero elsewhere -- one write pass
+    (ppn_upsample_zero) where torch took a fill and a strided copy_."""
+    B, h, w, ch = src.shape
+    if not src.is_contiguous():
+        src = src.contiguous()
+    if (ch * src.element_size()) % 16 != 0:
+        dst = torch.zeros(B, dst_h, dst_w, ch, dtype=src.dtype, device=src.device)
+        dst[:, ::stride, ::stride][:, :h, :w] = src
+        return dst
+    dst = torch.empty(B, dst_h, dst_w, ch, dtype=src.dtype, device=src.device)
+    L.check(L.load().ppn_upsample_zero(_dtype_code(src), src.data_ptr(), B, h, w, ch, stride, dst_h, dst_w, dst.data_ptr(),
+                                       L.current_stream_ptr()), "ppn_upsample_zero")
+    return dst
 
 
 import os as _os
@@ -468,8 +482,9 @@ def _dgrad_stride2(dy: torch.Tensor, w: torch.Tensor, H: int, W: int, add: Optio
     if k == 1:
         wt = w[:, :, 0, 0].t().contiguous().view(cin, cout, 1, 1)
         o = conv2d_nhwc(dy, wt, 1, 1, 0)
-        dx = torch.zeros(B, H, W, cin, dtype=dy.dtype, device=dev)
-        dx[:, ::2, ::2] = o[:, :(H + 1) // 2, :(W + 1) // 2]
+        if o.shape[1] != (H + 1) // 2 or o.shape[2] != (W + 1) // 2:
+            o = o[:, :(H + 1) // 2, :(W + 1) // 2].contiguous()
+        dx = upsample_zero(o, 2, H, W)
     else:
         idx = _S2_IDX.get(dev)
         if idx is None:
@@ -479,13 +494,18 @@ def _dgrad_stride2(dy: torch.Tensor, w: torch.Tensor, H: int, W: int, add: Optio
         wall = w4[:, :, idx[:, :, None, None], idx[None, None, :, :]]                # [cin, cout, py, uy, px, ux]
         wall = wall.permute(2, 4, 0, 1, 3, 5).contiguous()                           # [py, px, cin, cout, uy, ux]
         dx = torch.empty(B, H, W, cin, dtype=dy.dtype, device=dev)
-        for py in (0, 1):
-            for px in (0, 1):
-                ny, nx = (H - py + 1) // 2, (W - px + 1) // 2
-                if ny <= 0 or nx <= 0:
-                    continue
-                o = conv2d_nhwc(dy, wall[py, px], 1, 1, 1)                           # [B, Ho + 1, Wo + 1, cin]
-                dx[:, py::2, px::2] = o[:, py:py + ny, px:px + nx]
+        o = [[conv2d_nhwc(dy, wall[py, px], 1, 1, 1) for px in (0, 1)] for py in (0, 1)]   # each [B, Ho + 1, Wo + 1, cin]
+        if (cin * dy.element_size()) % 16 == 0:
+            # dx[:, py::2, px::2] = o[py][px][:, py:py + ny, px:px + nx] for the four parities, in one pass
+            L.check(L.load().ppn_interleave_parity(_dtype_code(dy), o[0][0].data_ptr(), o[0][1].data_ptr(), o[1][0].data_ptr(),
+                                                   o[1][1].data_ptr(), B, H, W, cin, dx.data_ptr(), L.current_stream_ptr()),
+                    "ppn_interleave_parity")
+        else:
+            for py in (0, 1):
+                for px in (0, 1):
+                    ny, nx = (H - py + 1) // 2, (W - px + 1) // 2
+                    if ny > 0 and nx > 0:
+                        dx[:, py::2, px::2] = o[py][px][:, py:py + ny, px:px + nx]
     if add is not None:
         dx += add
     return dx

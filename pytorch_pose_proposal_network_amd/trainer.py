@@ -274,8 +274,9 @@ class PPNTrainer:
         tape = []
         # the 7x7 stem reads NCHW f32; its weight gradient reads an NHWC copy padded with zero channels: 4 channels for
         # the dedicated bf16 kernel (csrc/stem_wgrad.hip: two MFMAs per filter row), 8 for the generic f32 kernel
-        xin8 = torch.zeros(B, H, W, 4 if self.tdt == torch.bfloat16 else 8, dtype=self.tdt, device=self.device)
-        xin8[..., :3] = x.permute(0, 2, 3, 1)
+        xin8 = torch.empty(B, H, W, 4 if self.tdt == torch.bfloat16 else 8, dtype=self.tdt, device=self.device)
+        L.check(lib.ppn_image_to_nhwc(self.compute_dtype, x.data_ptr(), B, H, W, xin8.shape[-1], xin8.data_ptr(),
+                                      L.current_stream_ptr()), "ppn_image_to_nhwc")
         cur = None
         for u in self.units:
             if u.kind == "cbr":

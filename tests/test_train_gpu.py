@@ -385,3 +385,39 @@ def test_bn_dual_backward_summed_equals_the_sum_of_the_streams():
     assert float((dx.double() - want).abs().max()) <= 2e-5 * float(want.abs().max())
     assert torch.equal(dxdot, ref[1])
     assert torch.allclose(dgam, ref[2].sum(0), rtol=1e-4, atol=1e-4) and torch.allclose(dbet, ref[3].sum(0), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_data_movement_kernels_equal_the_torch_copies(dtype):
+    """ppn_upsample_zero, ppn_interleave_parity, ppn_image_to_nhwc against the torch indexing they replace (bitwise: pure
+    data movement), odd sizes included."""
+    import ctypes as C
+    from pytorch_pose_proposal_network_amd import train as T, lib as L
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(3)
+    code = L.PPN_F32 if dtype == torch.float32 else L.PPN_BF16
+    for (B, h, w, ch, s, dh, dw) in [(2, 5, 7, 16, 2, 10, 13), (1, 6, 6, 64, 2, 11, 11), (3, 4, 9, 32, 1, 6, 10), (2, 7, 5, 8, 3, 19, 15)]:
+        src = torch.randn(B, h, w, ch, generator=g).to(dtype).to(dev)
+        want = torch.zeros(B, dh, dw, ch, dtype=dtype, device=dev)
+        want[:, ::s, ::s][:, :h, :w] = src
+        assert torch.equal(T.upsample_zero(src, s, dh, dw), want), (B, h, w, ch, s)
+    for (B, H, W, ch) in [(2, 9, 12, 16), (1, 8, 8, 32), (2, 7, 7, 8)]:
+        Ho1, Wo1 = (H + 2 - 3) // 2 + 2, (W + 2 - 3) // 2 + 2
+        o = [[torch.randn(B, Ho1, Wo1, ch, generator=g).to(dtype).to(dev) for _ in range(2)] for _ in range(2)]
+        want = torch.empty(B, H, W, ch, dtype=dtype, device=dev)
+        for py in (0, 1):
+            for px in (0, 1):
+                ny, nx = (H - py + 1) // 2, (W - px + 1) // 2
+                want[:, py::2, px::2] = o[py][px][:, py:py + ny, px:px + nx]
+        dx = torch.empty_like(want)
+        L.check(L.load().ppn_interleave_parity(code, o[0][0].data_ptr(), o[0][1].data_ptr(), o[1][0].data_ptr(), o[1][1].data_ptr(),
+                                               B, H, W, ch, dx.data_ptr(), L.current_stream_ptr()), "interleave")
+        assert torch.equal(dx, want), (B, H, W, ch)
+    x = torch.randn(3, 3, 11, 14, generator=g).to(dev)
+    for cp in (4, 8):
+        want = torch.zeros(3, 11, 14, cp, dtype=dtype, device=dev)
+        want[..., :3] = x.permute(0, 2, 3, 1)
+        got = torch.empty_like(want)
+        L.check(L.load().ppn_image_to_nhwc(code, x.data_ptr(), 3, 11, 14, cp, got.data_ptr(), L.current_stream_ptr()), "image")
+        assert torch.equal(got, want)
+    torch.cuda.synchronize()
