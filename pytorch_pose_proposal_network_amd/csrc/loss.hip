@@ -398,8 +398,9 @@ __global__ void __launch_bounds__(256) limb_kernel(LossArgs a) {
 
 __global__ void __launch_bounds__(256) finalize_kernel(LossArgs a) {
     // fixed-order, double-precision combination of the per-workgroup partial sums; mean over the batch.  One workgroup per
-    // loss (one workgroup walking the five in turn was five dependent rounds of loads: 54 us of an otherwise idle GPU on
-    // the training step's main stream); the order inside a loss is unchanged.
+    // loss.  (The ~50 us rocprofv3 shows for this launch in the training step are not its own work -- one workgroup walking
+    // the five losses in turn, or eight loads in flight per thread, measure the same: it starts behind the limb kernel's
+    // 280 MB of output still draining from the L2s.)
     __shared__ double s_acc[256];
     const int t = threadIdx.x, q = blockIdx.x;
     double v = 0.0;
