@@ -19,6 +19,7 @@ struct EncArgs {
     const int* visible;      // [B][pmax]: bit k-1 set = keypoint k labeled
     const int* count;        // [B]
     float *delta, *weight, *weight_ij, *tx_half, *ty_half, *tx, *ty, *tw, *th, *te;
+    unsigned char* limb_c;   // optional: te and weight_ij in two bits per element (bit 0: te = 1, bit 1: weight_ij = 1)
 };
 
 __device__ __forceinline__ bool labeled(const EncArgs& a, const float* P, int vis, int k) {
@@ -105,6 +106,10 @@ __global__ void __launch_bounds__(256) encode_limb_kernel(EncArgs a) {
             a.weight_ij[o] = v[0];
             a.te[o] = 0.f;
         }
+        if (a.limb_c) {                    // delta is 0 / 1 here, so weight_ij is 1 or 0.0005: one bit
+#pragma unroll
+            for (int j = 0; j < V; ++j) a.limb_c[o + j] = v[j] == 1.f ? 2 : 0;
+        }
     }
 }
 
@@ -127,16 +132,18 @@ __global__ void __launch_bounds__(64) encode_te_kernel(EncArgs a) {
         const int jy = (int)(ty_ / gridH) - iy + a.sH / 2, jx = (int)(tx_ / gridW) - ix + a.sW / 2;
         if (iy < 0 || ix < 0 || iy >= a.H || ix >= a.W) continue;
         if (jy < 0 || jx < 0 || jy >= a.sH || jx >= a.sW) continue;
-        a.te[((((size_t)b * a.E + ei) * a.sH + jy) * a.sW + jx) * HW + iy * a.W + ix] = 1.f;
+        const size_t o = ((((size_t)b * a.E + ei) * a.sH + jy) * a.sW + jx) * HW + iy * a.W + ix;
+        a.te[o] = 1.f;
+        if (a.limb_c) a.limb_c[o] |= 1;    // this (image, edge) thread owns every byte it touches
     }
 }
 
 }  // namespace
 
-extern "C" int ppn_encode_targets(const ppn_loss_cfg* cfg, const int32_t* edges, const float* people,
-                                  const int32_t* visible, const int32_t* count, int32_t batch, int32_t pmax,
-                                  float* delta, float* weight, float* weight_ij, float* tx_half, float* ty_half,
-                                  float* tx, float* ty, float* tw, float* th, float* te, void* stream) {
+static int encode_targets_impl(const ppn_loss_cfg* cfg, const int32_t* edges, const float* people,
+                               const int32_t* visible, const int32_t* count, int32_t batch, int32_t pmax,
+                               float* delta, float* weight, float* weight_ij, float* tx_half, float* ty_half,
+                               float* tx, float* ty, float* tw, float* th, float* te, unsigned char* limb_c, void* stream) {
     if (!cfg || !edges || !people || !visible || !count || !delta || !weight || !weight_ij || !tx_half || !ty_half ||
         !tx || !ty || !tw || !th || !te)
         return ppn::fail(PPN_E_INVALID, "ppn_encode_targets: NULL pointer");
@@ -154,6 +161,7 @@ extern "C" int ppn_encode_targets(const ppn_loss_cfg* cfg, const int32_t* edges,
     a.people = people; a.visible = visible; a.count = count;
     a.delta = delta; a.weight = weight; a.weight_ij = weight_ij; a.tx_half = tx_half; a.ty_half = ty_half;
     a.tx = tx; a.ty = ty; a.tw = tw; a.th = th; a.te = te;
+    a.limb_c = limb_c;
     hipStream_t st = (hipStream_t)stream;
     encode_unary_kernel<<<batch, 256, 0, st>>>(a);
     PPN_LAUNCH_CHECK();
@@ -170,4 +178,22 @@ extern "C" int ppn_encode_targets(const ppn_loss_cfg* cfg, const int32_t* edges,
         PPN_LAUNCH_CHECK();
     }
     return PPN_OK;
+}
+
+extern "C" int ppn_encode_targets(const ppn_loss_cfg* cfg, const int32_t* edges, const float* people,
+                                  const int32_t* visible, const int32_t* count, int32_t batch, int32_t pmax,
+                                  float* delta, float* weight, float* weight_ij, float* tx_half, float* ty_half,
+                                  float* tx, float* ty, float* tw, float* th, float* te, void* stream) {
+    return encode_targets_impl(cfg, edges, people, visible, count, batch, pmax, delta, weight, weight_ij, tx_half, ty_half,
+                               tx, ty, tw, th, te, nullptr, stream);
+}
+
+extern "C" int ppn_encode_targets_c(const ppn_loss_cfg* cfg, const int32_t* edges, const float* people,
+                                    const int32_t* visible, const int32_t* count, int32_t batch, int32_t pmax,
+                                    float* delta, float* weight, float* weight_ij, float* tx_half, float* ty_half,
+                                    float* tx, float* ty, float* tw, float* th, float* te, uint8_t* limb_compact,
+                                    void* stream) {
+    if (!limb_compact) return ppn::fail(PPN_E_INVALID, "ppn_encode_targets_c: limb_compact is NULL");
+    return encode_targets_impl(cfg, edges, people, visible, count, batch, pmax, delta, weight, weight_ij, tx_half, ty_half,
+                               tx, ty, tw, th, te, limb_compact, stream);
 }

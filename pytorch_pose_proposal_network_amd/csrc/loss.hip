@@ -22,6 +22,8 @@ constexpr float kEps = 1e-6f;     // config.py:82 EPSILON
 struct LossArgs {
     const float* head;
     const float *delta, *weight, *weight_ij, *tx_half, *ty_half, *tx, *ty, *tw, *th, *te;
+    const unsigned char* limb_c;   // optional (the two fused training kernels): te | weight_ij in two bits per element, as
+                                   // ppn_encode_targets_c writes them -- 1 byte read instead of 8 per limb element
     float* grad;          // may be NULL
     float* partial;       // workspace: [nblk_unary][4] then [nblk_limb]
     float* losses;        // [5]
@@ -36,6 +38,19 @@ struct LossArgs {
 // coefficient i: by value (host call) or from device memory (a uniform scalar load)
 __device__ __forceinline__ float coef(const LossArgs& a, int i) {
     return a.coeff_dev ? a.coeff_dev[i] / a.coeff_div : a.coeff[i];
+}
+
+// limb targets of element li: from the compact byte when there is one (weight_ij = 1 or 0.0005, te = 0 or 1: exactly the
+// f32 values encode_limb_kernel / encode_te_kernel write), else from the f32 tensors
+__device__ __forceinline__ void limb_targets(const LossArgs& a, size_t li, float* wj, float* te) {
+    if (a.limb_c) {
+        const unsigned v = a.limb_c[li];
+        *wj = (v & 2u) ? 1.f : 0.0005f;
+        *te = (v & 1u) ? 1.f : 0.f;
+    } else {
+        *wj = a.weight_ij[li];
+        *te = a.te[li];
+    }
 }
 
 __device__ __forceinline__ float block_sum(float v, float* s_red) {
@@ -267,9 +282,11 @@ __global__ void __launch_bounds__(256) limb_dual_nhwc_kernel(LossArgs a, const f
         if (c >= C6 && c < a.C && p < HW) {
             const size_t ho = ((size_t)b * a.C + c) * HW + p;
             const size_t li = (size_t)b * per_img + (size_t)(c - C6) * HW + p;
-            const float s = a.head[ho], tz = tzp[ho], wj = a.weight_ij[li];
+            const float s = a.head[ho], tz = tzp[ho];
+            float wj, te;
+            limb_targets(a, li, &wj, &te);
             const float sdot = s * (1.f - s) * tz;
-            sigmoid_dual_adjoint(s, tz, g2 * wj * sdot, g2 * wj * (s - a.te[li]), &zv, &tv);
+            sigmoid_dual_adjoint(s, tz, g2 * wj * sdot, g2 * wj * (s - te), &zv, &tv);
         }
         z_t[px][cl] = zv;
         tz_t[px][cl] = tv;
@@ -322,7 +339,9 @@ __global__ void __launch_bounds__(256) limb_loss_dz_kernel(LossArgs a, const flo
             float g;
             if (c >= C6) {
                 const size_t li = (size_t)b * per_img + (size_t)(c - C6) * HW + p;
-                const float wj = a.weight_ij[li], d = s - a.te[li];
+                float wj, te;
+                limb_targets(a, li, &wj, &te);
+                const float d = s - te;
                 lsum += wj * d * d;
                 g = g2 * wj * d;
             } else {
@@ -426,6 +445,7 @@ int fill(LossArgs& a, const ppn_loss_cfg* cfg, int batch) {
     a.B = batch; a.K = cfg->K; a.E = cfg->E; a.S = cfg->sH * cfg->sW; a.H = cfg->H; a.W = cfg->W;
     a.C = 6 * cfg->K + cfg->E * a.S; a.inW = cfg->inW; a.inH = cfg->inH;
     a.Cg = a.C;
+    a.limb_c = nullptr;
     const long long n_unary = (long long)batch * a.K * a.H * a.W;
     a.nblk_unary = (int)((n_unary + 255) / 256);
     a.nblk_limb = 2048;
@@ -557,13 +577,14 @@ extern "C" int ppn_loss_dual(const ppn_loss_cfg* cfg, const float* head, const f
 // [B][H*W][cpad] (cpad a multiple of 64 >= 6K + E*S; channels outside the limb range are zero) and
 // zsum f32 [B][ceil(H*W/64)][cpad], the per-block pixel sums of zbar.  Same arithmetic as ppn_loss_dual followed by
 // ppn_nchw_to_nhwc, without the two f32 head-layout intermediates.
-extern "C" int ppn_loss_limb_dual_nhwc(const ppn_loss_cfg* cfg, const float* head, const float* tz, int32_t batch,
-                                       const float* weight_ij, const float* te, float c4, int32_t dtype, int32_t cpad,
-                                       void* zb, void* tzb, float* zsum, void* stream) {
+static int limb_dual_nhwc_impl(const ppn_loss_cfg* cfg, const float* head, const float* tz, int32_t batch,
+                              const float* weight_ij, const float* te, const unsigned char* limb_c, float c4, int32_t dtype,
+                              int32_t cpad, void* zb, void* tzb, float* zsum, void* stream) {
     LossArgs a;
     if (int rc = fill(a, cfg, batch)) return rc;
-    if (!head || !tz || !weight_ij || !te || !zb || !tzb || !zsum)
+    if (!head || !tz || (!limb_c && (!weight_ij || !te)) || !zb || !tzb || !zsum)
         return ppn::fail(PPN_E_INVALID, "ppn_loss_limb_dual_nhwc: NULL pointer");
+    a.limb_c = limb_c;
     if (cpad % 64 || cpad < a.C) return ppn::fail(PPN_E_INVALID, "ppn_loss_limb_dual_nhwc: cpad %d for %d channels", cpad, a.C);
     if (dtype != PPN_F32 && dtype != PPN_BF16) return ppn::fail(PPN_E_INVALID, "ppn_loss_limb_dual_nhwc: bad dtype %d", dtype);
     a.head = head; a.weight_ij = weight_ij; a.te = te;
@@ -579,6 +600,18 @@ extern "C" int ppn_loss_limb_dual_nhwc(const ppn_loss_cfg* cfg, const float* hea
     return PPN_OK;
 }
 
+extern "C" int ppn_loss_limb_dual_nhwc(const ppn_loss_cfg* cfg, const float* head, const float* tz, int32_t batch,
+                                       const float* weight_ij, const float* te, float c4, int32_t dtype, int32_t cpad,
+                                       void* zb, void* tzb, float* zsum, void* stream) {
+    return limb_dual_nhwc_impl(cfg, head, tz, batch, weight_ij, te, nullptr, c4, dtype, cpad, zb, tzb, zsum, stream);
+}
+extern "C" int ppn_loss_limb_dual_nhwc_c(const ppn_loss_cfg* cfg, const float* head, const float* tz, int32_t batch,
+                                         const uint8_t* limb_compact, float c4, int32_t dtype, int32_t cpad, void* zb,
+                                         void* tzb, float* zsum, void* stream) {
+    if (!limb_compact) return ppn::fail(PPN_E_INVALID, "ppn_loss_limb_dual_nhwc_c: limb_compact is NULL");
+    return limb_dual_nhwc_impl(cfg, head, tz, batch, nullptr, nullptr, limb_compact, c4, dtype, cpad, zb, tzb, zsum, stream);
+}
+
 // ppn_loss_fwd_bwd_dev + ppn_head_grad in one: the five losses, and instead of d loss / d head in the head layout the
 // gradient w.r.t. conv3's LOGITS in the layout its backward reads -- dz `dtype` [B][H*W][cpad] NHWC (channels >= C zero)
 // -- plus dbsum f32 [B][ceil(H*W/64)][cpad], per-block cell sums of dz (summed over the first two axes: d loss / d
@@ -590,17 +623,18 @@ extern "C" size_t ppn_loss_dz_workspace_bytes(const ppn_loss_cfg* cfg, int32_t b
     return ((size_t)a.nblk_unary * 4 + nb) * sizeof(float);
 }
 
-extern "C" int ppn_loss_fwd_bwd_dz(const ppn_loss_cfg* cfg, const float* head, int32_t batch, const float* delta,
-                                   const float* weight, const float* weight_ij, const float* tx_half,
-                                   const float* ty_half, const float* tx, const float* ty, const float* tw,
-                                   const float* th, const float* te, const float* coeff_dev, float coeff_div,
-                                   float* losses, float* grad_unary, int32_t dtype, int32_t cpad, void* dz,
-                                   float* dbsum, void* workspace, void* stream) {
+static int loss_fwd_bwd_dz_impl(const ppn_loss_cfg* cfg, const float* head, int32_t batch, const float* delta,
+                               const float* weight, const float* weight_ij, const float* tx_half,
+                               const float* ty_half, const float* tx, const float* ty, const float* tw,
+                               const float* th, const float* te, const unsigned char* limb_c, const float* coeff_dev,
+                               float coeff_div, float* losses, float* grad_unary, int32_t dtype, int32_t cpad, void* dz,
+                               float* dbsum, void* workspace, void* stream) {
     LossArgs a;
     if (int rc = fill(a, cfg, batch)) return rc;
-    if (!head || !delta || !weight || !weight_ij || !tx_half || !ty_half || !tx || !ty || !tw || !th || !te ||
+    if (!head || !delta || !weight || (!limb_c && (!weight_ij || !te)) || !tx_half || !ty_half || !tx || !ty || !tw || !th ||
         !coeff_dev || !losses || !grad_unary || !dz || !dbsum || !workspace)
         return ppn::fail(PPN_E_INVALID, "ppn_loss_fwd_bwd_dz: NULL pointer");
+    a.limb_c = limb_c;
     if (!(coeff_div != 0.f)) return ppn::fail(PPN_E_INVALID, "ppn_loss_fwd_bwd_dz: coeff_div");
     if (cpad % 64 || cpad < a.C) return ppn::fail(PPN_E_INVALID, "ppn_loss_fwd_bwd_dz: cpad %d for %d channels", cpad, a.C);
     if (dtype != PPN_F32 && dtype != PPN_BF16) return ppn::fail(PPN_E_INVALID, "ppn_loss_fwd_bwd_dz: bad dtype %d", dtype);
@@ -623,4 +657,26 @@ extern "C" int ppn_loss_fwd_bwd_dz(const ppn_loss_cfg* cfg, const float* head, i
     hipLaunchKernelGGL(finalize_kernel, dim3(5), dim3(256), 0, st, a);
     PPN_LAUNCH_CHECK();
     return PPN_OK;
+}
+
+extern "C" int ppn_loss_fwd_bwd_dz(const ppn_loss_cfg* cfg, const float* head, int32_t batch, const float* delta,
+                                   const float* weight, const float* weight_ij, const float* tx_half,
+                                   const float* ty_half, const float* tx, const float* ty, const float* tw,
+                                   const float* th, const float* te, const float* coeff_dev, float coeff_div,
+                                   float* losses, float* grad_unary, int32_t dtype, int32_t cpad, void* dz,
+                                   float* dbsum, void* workspace, void* stream) {
+    return loss_fwd_bwd_dz_impl(cfg, head, batch, delta, weight, weight_ij, tx_half, ty_half, tx, ty, tw, th, te, nullptr,
+                                coeff_dev, coeff_div, losses, grad_unary, dtype, cpad, dz, dbsum, workspace, stream);
+}
+
+extern "C" int ppn_loss_fwd_bwd_dz_c(const ppn_loss_cfg* cfg, const float* head, int32_t batch, const float* delta,
+                                     const float* weight, const uint8_t* limb_compact, const float* tx_half,
+                                     const float* ty_half, const float* tx, const float* ty, const float* tw,
+                                     const float* th, const float* coeff_dev, float coeff_div, float* losses,
+                                     float* grad_unary, int32_t dtype, int32_t cpad, void* dz, float* dbsum,
+                                     void* workspace, void* stream) {
+    if (!limb_compact) return ppn::fail(PPN_E_INVALID, "ppn_loss_fwd_bwd_dz_c: limb_compact is NULL");
+    return loss_fwd_bwd_dz_impl(cfg, head, batch, delta, weight, nullptr, tx_half, ty_half, tx, ty, tw, th, nullptr,
+                                limb_compact, coeff_dev, coeff_div, losses, grad_unary, dtype, cpad, dz, dbsum, workspace,
+                                stream);
 }

@@ -102,6 +102,9 @@ _SIGNATURES = {
     "ppn_loss_fwd_bwd_dz": (C.c_int, [C.POINTER(LossCfg), C.c_void_p, C.c_int32] + [C.c_void_p] * 10 +
                             [C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                              C.c_void_p, C.c_void_p]),
+    "ppn_loss_fwd_bwd_dz_c": (C.c_int, [C.POINTER(LossCfg), C.c_void_p, C.c_int32] + [C.c_void_p] * 9 +
+                              [C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                               C.c_void_p, C.c_void_p]),
     "ppn_loss_fwd_bwd_dev": (C.c_int, [C.POINTER(LossCfg), C.c_void_p, C.c_int32] + [C.c_void_p] * 10 +
                              [C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ppn_conv_tiling": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32),
@@ -175,6 +178,8 @@ _SIGNATURES.update({
                            [C.POINTER(C.c_float), C.c_void_p, C.c_void_p, C.c_void_p]),
     "ppn_encode_targets": (C.c_int, [C.POINTER(LossCfg), C.POINTER(C.c_int32), C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_int32, C.c_int32] + [C.c_void_p] * 11),
+    "ppn_encode_targets_c": (C.c_int, [C.POINTER(LossCfg), C.POINTER(C.c_int32), C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_int32, C.c_int32] + [C.c_void_p] * 12),
     "ppn_nchw_to_nhwc": (C.c_int, [C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                    C.c_void_p, C.c_void_p]),
     "ppn_bn_act_mask": (C.c_int, [C.POINTER(BnBwdDesc), C.c_void_p]),
@@ -187,6 +192,9 @@ _SIGNATURES.update({
     "ppn_loss_limb_dual_nhwc": (C.c_int, [C.POINTER(LossCfg), C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                           C.c_float, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_void_p]),
+    "ppn_loss_limb_dual_nhwc_c": (C.c_int, [C.POINTER(LossCfg), C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                            C.c_float, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_void_p]),
     "ppn_loss_dual": (C.c_int, [C.POINTER(LossCfg), C.c_void_p, C.c_void_p, C.c_int32] + [C.c_void_p] * 10 +
                       [C.POINTER(C.c_float), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ppn_conv_wgrad_workspace_bytes": (C.c_size_t, [C.POINTER(WgradDesc)]),

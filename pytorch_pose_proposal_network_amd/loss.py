@@ -12,12 +12,15 @@ it yields the per-loss gradient that seeds the GradNorm partial backward passes 
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, Optional, Sequence
 
 import torch
 
 from . import config as cfg
 from . import lib as L
+
+_LIMB_COMPACT = os.environ.get("PPN_LOSS_COMPACT_TARGETS", "1") != "0"      # A/B switch: read te / weight_ij as f32
 
 TARGET_KEYS = ("delta", "weight", "weight_ij", "tx_half", "ty_half", "tx", "ty", "tw", "th", "te")
 
@@ -175,14 +178,35 @@ class PPNLoss:
         gu = torch.empty(B, 6 * c.K, c.H, c.W, dtype=torch.float32, device=dev)
         dz = torch.empty(B, c.H, c.W, cpad, dtype=dtype, device=dev)
         dbsum = torch.empty(B * ((c.H * c.W + 63) // 64), cpad, dtype=torch.float32, device=dev)
+        lc = self._limb_compact(targets, B)
+        dcode = L.PPN_F32 if dtype == torch.float32 else L.PPN_BF16
+        if lc is not None:
+            L.check(lib.ppn_loss_fwd_bwd_dz_c(C.byref(c), feature_map.data_ptr(), B, t["delta"].data_ptr(),
+                                              t["weight"].data_ptr(), lc.data_ptr(), t["tx_half"].data_ptr(),
+                                              t["ty_half"].data_ptr(), t["tx"].data_ptr(), t["ty"].data_ptr(),
+                                              t["tw"].data_ptr(), t["th"].data_ptr(), cw.data_ptr(), float(div),
+                                              losses.data_ptr(), gu.data_ptr(), dcode, cpad, dz.data_ptr(),
+                                              dbsum.data_ptr(), ws.data_ptr(), L.current_stream_ptr()),
+                    "ppn_loss_fwd_bwd_dz_c")
+            return losses, dz, dbsum
         L.check(lib.ppn_loss_fwd_bwd_dz(C.byref(c), feature_map.data_ptr(), B, t["delta"].data_ptr(),
                                         t["weight"].data_ptr(), t["weight_ij"].data_ptr(), t["tx_half"].data_ptr(),
                                         t["ty_half"].data_ptr(), t["tx"].data_ptr(), t["ty"].data_ptr(),
                                         t["tw"].data_ptr(), t["th"].data_ptr(), t["te"].data_ptr(), cw.data_ptr(),
-                                        float(div), losses.data_ptr(), gu.data_ptr(),
-                                        L.PPN_F32 if dtype == torch.float32 else L.PPN_BF16, cpad, dz.data_ptr(),
+                                        float(div), losses.data_ptr(), gu.data_ptr(), dcode, cpad, dz.data_ptr(),
                                         dbsum.data_ptr(), ws.data_ptr(), L.current_stream_ptr()), "ppn_loss_fwd_bwd_dz")
         return losses, dz, dbsum
+
+    def _limb_compact(self, targets, B):
+        """targets["limb_c"] (u8, te's shape; targets.encode_targets writes it) when present and enabled, else None."""
+        lc = targets.get("limb_c") if _LIMB_COMPACT else None
+        if lc is None:
+            return None
+        c = self._cfg
+        if (lc.dtype != torch.uint8 or tuple(lc.shape) != (B, c.E, c.sH, c.sW, c.H, c.W) or not lc.is_cuda or
+                not lc.is_contiguous()):
+            raise ValueError("targets['limb_c'] must be a contiguous uint8 CUDA tensor of te's shape")
+        return lc
 
     def limb_dual_nhwc(self, feature_map: torch.Tensor, tz: torch.Tensor, targets: Dict[str, torch.Tensor], c4: float,
                        dtype: torch.dtype):
@@ -205,10 +229,16 @@ class PPNLoss:
         tzb = torch.empty_like(zb)
         npy = (c.H * c.W + 63) // 64
         zsum = torch.empty(B * npy, cpad, dtype=torch.float32, device=dev)
+        lc = self._limb_compact(targets, B)
+        dcode = L.PPN_F32 if dtype == torch.float32 else L.PPN_BF16
+        if lc is not None:
+            L.check(lib.ppn_loss_limb_dual_nhwc_c(C.byref(c), feature_map.data_ptr(), tz.data_ptr(), B, lc.data_ptr(),
+                                                  float(c4), dcode, cpad, zb.data_ptr(), tzb.data_ptr(), zsum.data_ptr(),
+                                                  L.current_stream_ptr()), "ppn_loss_limb_dual_nhwc_c")
+            return zb, tzb, zsum
         L.check(lib.ppn_loss_limb_dual_nhwc(C.byref(c), feature_map.data_ptr(), tz.data_ptr(), B, wij.data_ptr(),
-                                            te.data_ptr(), float(c4), L.PPN_F32 if dtype == torch.float32 else L.PPN_BF16,
-                                            cpad, zb.data_ptr(), tzb.data_ptr(), zsum.data_ptr(),
-                                            L.current_stream_ptr()), "ppn_loss_limb_dual_nhwc")
+                                            te.data_ptr(), float(c4), dcode, cpad, zb.data_ptr(), tzb.data_ptr(),
+                                            zsum.data_ptr(), L.current_stream_ptr()), "ppn_loss_limb_dual_nhwc")
         return zb, tzb, zsum
 
     def forward(self, image, feature_map, delta, weight, weight_ij, tx_half, ty_half, tx, ty, tw, th, te):

@@ -61,9 +61,14 @@ def encode_targets(packed, insize=(384, 384), outsize=(24, 24), local_grid=(21, 
         shape = (B, E, c.sH, c.sW, c.H, c.W) if k in ("weight_ij", "te") else (B, K, c.H, c.W)
         t[k] = torch.empty(shape, dtype=torch.float32, device=dev)
     edges = (C.c_int32 * (2 * E))(*[int(v) for e in cfg.EDGES for v in e])
-    L.check(lib.ppn_encode_targets(C.byref(c), edges, pd.data_ptr(), vd.data_ptr(), cd.data_ptr(), B, pmax,
-                                   *[t[k].data_ptr() for k in TARGET_KEYS], L.current_stream_ptr()),
-            "ppn_encode_targets")
+    # "limb_c" (u8, same shape as te): te | weight_ij in two bits per element -- what the two limb-streaming kernels of a
+    # training iteration read instead of the two f32 tensors (PPNLoss.forward_backward_dz / limb_dual_nhwc use it when the
+    # targets carry it; bit-identical results, 1.1 GB less HBM traffic per kernel at batch 32)
+    limb_c = torch.empty((B, E, c.sH, c.sW, c.H, c.W), dtype=torch.uint8, device=dev)
+    L.check(lib.ppn_encode_targets_c(C.byref(c), edges, pd.data_ptr(), vd.data_ptr(), cd.data_ptr(), B, pmax,
+                                     *[t[k].data_ptr() for k in TARGET_KEYS], limb_c.data_ptr(), L.current_stream_ptr()),
+            "ppn_encode_targets_c")
+    t["limb_c"] = limb_c
     return t
 
 

@@ -146,3 +146,34 @@ def test_loss_fwd_bwd_dz_equals_loss_then_head_grad(dtype):
     db1 = dbsum.sum(0)
     assert float(db1[Cn:].abs().max()) == 0.0
     assert float((db1[:Cn] - db0).abs().max()) <= 1e-5 * float(db0.abs().max())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_compact_limb_targets_give_the_f32_targets_results(dtype):
+    """targets["limb_c"] (te | weight_ij in two bits per element, written by ppn_encode_targets_c) decodes to exactly the f32
+    tensors the encoder writes beside it, and the two kernels that read it -- ppn_loss_fwd_bwd_dz_c, ppn_loss_limb_dual_nhwc_c
+    -- return bitwise what their f32-target forms return."""
+    from pytorch_pose_proposal_network_amd import targets, loss as LS, config as cfg
+    dev = torch.device("cuda")
+    size, B = 192, 3
+    tg = targets.synthetic_targets(77, B, (size, size), device=dev)
+    lc = tg["limb_c"]
+    assert lc.dtype == torch.uint8 and lc.shape == tg["te"].shape
+    assert torch.equal((lc & 1).float(), tg["te"]) and int(tg["te"].sum()) > 0
+    assert torch.equal(torch.where((lc & 2) != 0, 1.0, 0.0005).float(), tg["weight_ij"]) and float(tg["weight_ij"].max()) == 1.0
+    crit = LS.PPNLoss(insize=(size, size), outsize=(size // 16, size // 16))
+    g = torch.Generator().manual_seed(5)
+    Ch = 6 * cfg.K + cfg.E * 21 * 21
+    head = torch.sigmoid(torch.randn(B, Ch, size // 16, size // 16, generator=g)).to(dev)
+    tz = torch.randn(B, Ch, size // 16, size // 16, generator=g).to(dev)
+    w = torch.tensor([1.1, 0.9, 1.0, 0.8, 1.2], device=dev)
+    plain = {k: v for k, v in tg.items() if k != "limb_c"}
+    a = crit.forward_backward_dz(head, tg, (w, 5.0), dtype)
+    b = crit.forward_backward_dz(head, plain, (w, 5.0), dtype)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    a = crit.limb_dual_nhwc(head, tz, tg, 0.37, dtype)
+    b = crit.limb_dual_nhwc(head, tz, plain, 0.37, dtype)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    torch.cuda.synchronize()
