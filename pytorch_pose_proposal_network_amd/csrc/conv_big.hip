@@ -929,6 +929,10 @@ bool big_tile_for(int cout, long long m, BigTile* out, int ksteps, bool shared_g
     // 144 x 256 (round 4; 8 waves side by side along the channels, each 32 channels x all 144 pixels): 18 432 pixels x 512
     // channels (the five 24 x 24 layers of DRN-D-22 at batch 32) = exactly 256 workgroups = one full round, where 192 x 256
     // leaves 64 of the 256 CUs idle; and 73 728 x 256 (layer5) = 512 = two rounds.  Same K order: results unchanged.
+    // (round 4, measured and removed: a 288 x 256 tile -- 4 x 2 wave grid, 36 MFMA tiles per wave, 256 VGPRs with 6 spilled --
+    // makes layer5's 73 728 x 256 launches ONE round of 256 workgroups: 93.9 -> 77.8 us alone, but -1.7 % images/s with three
+    // lanes (a 136 KB workgroup holds its CU alone for 78 us; two 80 KB workgroups of 192 x 128 share one), nothing on a
+    // single lane or the training step, and on the 512-channel layers its two rounds take what 192 x 256's three do.)
     static const Cand cands[] = {{256, 256, 1.27}, {192, 256, 1.10}, {144, 256, kEff144}, {128, 256, 0.92}, {256, 128, 0.90},
                                  {192, 128, 0.95}, {128, 128, 0.87}, {256, 64, 0.60},  {128, 64, 0.55}};
     int bc_max = cout >= 256 ? 256 : (cout >= 128 ? 128 : 64);
