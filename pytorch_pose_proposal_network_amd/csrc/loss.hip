@@ -53,6 +53,37 @@ __device__ __forceinline__ void limb_targets(const LossArgs& a, size_t li, float
     }
 }
 
+// ... of V consecutive elements starting at li (V = 4: li % 4 == 0 and 16-byte aligned f32 tensors, checked on the host)
+template <int V>
+__device__ __forceinline__ void limb_targets_v(const LossArgs& a, size_t li, float (&wj)[V], float (&te)[V]) {
+    if constexpr (V == 4) {
+        if (a.limb_c) {
+            const unsigned v = *reinterpret_cast<const unsigned*>(a.limb_c + li);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned bte = (v >> (8 * j)) & 0xffu;
+                wj[j] = (bte & 2u) ? 1.f : 0.0005f;
+                te[j] = (bte & 1u) ? 1.f : 0.f;
+            }
+        } else {
+            const float4 w4 = *reinterpret_cast<const float4*>(a.weight_ij + li), t4 = *reinterpret_cast<const float4*>(a.te + li);
+            wj[0] = w4.x; wj[1] = w4.y; wj[2] = w4.z; wj[3] = w4.w;
+            te[0] = t4.x; te[1] = t4.y; te[2] = t4.z; te[3] = t4.w;
+        }
+    } else {
+        limb_targets(a, li, &wj[0], &te[0]);
+    }
+}
+template <int V>
+__device__ __forceinline__ void load_v(const float* p, float (&o)[V]) {
+    if constexpr (V == 4) {
+        const float4 q = *reinterpret_cast<const float4*>(p);
+        o[0] = q.x; o[1] = q.y; o[2] = q.z; o[3] = q.w;
+    } else {
+        o[0] = p[0];
+    }
+}
+
 __device__ __forceinline__ float block_sum(float v, float* s_red) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
 #pragma unroll
@@ -264,32 +295,46 @@ __global__ void __launch_bounds__(256) limb_dual_kernel(DualArgs p) {
 // and input gradients read) through a 64 x 64 LDS transpose instead of to two f32 head-layout tensors that a second pass
 // re-reads (2 x 541 MB written + read at batch 32) -- and the per-channel sums of zbar over a block's pixels (conv3.bias'
 // second-order gradient) leave as partials [B][ceil(HW/64)][Cpad].  Channels outside [6K, C) are zero.
-template <typename T>
+// V = 4 (H*W a multiple of 4, 16-byte aligned tensors): a thread takes FOUR consecutive cells of a channel -- 16-byte loads of
+// the head / tangent planes (1 KB per wave and load instead of 256 B) and one 4-byte load of the compact targets.
+template <typename T, int V>
 __global__ void __launch_bounds__(256) limb_dual_nhwc_kernel(LossArgs a, const float* __restrict__ tzp, float c4, int Cpad,
                                                              T* __restrict__ zb, T* __restrict__ tzb,
                                                              float* __restrict__ zsum) {
     __shared__ float tz_t[64][65], z_t[64][65];
     const int HW = a.H * a.W, C6 = 6 * a.K;
     const int c0 = blockIdx.x * 64, p0 = blockIdx.y * 64, b = blockIdx.z;
-    const int t = threadIdx.x, px = t & 63;
+    const int t = threadIdx.x;
     const size_t per_img = (size_t)a.E * a.S * HW;
     const float g2 = 2.f * c4 / (float)a.B;
+    constexpr int PXT = 64 / V;                                          // threads along the cells
+    constexpr int CPP = 256 / PXT;                                       // channels per pass
+    const int px0 = (t % PXT) * V;
 #pragma unroll 4
-    for (int i = 0; i < 16; ++i) {
-        const int cl = (t >> 6) + 4 * i;
-        const int c = c0 + cl, p = p0 + px;
-        float zv = 0.f, tv = 0.f;
-        if (c >= C6 && c < a.C && p < HW) {
+    for (int i = 0; i < 64 / CPP; ++i) {
+        const int cl = t / PXT + CPP * i;
+        const int c = c0 + cl, p = p0 + px0;
+        float zv[V], tv[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) zv[j] = tv[j] = 0.f;
+        if (c >= C6 && c < a.C && p < HW) {                              // (V = 4: HW % 4 == 0, so the four cells exist together)
             const size_t ho = ((size_t)b * a.C + c) * HW + p;
             const size_t li = (size_t)b * per_img + (size_t)(c - C6) * HW + p;
-            const float s = a.head[ho], tz = tzp[ho];
-            float wj, te;
-            limb_targets(a, li, &wj, &te);
-            const float sdot = s * (1.f - s) * tz;
-            sigmoid_dual_adjoint(s, tz, g2 * wj * sdot, g2 * wj * (s - te), &zv, &tv);
+            float s[V], tz[V], wj[V], te[V];
+            load_v<V>(a.head + ho, s);
+            load_v<V>(tzp + ho, tz);
+            limb_targets_v<V>(a, li, wj, te);
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                const float sdot = s[j] * (1.f - s[j]) * tz[j];
+                sigmoid_dual_adjoint(s[j], tz[j], g2 * wj[j] * sdot, g2 * wj[j] * (s[j] - te[j]), &zv[j], &tv[j]);
+            }
         }
-        z_t[px][cl] = zv;
-        tz_t[px][cl] = tv;
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            z_t[px0 + j][cl] = zv[j];
+            tz_t[px0 + j][cl] = tv[j];
+        }
     }
     __syncthreads();
 #pragma unroll
@@ -318,38 +363,47 @@ __global__ void __launch_bounds__(256) limb_dual_nhwc_kernel(LossArgs a, const f
 // dz = g * s(1 - s) goes straight to the NHWC `T` tensor conv3's weight / input gradients read (the unary channels' g
 // comes from the compact tensor unary_kernel wrote), and the per-channel sums of dz over the block's cells leave as
 // partials (conv3.bias' gradient).  Saves the f32 head-layout gradient (17 MB per image written, then re-read twice).
-template <typename T>
+template <typename T, int V>
 __global__ void __launch_bounds__(256) limb_loss_dz_kernel(LossArgs a, const float* __restrict__ ugrad, int Cpad,
                                                            T* __restrict__ dz, float* __restrict__ dbsum) {
     __shared__ float d_t[64][65];
     __shared__ float s_red[4];
     const int HW = a.H * a.W, C6 = 6 * a.K;
     const int c0 = blockIdx.x * 64, p0 = blockIdx.y * 64, b = blockIdx.z;
-    const int t = threadIdx.x, px = t & 63;
+    const int t = threadIdx.x;
     const size_t per_img = (size_t)a.E * a.S * HW;
     const float g2 = 2.f * coef(a, 4) / (float)a.B;
     float lsum = 0.f;
+    constexpr int PXT = 64 / V, CPP = 256 / PXT;                          // as limb_dual_nhwc_kernel
+    const int px0 = (t % PXT) * V;
 #pragma unroll 4
-    for (int i = 0; i < 16; ++i) {
-        const int cl = (t >> 6) + 4 * i;
-        const int c = c0 + cl, p = p0 + px;
-        float v = 0.f;
+    for (int i = 0; i < 64 / CPP; ++i) {
+        const int cl = t / PXT + CPP * i;
+        const int c = c0 + cl, p = p0 + px0;
+        float v[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) v[j] = 0.f;
         if (c < a.C && p < HW) {
-            const float s = a.head[((size_t)b * a.C + c) * HW + p];
-            float g;
+            float s[V], g[V];
+            load_v<V>(a.head + ((size_t)b * a.C + c) * HW + p, s);
             if (c >= C6) {
                 const size_t li = (size_t)b * per_img + (size_t)(c - C6) * HW + p;
-                float wj, te;
-                limb_targets(a, li, &wj, &te);
-                const float d = s - te;
-                lsum += wj * d * d;
-                g = g2 * wj * d;
+                float wj[V], te[V];
+                limb_targets_v<V>(a, li, wj, te);
+#pragma unroll
+                for (int j = 0; j < V; ++j) {
+                    const float d = s[j] - te[j];
+                    lsum += wj[j] * d * d;
+                    g[j] = g2 * wj[j] * d;
+                }
             } else {
-                g = ugrad[((size_t)b * C6 + c) * HW + p];
+                load_v<V>(ugrad + ((size_t)b * C6 + c) * HW + p, g);
             }
-            v = g * (s * (1.f - s));
+#pragma unroll
+            for (int j = 0; j < V; ++j) v[j] = g[j] * (s[j] * (1.f - s[j]));
         }
-        d_t[px][cl] = v;
+#pragma unroll
+        for (int j = 0; j < V; ++j) d_t[px0 + j][cl] = v[j];
     }
     const float bs = block_sum(lsum, s_red);                             // (contains the barrier the tile needs)
     if (t == 0)
@@ -594,8 +648,16 @@ static int limb_dual_nhwc_impl(const ppn_loss_cfg* cfg, const float* head, const
     const int HW = a.H * a.W;
     const dim3 grid(cpad / 64, (HW + 63) / 64, batch);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (dtype == PPN_F32) hipLaunchKernelGGL(limb_dual_nhwc_kernel<float>, grid, dim3(256), 0, st, a, tz, c4, cpad, (float*)zb, (float*)tzb, zsum);
-    else hipLaunchKernelGGL(limb_dual_nhwc_kernel<__bf16>, grid, dim3(256), 0, st, a, tz, c4, cpad, (__bf16*)zb, (__bf16*)tzb, zsum);
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    const bool vec = HW % 4 == 0 && al16(head) && al16(tz) &&
+                     (limb_c ? (reinterpret_cast<uintptr_t>(limb_c) & 3) == 0 : (al16(weight_ij) && al16(te)));
+    if (dtype == PPN_F32) {
+        if (vec) hipLaunchKernelGGL((limb_dual_nhwc_kernel<float, 4>), grid, dim3(256), 0, st, a, tz, c4, cpad, (float*)zb, (float*)tzb, zsum);
+        else hipLaunchKernelGGL((limb_dual_nhwc_kernel<float, 1>), grid, dim3(256), 0, st, a, tz, c4, cpad, (float*)zb, (float*)tzb, zsum);
+    } else {
+        if (vec) hipLaunchKernelGGL((limb_dual_nhwc_kernel<__bf16, 4>), grid, dim3(256), 0, st, a, tz, c4, cpad, (__bf16*)zb, (__bf16*)tzb, zsum);
+        else hipLaunchKernelGGL((limb_dual_nhwc_kernel<__bf16, 1>), grid, dim3(256), 0, st, a, tz, c4, cpad, (__bf16*)zb, (__bf16*)tzb, zsum);
+    }
     PPN_LAUNCH_CHECK();
     return PPN_OK;
 }
@@ -651,8 +713,16 @@ static int loss_fwd_bwd_dz_impl(const ppn_loss_cfg* cfg, const float* head, int3
     hipStream_t st = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(unary_kernel, dim3(a.nblk_unary), dim3(256), 0, st, a);
     PPN_LAUNCH_CHECK();
-    if (dtype == PPN_F32) hipLaunchKernelGGL(limb_loss_dz_kernel<float>, grid, dim3(256), 0, st, a, grad_unary, cpad, (float*)dz, dbsum);
-    else hipLaunchKernelGGL(limb_loss_dz_kernel<__bf16>, grid, dim3(256), 0, st, a, grad_unary, cpad, (__bf16*)dz, dbsum);
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    const bool vec = HW % 4 == 0 && al16(head) && al16(grad_unary) &&
+                     (limb_c ? (reinterpret_cast<uintptr_t>(limb_c) & 3) == 0 : (al16(weight_ij) && al16(te)));
+    if (dtype == PPN_F32) {
+        if (vec) hipLaunchKernelGGL((limb_loss_dz_kernel<float, 4>), grid, dim3(256), 0, st, a, grad_unary, cpad, (float*)dz, dbsum);
+        else hipLaunchKernelGGL((limb_loss_dz_kernel<float, 1>), grid, dim3(256), 0, st, a, grad_unary, cpad, (float*)dz, dbsum);
+    } else {
+        if (vec) hipLaunchKernelGGL((limb_loss_dz_kernel<__bf16, 4>), grid, dim3(256), 0, st, a, grad_unary, cpad, (__bf16*)dz, dbsum);
+        else hipLaunchKernelGGL((limb_loss_dz_kernel<__bf16, 1>), grid, dim3(256), 0, st, a, grad_unary, cpad, (__bf16*)dz, dbsum);
+    }
     PPN_LAUNCH_CHECK();
     hipLaunchKernelGGL(finalize_kernel, dim3(5), dim3(256), 0, st, a);
     PPN_LAUNCH_CHECK();
