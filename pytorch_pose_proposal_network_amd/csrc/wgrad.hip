@@ -476,27 +476,33 @@ __global__ void __launch_bounds__(64 * WM * WN) wgrad_kernel(WgArgs a) {
         }
 }
 
-// dw[co][ci][tap] = beta*dw + sum_s partial[s][tap][co][ci]   (fixed order; one thread per output element, the
-// loads of four splits in flight at a time -- a serial chain of nsplit*taps loads per thread was latency-bound)
+// dw[co][ci][tap] = beta*dw + sum_s partial[s][tap][co][ci]   (fixed order; one thread per FOUR consecutive output elements
+// of a tap -- 16-byte loads, 1 KB per wave and load instead of 256 B -- with the loads of four splits in flight at a time: a
+// serial chain of nsplit*taps loads per thread was latency-bound)
 __global__ void __launch_bounds__(256) wgrad_fold_kernel(const float* __restrict__ partial, int nsplit, int ntaps,
                                                          int Cout, int Cin, float beta, float* __restrict__ dw) {
-    const long long n = (long long)Cout * Cin;
+    const long long n = (long long)Cout * Cin, n4 = n / 4;              // Cin % 4 == 0 (geometry())
     const long long w = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (w >= n * ntaps) return;
-    const int t = (int)(w / n);
-    const long long o = w - (long long)t * n;
+    if (w >= n4 * ntaps) return;
+    const int t = (int)(w / n4);
+    const long long o = (w - (long long)t * n4) * 4;
     const float* p = partial + (size_t)t * n + o;
     const size_t stride = (size_t)ntaps * n;
-    float acc = 0.f;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto add = [&](const float4& v) { acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; };
     int s = 0;
     for (; s + 4 <= nsplit; s += 4) {
-        const float v0 = p[(size_t)s * stride], v1 = p[(size_t)(s + 1) * stride];
-        const float v2 = p[(size_t)(s + 2) * stride], v3 = p[(size_t)(s + 3) * stride];
-        acc = (((acc + v0) + v1) + v2) + v3;
+        const float4 v0 = *reinterpret_cast<const float4*>(p + (size_t)s * stride);
+        const float4 v1 = *reinterpret_cast<const float4*>(p + (size_t)(s + 1) * stride);
+        const float4 v2 = *reinterpret_cast<const float4*>(p + (size_t)(s + 2) * stride);
+        const float4 v3 = *reinterpret_cast<const float4*>(p + (size_t)(s + 3) * stride);
+        add(v0); add(v1); add(v2); add(v3);
     }
-    for (; s < nsplit; ++s) acc += p[(size_t)s * stride];
+    for (; s < nsplit; ++s) add(*reinterpret_cast<const float4*>(p + (size_t)s * stride));
     float* d = dw + o * ntaps + t;
-    *d = beta != 0.f ? beta * *d + acc : acc;
+    const float r[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) d[(size_t)j * ntaps] = beta != 0.f ? beta * d[(size_t)j * ntaps] + r[j] : r[j];
 }
 
 struct Geom {
@@ -582,6 +588,8 @@ int ppn_conv_wgrad(const ppn_wgrad_desc* d, void* stream) {
     Geom g;
     if (int rc = geometry(d, &g)) return rc;
     if (!d->x || !d->dy || !d->dw || !d->workspace) return ppn::fail(PPN_E_INVALID, "ppn_conv_wgrad: NULL pointer");
+    if (reinterpret_cast<uintptr_t>(d->workspace) & 15)
+        return ppn::fail(PPN_E_INVALID, "ppn_conv_wgrad: workspace must be 16-byte aligned");
     if (ppn::stem_wgrad_supported(d)) {
         if (d->workspace_bytes < ppn::stem_wgrad_workspace_bytes(d))
             return ppn::fail(PPN_E_INVALID, "ppn_conv_wgrad: workspace too small");
@@ -623,8 +631,8 @@ int ppn_conv_wgrad(const ppn_wgrad_desc* d, void* stream) {
     else rc = g.big ? launch<__bf16, 4, 2, 4, 8>(a, grid, st) : launch<__bf16, 2, 2, 4, 4>(a, grid, st);
     if (rc) return rc;
     const long long n = (long long)d->cout * d->cin * g.ntaps;
-    wgrad_fold_kernel<<<(int)((n + 255) / 256), 256, 0, st>>>(a.partial, g.nsplit, g.ntaps, d->cout, d->cin, d->beta,
-                                                              d->dw);
+    wgrad_fold_kernel<<<(int)((n / 4 + 255) / 256), 256, 0, st>>>(a.partial, g.nsplit, g.ntaps, d->cout, d->cin, d->beta,
+                                                                  d->dw);
     PPN_LAUNCH_CHECK();
     return PPN_OK;
 }
