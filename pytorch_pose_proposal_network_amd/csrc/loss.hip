@@ -228,8 +228,10 @@ __device__ __forceinline__ void unary_grad_dual(Dual resp, Dual conf, Dual x, Du
 // zbar = s_bar*sig' + sdot_bar*sig''*tz,  tzbar = sdot_bar*sig'   (sig' = s(1-s), sig'' = sig'(1-2s)); written in head layout
 __device__ __forceinline__ void sigmoid_dual_adjoint(float s, float tz, float s_bar, float sdot_bar, float* zbar,
                                                      float* tzbar) {
-    const float s1 = s * (1.f - s), s2 = s1 * (1.f - 2.f * s);
-    *zbar = s_bar * s1 + sdot_bar * s2 * tz;
+    // the contractions are written out: this is inlined into kernels of different shapes (scalar and four-cell loops) whose
+    // results the tests compare bit for bit, and the compiler's own choice of which product to fuse differs between them
+    const float s1 = s * (1.f - s), s2 = s1 * __builtin_fmaf(-2.f, s, 1.f);
+    *zbar = __builtin_fmaf(s_bar, s1, (sdot_bar * s2) * tz);
     *tzbar = sdot_bar * s1;
 }
 
