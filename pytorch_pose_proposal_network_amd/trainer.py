@@ -99,6 +99,7 @@ class PPNTrainer:
         # second-order tail: enqueue its forward-mode half before the host reads the probe norms (A/B: =0)
         self._speculate_tail = os.environ.get("PPN_TRAIN_SPECULATE_TAIL", "1") != "0"
         self._so_pin = None
+        self._w3p = {}                               # _w3_padded
         self._tail_wgrad_side = os.environ.get("PPN_TRAIN_TAIL_WGRAD_SIDE", "1") != "0"
         pri = int(os.environ.get("PPN_TRAIN_PROBE_PRIORITY", "0"))
         self._probe_stream = torch.cuda.Stream(device=self.device, priority=pri) if self._side is not None else None
@@ -113,6 +114,8 @@ class PPNTrainer:
     def __del__(self):
         try:
             T.unregister_param_storage(self._storage_key)
+            for ent in getattr(self, "_w3p", {}).values():
+                T.unregister_param_storage(ent[2])
         except Exception:
             pass
 
@@ -270,6 +273,8 @@ class PPNTrainer:
         x = x.contiguous()
         B, _, H, W = x.shape
         T.bump_param_version()        # parameters may have been edited in place since the last pass: repack once per forward
+        for used in list(self._w3p):  # the padded copies of conv3.weight follow the parameters BEFORE they are repacked
+            self._w3_padded(used)
         T.repack_all(self.device)     # ... every weight view the previous passes met, in one launch
         tape = []
         # the 7x7 stem reads NCHW f32; its weight gradient reads an NHWC copy padded with zero channels: 4 channels for
@@ -373,9 +378,7 @@ class PPNTrainer:
             L.check(lib.ppn_head_grad(self.compute_dtype, head.data_ptr(), grad_head.data_ptr(), B, Ch, Ho * Wo, used,
                                       cpad, dz.data_ptr(), dbias3.data_ptr() if keep else None, L.current_stream_ptr()),
                     "ppn_head_grad")
-        w3 = self.P["conv3.weight"]
-        w3p = torch.zeros(cpad, w3.shape[1], 1, 1, dtype=torch.float32, device=self.device)
-        w3p[:used] = w3[:used]
+        w3p = self._w3_padded(used)
         if keep:
             def wg3():
                 dw3 = T.conv_wgrad(c["h3"], dz, 1)
@@ -518,8 +521,7 @@ class PPNTrainer:
                 zb, tzb = T.nchw_to_nhwc(zbar, self.tdt), T.nchw_to_nhwc(tzbar, self.tdt)
                 zbias = zbar.sum((0, 2, 3))
             cpad = zb.shape[-1]
-            w3p = torch.zeros(cpad, w3u.shape[1], 1, 1, dtype=torch.float32, device=self.device)
-            w3p[:used] = w3u
+            w3p = self._w3_padded(used)
             zsum = zb if m == 1 else zb.view(m, B, Ho, Wo, cpad).sum(0)          # (m == 1: a 280 MB no-op reduction)
             # Weight gradients are leaves here too: on the side stream (idle during the tail) instead of ~0.9 ms of the
             # main stream; they accumulate into gradients the side stream wrote, so the order is the stream's own.
@@ -595,6 +597,22 @@ class PPNTrainer:
             th3 = TH3[js[0] * B:(js[-1] + 1) * B]                                 # the group's streams are adjacent
             tz_groups.append((js, used, w3u, th3, T.conv2d_nhwc(th3, w3u, nchw_f32=True)))
         return vs, u2, TH2, TA3, TC2, TH3, tz_groups
+
+    def _w3_padded(self, used: int) -> torch.Tensor:
+        """conv3.weight[:used] zero-padded to a multiple of 64 rows (what the input-gradient convolution of the 7605- /
+        108-channel head reads as its input width), in a PERSISTENT buffer registered with the packed-weight cache: padded and
+        packed once per parameter version instead of a zeros + copy + 33 us pack at each of its three uses per iteration.
+        forward() refreshes the existing buffers before it repacks."""
+        ent = self._w3p.get(used)
+        if ent is None:
+            w3 = self.P["conv3.weight"]
+            cpad = (used + 63) // 64 * 64
+            buf = torch.zeros(cpad, w3.shape[1], 1, 1, dtype=torch.float32, device=self.device)
+            ent = self._w3p[used] = [-1, buf, T.register_param_storage(buf)]
+        if ent[0] != T._param_version[0]:
+            ent[1][:used].copy_(self.P["conv3.weight"][:used])
+            ent[0] = T._param_version[0]
+        return ent[1]
 
     def _unit_offset(self, kind, u) -> int:
         """First element of the flat buffer that belongs to this unit (its parameters are contiguous)."""
@@ -688,8 +706,8 @@ class PPNTrainer:
     def _stacked_unary_probe_grads(self, head, targets, scratch):
         """[dL_i/dW for i < 4] (W = conv1.weight, the four unary losses): the four probe passes of probe_grad() with their
         convolutions STACKED along the batch dimension -- one conv3 / conv2 / conv1x1_2 input-gradient launch for all four
-        (they are per-image operations) -- and only the BN backward passes (per-pass batch statistics) and the four weight
-        gradients run pass by pass: 43 launches instead of 68, and three well-filled convolution launches instead of twelve
+        (they are per-image operations) -- the BN backward passes (per-pass batch statistics) take the pass as a grid dimension
+        and only the four weight gradients run pass by pass: 25 launches instead of 68, and three well-filled convolution launches instead of twelve
         at a quarter of the GPU.  Same arithmetic per element as probe_grad(): the results are bit-identical."""
         kind, _, c = self._tape[-1]
         assert kind == "head"
@@ -702,22 +720,14 @@ class PPNTrainer:
             self.criterion.unary_backward(head, targets, [1.0 if j == i else 0.0 for j in range(4)], out=scratch)
             L.check(lib.ppn_head_grad(self.compute_dtype, head.data_ptr(), scratch.data_ptr(), B, Ch, Ho * Wo, k6, cpad,
                                       dz4[i * B:(i + 1) * B].data_ptr(), None, L.current_stream_ptr()), "ppn_head_grad")
-        w3 = self.P["conv3.weight"]
-        w3p = torch.zeros(cpad, w3.shape[1], 1, 1, dtype=torch.float32, device=self.device)
-        w3p[:k6] = w3[:k6]
-        dh3 = T.conv_dgrad(dz4, w3p, (Ho, Wo))
-        dc2 = torch.empty_like(dh3)
-        for i in range(4):
-            T.bn_train_backward(c["c2"], dh3[i * B:(i + 1) * B], self.P["bn2.weight"], self.P["bn2.bias"], c["s3"],
-                                act="lrelu", out=dc2[i * B:(i + 1) * B])
+        dh3 = T.conv_dgrad(dz4, self._w3_padded(k6), (Ho, Wo))
+        # the BN backward of the four passes in one set of launches (per-pass batch statistics: the pass is a grid dimension)
+        dc2, _, _ = T.bn_train_backward(c["c2"], dh3, self.P["bn2.weight"], self.P["bn2.bias"], c["s3"], act="lrelu", nstreams=4)
         da3 = T.conv_dgrad(dc2, self.P["conv2.weight"], (Ho, Wo), 1, 1, 1)
         dh2 = T.conv_dgrad(da3, self.P["conv1x1_2.weight"], (Ho, Wo))
-        grads = []
-        for i in range(4):
-            da2, _, _ = T.bn_train_backward(c["a2"], dh2[i * B:(i + 1) * B], self.P["bn0_2.weight"],
-                                            self.P["bn0_2.bias"], c["s2"], act="lrelu")
-            grads.append(T.conv_wgrad(c["h1"], da2, 3, 1, 1, 1))
-        return grads
+        da2, _, _ = T.bn_train_backward(c["a2"], dh2, self.P["bn0_2.weight"], self.P["bn0_2.bias"], c["s2"], act="lrelu",
+                                        nstreams=4)
+        return [T.conv_wgrad(c["h1"], da2[i * B:(i + 1) * B], 3, 1, 1, 1) for i in range(4)]
 
     def _unary_probes(self, head, targets, coeff, scratch):
         """The four cheap probe passes: (gnorm[0:4] f32[4], sum_{i<4} coeff_i dL_i/dW).  Independent of backward()."""
