@@ -567,6 +567,11 @@ int ppn_upsample_zero(int32_t dtype, const void* src, int32_t batch, int32_t src
                       int32_t stride, int32_t dst_h, int32_t dst_w, void* dst, void* stream);
 int ppn_interleave_parity(int32_t dtype, const void* o00, const void* o01, const void* o10, const void* o11, int32_t batch,
                           int32_t h, int32_t w, int32_t channels, void* dx, void* stream);
+/* ppn_interleave_parity with the four sub-convolutions stacked along the channels of one tensor o [B][Ho+1][Wo+1][4 C]
+ * (parity (py, px) in channel block 2 py + px): the output of ONE convolution with the four 2 x 2 filter sets stacked along
+ * its output channels, which reads dy once instead of four times. */
+int ppn_interleave_parity_stacked(int32_t dtype, const void* o, int32_t batch, int32_t h, int32_t w, int32_t channels, void* dx,
+                                  void* stream);
 int ppn_image_to_nhwc(int32_t dtype, const float* src, int32_t batch, int32_t h, int32_t w, int32_t channels_pad, void* dst,
                       void* stream);
 

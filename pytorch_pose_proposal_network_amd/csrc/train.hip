@@ -738,6 +738,22 @@ __global__ void __launch_bounds__(kThreads) interleave_parity_kernel(const uint4
         dx[i] = o[(((size_t)b * Ho1 + ((y + py) >> 1)) * Wo1 + ((x + px) >> 1)) * c16 + c];
     }
 }
+// ... with the four sub-convolutions' outputs stacked along the channels of ONE tensor o [B][Ho1][Wo1][4 * c16] (parity
+// (py, px) in channel block 2 py + px): they then come from a single launch that reads dy once.
+__global__ void __launch_bounds__(kThreads) interleave_parity_stacked_kernel(const uint4* __restrict__ o, uint4* __restrict__ dx,
+                                                                             int B, int H, int W, int Ho1, int Wo1, int c16) {
+    const long long n = (long long)B * H * W * c16;
+    const long long stride = (long long)gridDim.x * kThreads;
+    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
+        const int c = (int)(i % c16);
+        long long p = i / c16;
+        const int x = (int)(p % W); p /= W;
+        const int y = (int)(p % H);
+        const int b = (int)(p / H);
+        const int py = y & 1, px = x & 1;
+        dx[i] = o[((((size_t)b * Ho1 + ((y + py) >> 1)) * Wo1 + ((x + px) >> 1)) * 4 + (2 * py + px)) * c16 + c];
+    }
+}
 // f32 NCHW image [B][3][H][W] -> NHWC [B][H][W][cpad] (cpad 4 or 8, channels 3.. zero): the copy of the input the 7x7
 // layer's weight gradient reads (torch: zeros + a strided permute-copy).
 template <typename T, int CP>
@@ -1108,6 +1124,24 @@ int ppn_interleave_parity(int32_t dtype, const void* o00, const void* o01, const
     interleave_parity_kernel<<<(int)blocks, kThreads, 0, (hipStream_t)stream>>>((const uint4*)o00, (const uint4*)o01,
                                                                                 (const uint4*)o10, (const uint4*)o11, (uint4*)dx,
                                                                                 batch, h, w, Ho1, Wo1, c16);
+    PPN_LAUNCH_CHECK();
+    return PPN_OK;
+}
+
+int ppn_interleave_parity_stacked(int32_t dtype, const void* o, int32_t batch, int32_t h, int32_t w, int32_t channels, void* dx,
+                                  void* stream) {
+    if (!o || !dx || batch < 1 || h < 1 || w < 1 || channels < 1)
+        return ppn::fail(PPN_E_INVALID, "ppn_interleave_parity_stacked: bad arguments");
+    if (dtype != PPN_F32 && dtype != PPN_BF16 && dtype != PPN_F16) return ppn::fail(PPN_E_INVALID, "bad dtype %d", dtype);
+    const int es = dtype == PPN_F32 ? 4 : 2;
+    if ((channels * es) % 16) return ppn::fail(PPN_E_UNSUPPORTED, "ppn_interleave_parity_stacked: a pixel must be a multiple of 16 bytes");
+    const int c16 = channels * es / 16;
+    const int Ho1 = (h + 2 - 3) / 2 + 2, Wo1 = (w + 2 - 3) / 2 + 2;
+    const long long n = (long long)batch * h * w * c16;
+    long long blocks = (n + kThreads - 1) / kThreads;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    interleave_parity_stacked_kernel<<<(int)blocks, kThreads, 0, (hipStream_t)stream>>>((const uint4*)o, (uint4*)dx, batch, h, w,
+                                                                                       Ho1, Wo1, c16);
     PPN_LAUNCH_CHECK();
     return PPN_OK;
 }

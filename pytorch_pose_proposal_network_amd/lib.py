@@ -170,6 +170,7 @@ _SIGNATURES.update({
     "ppn_relu_mask": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "ppn_upsample_zero": (C.c_int, [C.c_int32, C.c_void_p] + [C.c_int32] * 7 + [C.c_void_p, C.c_void_p]),
     "ppn_interleave_parity": (C.c_int, [C.c_int32] + [C.c_void_p] * 4 + [C.c_int32] * 4 + [C.c_void_p, C.c_void_p]),
+    "ppn_interleave_parity_stacked": (C.c_int, [C.c_int32, C.c_void_p] + [C.c_int32] * 4 + [C.c_void_p, C.c_void_p]),
     "ppn_image_to_nhwc": (C.c_int, [C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "ppn_colsum": (C.c_int, [C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ppn_head_grad": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
