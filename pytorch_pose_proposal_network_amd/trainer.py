@@ -100,6 +100,7 @@ class PPNTrainer:
         self._speculate_tail = os.environ.get("PPN_TRAIN_SPECULATE_TAIL", "1") != "0"
         self._so_pin = None
         self._w3p = {}                               # _w3_padded
+        self._wg0_main = os.environ.get("PPN_TRAIN_WG0_MAIN", "1") != "0"
         self._tail_wgrad_side = os.environ.get("PPN_TRAIN_TAIL_WGRAD_SIDE", "1") != "0"
         pri = int(os.environ.get("PPN_TRAIN_PROBE_PRIORITY", "0"))
         self._probe_stream = torch.cuda.Stream(device=self.device, priority=pri) if self._side is not None else None
@@ -688,7 +689,12 @@ class PPNTrainer:
                     def wg0(x8=c["x"], dy=dy, wn=wn):
                         dw8 = T.conv_wgrad(x8, dy, 7, 1, 1, 3)            # [16, 4 | 8, 7, 7]; input channels 3.. are zero
                         self.G[wn].copy_(dw8[:, :3])
-                    self._on_side(wg0, c["x"], dy)
+                    # the LAST weight gradient of the pass: on the main stream (idle from here on) beside the side stream's
+                    # layer1 / layer2 weight gradients instead of behind them (PPN_TRAIN_WG0_MAIN=0: on the side stream)
+                    if self._wg0_main:
+                        wg0()
+                    else:
+                        self._on_side(wg0, c["x"], dy)
                     g = None                                               # the input needs no gradient
                 else:
                     self._wgrad(wn, c["x"], dy, 3, u.stride, d, d)
