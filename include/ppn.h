@@ -278,6 +278,14 @@ typedef struct ppn_conv_desc {
      * CU's whole LDS and register file -- the choice of a plan that shares the GPU with other lanes' plans
      * (rt.MultiLaneInference).  Results are bit-identical either way. */
     int32_t flags;
+    /* Prefetch hint (round 5; large-tile kernel only, ignored elsewhere): `prefetch_bytes` bytes at `prefetch` -- the packed
+     * weights of the NEXT launch of a plan -- are touched once (one dword per 128-byte line, shared out over the workgroups)
+     * before this launch's epilogue, which puts them into the Infinity Cache.  In the forward pass a layer's weights were
+     * last read one whole pass (> 1 GB of traffic) ago, so its first round of workgroups otherwise fetches every K step's
+     * weight slab from HBM in lockstep (profiles/r05/cold_operands.txt: 80 vs 100 us on the 24 x 24 512-wide layers).
+     * Results do not depend on it.  NULL / 0: none. */
+    const void* prefetch;
+    int64_t prefetch_bytes;
 } ppn_conv_desc;
 #define PPN_CONV_NO_FILTER_BANK 1
 /* PPN_CONV_SHARED_GPU: this launch runs beside other streams' launches (rt.MultiLaneInference): the tile chooser then

@@ -698,6 +698,9 @@ int ppn::conv_launch(const ppn_conv_desc* d, hipStream_t st, const char** kname)
     a.out_plain = (d->flags & PPN_CONV_X3_PLAIN_OUT) ? 1 : 0;
     if (a.out_plain && (!x3 || d->out_nchw_f32))
         return ppn::fail(PPN_E_UNSUPPORTED, "PPN_CONV_X3_PLAIN_OUT: a PPN_F16X3 launch with NHWC outputs");
+    a.pf_ptr = static_cast<const char*>(d->prefetch);
+    a.pf_lines = (d->prefetch && d->prefetch_bytes > 0) ? (unsigned)std::min<long long>(d->prefetch_bytes / 128, 1 << 24) : 0u;
+    a.pf_per_wg = 0;                                                  // set by launch_big (it knows the grid)
     a.out_bf16 = (d->flags & PPN_CONV_OUT_BF16) ? 1 : 0;
     if (a.out_bf16 && (d->dtype != PPN_F16 || !big || d->out_nchw_f32))
         return ppn::fail(PPN_E_UNSUPPORTED, "PPN_CONV_OUT_BF16: a PPN_F16 launch of the large-tile kernel with NHWC outputs");

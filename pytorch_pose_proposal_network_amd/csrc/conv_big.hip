@@ -134,6 +134,7 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef PPN_CLOCK
     const unsigned long long ck_entry = __builtin_amdgcn_s_memtime();
+    const unsigned long long rk_entry = __builtin_amdgcn_s_memrealtime();   // absolute 100 MHz time (-DPPN_CLOCK=2: reported)
 #endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -437,6 +438,19 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
         for (int j = 0; j < 16; ++j) acc[(i * 4 + j / 4) / TP][(i * 4 + j / 4) % TP][j % 4] += acc32[i][j];
 #endif
     __syncthreads();                                                 // LDS is reused by the epilogue
+
+    // ---- prefetch hint (ppn_conv_desc.prefetch): touch this workgroup's share of the NEXT launch's weights, one dword per
+    // 128-byte line, so that they sit in the Infinity Cache when that launch's first round starts (they were last read a whole
+    // forward pass ago).  The values are kept "live" up to the end of the kernel (empty asm below): the loads' latency then
+    // passes under the epilogue instead of in front of whatever instruction would reuse their registers.
+    int pf_keep0 = 0, pf_keep1 = 0;
+    if (a.pf_per_wg) {
+        const unsigned l0 = blockIdx.x * a.pf_per_wg + tid, lend = min((blockIdx.x + 1) * a.pf_per_wg, a.pf_lines);
+        // ordinary loads (a non-temporal load does not allocate in the Infinity Cache: measured, no effect)
+        if (l0 < lend) pf_keep0 = *reinterpret_cast<const int*>(a.pf_ptr + (size_t)l0 * 128);
+        if (l0 + 64 * NW < lend) pf_keep1 = *reinterpret_cast<const int*>(a.pf_ptr + (size_t)(l0 + 64 * NW) * 128);
+        asm volatile("" : "+v"(pf_keep0), "+v"(pf_keep1));            // issued HERE (not sunk to the use at the kernel's end)
+    }
 
     // ---- epilogue through LDS chunks of 64 pixels (NHWC) / 64 channels (NCHW head) -------------------
     float* ct = reinterpret_cast<float*>(smem);
@@ -781,11 +795,18 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
         };
         static_for<TC / IC>(chunk);
     }
+    asm volatile("" ::"v"(pf_keep0), "v"(pf_keep1));              // the prefetch loads are waited for here, not earlier
 #ifdef PPN_CLOCK
     if (lane == 0 && a.scale2 == nullptr && a.shift2 != nullptr) {
         unsigned long long* dbg = (unsigned long long*)a.shift2 + ((size_t)blockIdx.x * NW + wave) * 8;
         dbg[4] = __builtin_amdgcn_s_memtime() - dbg[3];           // epilogue cycles
+#if PPN_CLOCK + 0 >= 2
+        // tools/clock_conv_seq.py: when the workgroup entered and left, in 10 ns ticks of the chip-wide constant clock
+        // (instead of the two prologue marks), so that rounds, launch ramp and tail can be laid on one time axis
+        dbg[5] = rk_entry; dbg[6] = __builtin_amdgcn_s_memrealtime();
+#endif
     }
+    (void)rk_entry;
 #endif
 #ifdef PPN_STAMP
     {
@@ -815,7 +836,12 @@ int launch_sc(const ConvKArgs& a, hipStream_t st, const char** kname) {
         PPN_LDS_ONCE(max_lds_set, reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)lds);
     }
-    hipLaunchKernelGGL(k, dim3(a.n_ctiles * a.n_ptiles), dim3(64 * NW), lds, st, a, (unsigned)src_bytes,
+    ConvKArgs b = a;
+    if (b.pf_lines) {                                  // prefetch hint: lines per workgroup, at most two per thread
+        const unsigned nwg = (unsigned)(a.n_ctiles * a.n_ptiles);
+        b.pf_per_wg = std::min<unsigned>((b.pf_lines + nwg - 1) / nwg, 2u * 64 * NW);
+    }
+    hipLaunchKernelGGL(k, dim3(a.n_ctiles * a.n_ptiles), dim3(64 * NW), lds, st, b, (unsigned)src_bytes,
                        (unsigned)wgt_bytes);
     PPN_LAUNCH_CHECK();
     return PPN_OK;

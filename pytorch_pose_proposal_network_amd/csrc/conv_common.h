@@ -60,6 +60,8 @@ struct ConvKArgs {
     int lo_off;                       // PPN_F16X3: bytes from a pixel's hi block to its lo' block in the SOURCE tensor
     int out_bf16;                     // PPN_F16 launch whose NHWC outputs are stored as bf16 (PPN_CONV_OUT_BF16)
     int out_plain;                    // PPN_F16X3 launch whose NHWC outputs are stored as plain half (PPN_CONV_X3_PLAIN_OUT)
+    const char* pf_ptr;               // ppn_conv_desc.prefetch: the next launch's weights, touched line by line (large-tile kernel)
+    unsigned pf_lines, pf_per_wg;     // 128-byte lines in all / per workgroup (at most 2 per thread)
 };
 
 template <typename T>

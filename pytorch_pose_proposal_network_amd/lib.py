@@ -39,6 +39,7 @@ class ConvDesc(C.Structure):
         ("unary_out", C.c_void_p), ("argmax_keys", C.c_void_p), ("unary_channels", C.c_int32),
         ("limb_window", C.c_int32), ("m_begin", C.c_int32), ("m_count", C.c_int32), ("limb_edge_pad", C.c_int32),
         ("flags", C.c_int32),
+        ("prefetch", C.c_void_p), ("prefetch_bytes", C.c_int64),
     ]
 
 

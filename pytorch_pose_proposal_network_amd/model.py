@@ -442,11 +442,23 @@ class PoseProposalNet:
             del bufs["head"]
             bufs["unary"] = torch.empty(batch, n_unary, th, tw, dtype=torch.float32, device=dev)
             bufs["keys"] = torch.empty(batch, len(self.edges), th, tw, dtype=torch.int64, device=dev)
-        for op in self._ops:
+        # prefetch hint (ppn_conv_desc.prefetch, round 5): every large-tile launch touches the packed weights of the NEXT
+        # launch before its epilogue -- a layer's weights were last read a whole pass ago and its first round of workgroups
+        # otherwise fetches them from HBM in lockstep (PPN_PREFETCH=0 switches the hint off; results do not depend on it)
+        use_pf = os.environ.get("PPN_PREFETCH", "1") != "0"
+
+        def set_prefetch(d, t):
+            if use_pf and t is not None:
+                d.prefetch, d.prefetch_bytes = t.data_ptr(), t.numel() * t.element_size()
+        edge_head = fused and bool(self._head_edge_pad())
+        for oi, op in enumerate(self._ops):
             ih, iw, _ = shapes[op.src]
             oh, ow = A.out_hw(op, ih, iw)
             entries.append((op.name, A.op_flops(op, shapes) * batch))
             odt = self._op_dtype(op)
+            nxt = self._ops[oi + 1] if oi + 1 < len(self._ops) else None
+            nxt_w = None if nxt is None else self._dev.get(
+                nxt.name + (".w_unary" if (nxt.nchw_f32_out and edge_head) else ".w"))
             if op.k == 7 and op.next_s2 is not None:
                 assert op.src == "input" and self.compute_dtype in (L.PPN_BF16, L.PPN_F16)
                 out_dt = store_dt[op.out_raw or op.out_act]
@@ -510,6 +522,7 @@ class PoseProposalNet:
                 sh2, sw2, sc2 = shapes[op.ds_src]
                 d.src2, d.in2_h, d.in2_w, d.cin2, d.stride2 = bufs[op.ds_src].data_ptr(), sh2, sw2, sc2, op.ds_stride
             d.out_raw = bufs[op.out_raw].data_ptr() if (op.out_raw and op.out_raw in bufs) else None
+            set_prefetch(d, nxt_w)
             if fused and op.nchw_f32_out and self._head_edge_pad():
                 # (1) the unary channels: an ordinary sigmoid NCHW conv straight into the compact unary tensor
                 keys, nun = bufs["keys"], bufs["unary"].shape[1]
@@ -519,7 +532,9 @@ class PoseProposalNet:
                 d.weight, d.shift1 = self._ptr(op.name + ".w_unary"), self._ptr(op.name + ".b_unary")
                 d.out_raw = bufs["unary"].data_ptr()
                 d.zero_page = self._dev["zero"].data_ptr()
+                set_prefetch(d, self._dev[op.name + ".w_edge"])
                 L.check(lib.ppn_plan_add_conv(handle, C.byref(d)), f"ppn_plan_add_conv({op.name}.unary)")
+                d.prefetch, d.prefetch_bytes = None, 0
                 entries.append((name + ".unary", flops * nun // op.cout))
                 # (2) the limb channels, one channel tile per edge: keys are stored, not accumulated -- no zero fill
                 ep = self._head_edge_pad()
