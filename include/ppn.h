@@ -314,6 +314,37 @@ int ppn_conv_tiling(int32_t dtype, int32_t cin, int32_t cout, int32_t ksize, int
 
 int ppn_conv2d_fused(const ppn_conv_desc* d, void* stream);
 
+/* One launch per 64-channel stride-1 pre-activation BasicBlock (drn.py:25-57; DRN-D's layer3 behind its first block), 16-bit
+ * modes (csrc/block64.hip, round 5):
+ *   mid     = act_mid(conv3x3(src, weight1) * scale_mid + shift_mid)        never written to HBM
+ *   v       = act1(conv3x3(mid, weight2) * scale1 + shift1) (+ residual)
+ *   out_raw = v;   out_act = act2(v * scale2 + shift2)
+ * i.e. the two ppn_conv2d_fused launches of the block (conv1 with out_raw = mid, conv2 reading it) in one persistent kernel:
+ * `src` is the block's pre-activated input relu(bn1(x)), `residual` the raw x.  Both weights are packed [64][576] with
+ * k = tap * 64 + ci (ppn_pack_weight k_order 0).  Outputs are BIT-IDENTICAL to the two launches (same K order, same epilogue
+ * arithmetic, mid rounded to the 16-bit type as the stored tensor was).  All tensors NHWC [batch][h][w][64] of `dtype`. */
+typedef struct ppn_block_desc {
+    int32_t dtype;               /* PPN_BF16 or PPN_F16 */
+    int32_t batch, h, w, channels;   /* channels = 64 */
+    const void* src;
+    const void* residual;        /* or NULL */
+    const void* weight1;
+    const float* scale_mid;      /* [64] or NULL (=1) */
+    const float* shift_mid;      /* [64] or NULL (=0) */
+    int32_t act_mid;
+    const void* weight2;
+    const float* scale1;
+    const float* shift1;
+    int32_t act1;
+    const float* scale2;
+    const float* shift2;
+    int32_t act2;
+    void* out_raw;               /* or NULL */
+    void* out_act;               /* or NULL */
+    int32_t flags;               /* 0 */
+} ppn_block_desc;
+int ppn_basicblock64_fused(const ppn_block_desc* d, void* stream);
+
 /* PPN_F16X3 helpers.
  * ppn_pack_weight_x3: w f32 [cout][cin][k][k] (device) -> out half [cout_pad][3 * k_pad], k_pad = k*k*cin (cin % 64 == 0),
  *   row layout per 64-channel slab sl: [half(ws) taps x 64 | half(ws - half(ws)) taps x 64 | half(ws * 2^-11) taps x 64]
@@ -392,6 +423,8 @@ int ppn_stem01(int32_t dtype, int32_t src_is_u8, const void* src, int32_t batch,
 typedef struct ppn_plan ppn_plan;
 int ppn_plan_create(ppn_plan** out);
 int ppn_plan_add_conv(ppn_plan* p, const ppn_conv_desc* d);
+/* A whole 64-channel BasicBlock as one entry (ppn_basicblock64_fused). */
+int ppn_plan_add_block(ppn_plan* p, const ppn_block_desc* d);
 /* Zero `bytes` at `ptr` as a step of the plan (the arg-max keys of the fused head conv); runs as a KERNEL with
  * 16-byte stores, never a memset node of the captured graph: `ptr` must be 16-byte aligned (PPN_E_INVALID else). */
 int ppn_plan_add_memset(ppn_plan* p, void* ptr, size_t bytes);

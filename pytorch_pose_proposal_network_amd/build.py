@@ -23,6 +23,7 @@ SOURCES = [
     ("conv_big.hip", []),
     ("conv_head.hip", []),
     ("conv64.hip", []),
+    ("block64.hip", []),
     ("stem.hip", []),
     ("stem3x3.hip", []),
     ("stem01.hip", []),

@@ -1,0 +1,440 @@
+// One launch per 64-channel stride-1 pre-activation BasicBlock (drn.py:25-57: bn1 -> relu -> conv1 -> bn2 -> relu -> conv2 -> += x;
+// DRN-D's layer3, 96 x 96 for a 384 x 384 input), 16-bit modes.  The two 3x3 convolutions of the block run in ONE persistent
+// kernel and the tensor between them never goes to HBM:
+//
+//   roles      a workgroup is 8 waves = two ROLES of 4 waves; every SIMD hosts one wave of each.  Role 0 computes conv1 (+ bn2 +
+//              ReLU) of output tile t+1 into an LDS "mid" tile while role 1 computes conv2 (+ residual, second output) of tile
+//              t from the mid tile role 0 wrote one phase earlier: a two-stage software pipeline with ONE workgroup barrier per
+//              tile.  Each role keeps ITS convolution's whole 64 x 576 filter bank in registers as MFMA A fragments (32 channels
+//              x 576 = 144 VGPRs per wave, as csrc/conv64.hip does for one convolution): no weight traffic in the loop.
+//   tiles      8 x 16 output pixels.  conv2 needs the 10 x 18 mid pixels around them, conv1 the 12 x 20 input pixels around
+//              those.  Input patch and mid tile share the row pitch 20 and are indexed LINEARLY (pixel (r, c) = row 20 r + c of
+//              128 bytes = 64 channels): a filter tap is then a constant row shift 20 dy + dx for ANY 16 consecutive rows, so
+//              conv1 walks the mid tile as 13 MFMA pixel tiles of 16 linear rows (208 rows cover the 10 x 18 region; the 28 rows
+//              that are not mid pixels are computed and discarded) and conv2 as 8 row-aligned ones.
+//   swizzle    row L keeps its eight 16-byte chunks XORed with (L >> 1) & 7 (source side for the LDS-DMA of the input patch,
+//              store side for the mid tile): the key of row 16 n + r + 20 dy + dx is ((r + dx) >> 1) + 2 dy mod 8 whatever the
+//              tile, so nine (conv1) / twelve (conv2) per-lane offsets plus immediates address every fragment read.
+//   borders    input pixels outside the image arrive as zeros (out-of-range buffer offsets); mid pixels outside the image are
+//              STORED as zeros (conv2's zero padding applies to relu(bn2(conv1)), drn.py:45-51), not computed from padding.
+//   epilogue   conv2's epilogue works on the accumulators as they lie (4 consecutive channels of a pixel per lane and MFMA tile):
+//              the residual rows were fetched into LDS by role 0 one phase ahead, outputs leave as 8-byte stores (no staging
+//              tile, no barrier, no memory wait).  The arithmetic -- K order tap-major in 32-deep halves, v = act1(acc*s1+b1) (+res), out_act =
+//              act2(v*s2+b2), one rounding per stored value -- is that of the two separate launches (conv.hip / conv_big.hip /
+//              conv64.hip), so the block's outputs are BIT-IDENTICAL to them.
+//
+// Work per tile: conv1 13 x 4 x 18 + conv2 8 x 4 x 18 MFMAs (1.31x the separate launches' FLOPs: the halo is recomputed) against
+// half their HBM traffic (x_act + x in, two tensors out; the mid tensor, 37.7 MB at batch 32, stays on chip) and one launch.
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
+#include <utility>
+
+#include "conv_common.h"
+
+namespace {
+
+using namespace ppnconv;
+
+constexpr unsigned kOOB = 0x80000000u;
+
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+__device__ __forceinline__ void bufload_lds16(__amdgpu_buffer_rsrc_t rsrc, char* lds_wave_base, unsigned voff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (void __attribute__((address_space(3)))*)lds_wave_base, 16, voff, 0, 0, 0);
+}
+
+struct BlkArgs {
+    const char* src;                 // relu(bn1(x)): NHWC [B][H][W][64]
+    const char* res;                 // x (the block's residual) or NULL
+    const char* w1;                  // packed [64][576], k = tap * 64 + ci
+    const char* w2;
+    const float *sm, *bm;            // bn2 folded (between the convolutions), act_mid
+    const float *s1, *b1;            // conv2's own affine (NULL for a BasicBlock), act1
+    const float *s2, *b2;            // second output: the next block's bn1 folded, act2
+    char* out_raw;
+    char* out_act;
+    int B, H, W, act_mid, act1, act2;
+    int tiles_x, tiles_y, n_tiles;   // 16-wide x 8-high output tiles per image
+    FastDiv div_tx, div_tpi;
+    unsigned long long* dbg;         // -DPPN_CLOCK builds only
+};
+
+constexpr int TH = 8, TW = 16;                    // output tile
+constexpr int PW = 20;                            // row pitch of the input patch AND of the mid tile
+constexpr int IN_ROWS = 256;                      // 12 x 20 = 240 rows are filled; conv1's last pixel tile reads up to row 249
+constexpr int IN_DMA = 240 / 8;                   // 30 wave-instructions of 8 rows
+constexpr int IN_BYTES = IN_ROWS * 128;
+constexpr int MID_TILES = 13;                     // 16-row MFMA pixel tiles of conv1: linear mid rows 0 .. 207 (pixel half 0: tiles 0-6, half 1: 6-12)
+constexpr int MID_BYTES = MID_TILES * 16 * 128;   // 26 624
+constexpr int RES_BYTES = TH * TW * 128;           // the residual rows of one output tile (16 384)
+constexpr int CST_BYTES = 6 * 64 * 4;
+constexpr int OFF_MID = 2 * IN_BYTES, OFF_RES = OFF_MID + 2 * MID_BYTES, OFF_CST = OFF_RES + 2 * RES_BYTES;
+constexpr int LDS_BYTES = OFF_CST + CST_BYTES;    // 153 088 of 163 840
+static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+
+template <typename T> struct Pack4;
+template <> struct Pack4<_Float16> {
+    typedef __attribute__((ext_vector_type(4))) _Float16 v4;
+    static __device__ __forceinline__ uint2 pack(const float* v) {
+        v4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = (_Float16)clamp_f16(v[i]);
+        return __builtin_bit_cast(uint2, o);
+    }
+};
+template <> struct Pack4<__bf16> {
+    typedef __attribute__((ext_vector_type(4))) __bf16 v4;
+    static __device__ __forceinline__ uint2 pack(const float* v) {
+        v4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = (__bf16)v[i];
+        return __builtin_bit_cast(uint2, o);
+    }
+};
+
+template <typename T>
+__global__ void __launch_bounds__(512, 2) block64_kernel(BlkArgs a, unsigned tensor_bytes) {
+    static_assert(sizeof(T) == 2, "16-bit modes only");
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int role = wave >> 2, rw = wave & 3;    // role 0: conv1, role 1: conv2 (waves w and w + 4 share a SIMD)
+    const int wc = rw >> 1, wp = rw & 1;          // 2 (channel halves) x 2 (pixel halves)
+    float* cst = reinterpret_cast<float*>(smem + OFF_CST);           // [sm | bm | s1 | b1 | s2 | b2][64]
+
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.src, 0, tensor_bytes, 0x00020000);
+
+    // ---- this role's filter bank as MFMA A fragments: wf[tap][half][channel tile] ----------------------------------------
+    f32x4 wf[9][2][2];
+    {
+        const char* wg = role ? a.w2 : a.w1;
+        const int frow = lane & 15, fq = lane >> 4;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int ch = wc * 32 + i * 16 + frow;
+                    wf[t][h][i] = *reinterpret_cast<const f32x4*>(wg + ((size_t)ch * 576 + t * 64 + h * 32 + fq * 8) * 2);
+                }
+    }
+    if (tid < 64) {
+        cst[tid] = a.sm ? a.sm[tid] : 1.f;       cst[64 + tid] = a.bm ? a.bm[tid] : 0.f;
+        cst[128 + tid] = a.s1 ? a.s1[tid] : 1.f; cst[192 + tid] = a.b1 ? a.b1[tid] : 0.f;
+        cst[256 + tid] = a.s2 ? a.s2[tid] : 1.f; cst[320 + tid] = a.b2 ? a.b2[tid] : 0.f;
+    }
+    const float slope_m = a.act_mid == PPN_ACT_RELU ? 0.f : (a.act_mid == PPN_ACT_LRELU ? 0.1f : 1.f);
+    const float slope1 = a.act1 == PPN_ACT_RELU ? 0.f : (a.act1 == PPN_ACT_LRELU ? 0.1f : 1.f);
+    const float slope2 = a.act2 == PPN_ACT_RELU ? 0.f : (a.act2 == PPN_ACT_LRELU ? 0.1f : 1.f);
+
+    const int G = gridDim.x, first = blockIdx.x;
+    const int n = (a.n_tiles - first + G - 1) / G;               // tiles of this workgroup (>= 1: the grid never exceeds n_tiles)
+    auto tile_pos = [&](int tile, int& img, int& ty, int& tx) {
+        img = fast_div(tile, a.div_tpi);
+        const int rem = tile - img * (a.tiles_x * a.tiles_y);
+        ty = fast_div(rem, a.div_tx);
+        tx = rem - ty * a.tiles_x;
+    };
+
+    // ---- role 0: the 12 x 20 input patch of a tile by LDS-DMA (30 instructions of 8 rows over the role's 4 waves) ----------
+    auto issue_patch = [&](int tile, int buf) {
+        int img, ty, tx;
+        tile_pos(tile, img, ty, tx);
+        const int y0 = ty * TH - 2, x0 = tx * TW - 2;
+        for (int g = rw; g < IN_DMA; g += 4) {
+            const int row = g * 8 + (lane >> 3);
+            const int py = row / PW, px = row - py * PW;
+            const int y = y0 + py, x = x0 + px;
+            const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+            const bool ok = (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+            const unsigned off = ok ? (unsigned)(((img * a.H + y) * a.W + x) * 128 + chunk * 16) : kOOB;
+            bufload_lds16(xrs, smem + buf * IN_BYTES + g * 1024, off);
+        }
+    };
+
+    // ---- role 0 also fetches the RESIDUAL rows of a tile (8 x 16 pixels, 16 instructions) for role 1, one phase ahead: role 1
+    // then needs neither registers nor a memory wait for them (row r keeps its chunks XORed with r & 7)
+    const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.res ? a.res : a.src), 0, a.res ? tensor_bytes : 0u, 0x00020000);
+    auto issue_res = [&](int tile, int buf) {
+        int img, ty, tx;
+        tile_pos(tile, img, ty, tx);
+        for (int g = rw; g < TH * TW / 8; g += 4) {
+            const int row = g * 8 + (lane >> 3);
+            const int y = ty * TH + (row >> 4), x = tx * TW + (row & 15);
+            const int chunk = (lane & 7) ^ (row & 7);
+            const bool ok = y < a.H && x < a.W;
+            const unsigned off = ok ? (unsigned)(((img * a.H + y) * a.W + x) * 128 + chunk * 16) : kOOB;
+            bufload_lds16(rrs, smem + OFF_RES + buf * RES_BYTES + g * 1024, off);
+        }
+    };
+
+    // ---- role 0: conv1 + bn2 + ReLU of one tile: input patch `buf` -> mid tile `buf` ---------------------------------------
+    // The role's 4 waves = 2 channel halves x 2 pixel halves; pixel half 0 computes the MFMA pixel tiles 0 .. 6 of the 13,
+    // half 1 the tiles 6 .. 12 (tile 6 twice, same values: seven tiles per wave without a branch in the MFMA stream), each in
+    // two passes of 4 + 3 tiles so that 32 accumulator registers are live beside the 144 of the filter bank.
+    auto conv1_tile = [&](int tile, int buf) {
+        int img, ty, tx;
+        tile_pos(tile, img, ty, tx);
+        int frow = lane & 15, fq = lane >> 4;
+        asm volatile("" : "+v"(frow), "+v"(fq));                     // (keeps the address expressions inside the tile loop)
+        const int tb = wp * 6;                                       // first pixel tile of this wave
+        const unsigned pbo = (unsigned)(buf * IN_BYTES + (tb * 16 + frow) * 128);
+        unsigned a9[3][3];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) a9[dy][dx] = pbo + (unsigned)((((((frow + dx) >> 1) + 2 * dy) & 7) ^ fq) << 4);
+        const int y0 = ty * TH - 1, x0 = tx * TW - 1;
+        const unsigned mbo = (unsigned)(OFF_MID + buf * MID_BYTES + (tb * 16 + frow) * 128 + (fq & 1) * 8);
+        const unsigned ck0 = (unsigned)((wc * 4 + (fq >> 1)) ^ ((frow >> 1) & 7)) << 4;
+        const unsigned ck1 = (unsigned)((wc * 4 + 2 + (fq >> 1)) ^ ((frow >> 1) & 7)) << 4;
+        auto pass = [&](auto j0c, auto njc) {
+            constexpr int J0 = decltype(j0c)::value, NJ = decltype(njc)::value;
+            auto xread = [&](int s, int j) {                         // fragment of half-step s (tap s / 2, half s % 2), pixel tile j
+                const int t = s >> 1, h = s & 1, dy = t / 3, dx = t % 3;
+                return *reinterpret_cast<const f32x4*>(smem + (a9[dy][dx] ^ (unsigned)(h << 6)) + (16 * j + PW * dy + dx) * 128);
+            };
+            f32x4 acc[2][NJ];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            // 18 half-steps x NJ pixel tiles, fragments read three items ahead of their MFMAs (a ring of four)
+            constexpr int NIT = 18 * NJ, AHEAD = 3;
+            f32x4 ring[4];
+            static_for<AHEAD>([&](auto nc) {
+                constexpr int it = decltype(nc)::value;
+                ring[it & 3] = xread(it / NJ, J0 + it % NJ);
+            });
+            static_for<NIT>([&](auto nc) {
+                constexpr int it = decltype(nc)::value;
+                constexpr int s = it / NJ, j = it % NJ, t = s / 2, h = s % 2;
+                constexpr int nx = it + AHEAD;
+                if constexpr (nx < NIT) ring[nx & 3] = xread(nx / NJ, J0 + nx % NJ);
+                mma_step(acc[0][j], wf[t][h][0], ring[it & 3], (T*)nullptr);
+                mma_step(acc[1][j], wf[t][h][1], ring[it & 3], (T*)nullptr);
+                __builtin_amdgcn_sched_barrier(0);                   // the stream as written: one read, two MFMAs (no read clustering)
+            });
+            // epilogue: v = act(acc * sm + bm) as T, zero outside the image / outside the 10 x 18 mid region, into the mid tile
+            f32x4 sm[2], bm[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                sm[i] = *reinterpret_cast<const f32x4*>(cst + wc * 32 + i * 16 + 4 * fq);
+                bm[i] = *reinterpret_cast<const f32x4*>(cst + 64 + wc * 32 + i * 16 + 4 * fq);
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int L = (tb + J0 + j) * 16 + frow;
+                const int my = L / PW, mx = L - my * PW;
+                const bool ok = my < TH + 2 && mx < TW + 2 && (unsigned)(y0 + my) < (unsigned)a.H && (unsigned)(x0 + mx) < (unsigned)a.W;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float t1 = acc[i][j][e] * sm[i][e] + bm[i][e];
+                        v[e] = fmaxf(t1, t1 * slope_m);
+                    }
+                    uint2 o = Pack4<T>::pack(v);
+                    if (!ok) o = make_uint2(0u, 0u);
+                    *reinterpret_cast<uint2*>(smem + mbo + (i ? ck1 : ck0) + (J0 + j) * 16 * 128) = o;
+                }
+            }
+        };
+        pass(std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{});
+        pass(std::integral_constant<int, 4>{}, std::integral_constant<int, 3>{});
+    };
+
+    // ---- role 1: conv2 + residual + second output of one tile: mid tile `buf` -> HBM ------------------------------------------
+    // The epilogue works on the accumulators as they lie (a lane holds 4 consecutive channels of a pixel per MFMA tile): residual
+    // from LDS (8 bytes per lane), two 8-byte stores per tile and output tensor -- no staging tile, no barrier.
+    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out_raw ? a.out_raw : a.out_act), 0, a.out_raw ? tensor_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out_act ? a.out_act : a.out_raw), 0, a.out_act ? tensor_bytes : 0u, 0x00020000);
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;   // LDS address of smem (asm reads)
+    auto conv2_tile = [&](int tile, int buf) {
+        int img, ty, tx;
+        tile_pos(tile, img, ty, tx);
+        int frow = lane & 15, fq = lane >> 4;
+        asm volatile("" : "+v"(frow), "+v"(fq));
+        const unsigned pbo = (unsigned)(OFF_MID + buf * MID_BYTES + (wp * 4 * PW + frow) * 128);
+        unsigned a12[4][3];                                          // [(j + dy) & 3][dx]
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx)
+                a12[rr][dx] = pbo + (unsigned)(dx * 128) + (unsigned)((((((frow + dx) >> 1) + 2 * rr) & 7) ^ fq) << 4);
+        auto xread = [&](int s, int j) {
+            const int t = s >> 1, h = s & 1, dy = t / 3, dx = t % 3;
+            return *reinterpret_cast<const f32x4*>(smem + (a12[(j + dy) & 3][dx] ^ (unsigned)(h << 6)) + (j + dy) * (PW * 128));
+        };
+        f32x4 acc[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // 18 half-steps x 4 pixel tiles, fragments read three items ahead (a ring of four)
+        constexpr int NIT = 18 * 4, AHEAD = 3;
+        f32x4 ring[4];
+        static_for<AHEAD>([&](auto nc) {
+            constexpr int it = decltype(nc)::value;
+            ring[it & 3] = xread(it / 4, it % 4);
+        });
+        static_for<NIT>([&](auto nc) {
+            constexpr int it = decltype(nc)::value;
+            constexpr int s = it / 4, j = it % 4, t = s / 2, h = s % 2;
+            constexpr int nx = it + AHEAD;
+            if constexpr (nx < NIT) ring[nx & 3] = xread(nx / 4, nx % 4);
+            mma_step(acc[0][j], wf[t][h][0], ring[it & 3], (T*)nullptr);
+            mma_step(acc[1][j], wf[t][h][1], ring[it & 3], (T*)nullptr);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        // epilogue: lane (frow, fq) holds channels wc*32 + i*16 + 4 fq .. +3 of pixel (tile row wp*4 + j, column frow)
+        f32x4 s1[2], b1[2], s2[2], b2[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = wc * 32 + i * 16 + 4 * fq;
+            s1[i] = *reinterpret_cast<const f32x4*>(cst + 128 + c); b1[i] = *reinterpret_cast<const f32x4*>(cst + 192 + c);
+            s2[i] = *reinterpret_cast<const f32x4*>(cst + 256 + c); b2[i] = *reinterpret_cast<const f32x4*>(cst + 320 + c);
+        }
+        const unsigned rbo = (unsigned)(OFF_RES + buf * RES_BYTES + (wp * 4 * 16 + frow) * 128 + (fq & 1) * 8);
+        const unsigned rk0 = (unsigned)((wc * 4 + (fq >> 1)) ^ (frow & 7)) << 4, rk1 = (unsigned)((wc * 4 + 2 + (fq >> 1)) ^ (frow & 7)) << 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int y = ty * TH + wp * 4 + j, x = tx * TW + frow;
+            const unsigned obase = (y < a.H && x < a.W) ? (unsigned)((((img * a.H + y) * a.W + x) * 64 + wc * 32 + 4 * fq) * 2) : kOOB;
+            // the residual of this pixel tile, as INLINE ASM: hipcc puts s_waitcnt vmcnt(0) in front of every LDS read it knows of
+            // that may alias an LDS-DMA target (role 0 fills this buffer) -- here that would wait for the stores just issued
+            u32x2 rres[2];
+            asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(rres[0]), "=&v"(rres[1])
+                         : "v"(lds_base + rbo + rk0 + (unsigned)(j * 16 * 128)), "v"(lds_base + rbo + rk1 + (unsigned)(j * 16 * 128))
+                         : "memory");
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float t1 = acc[i][j][e] * s1[i][e] + b1[i][e];
+                    v[e] = fmaxf(t1, t1 * slope1);
+                }
+                if (a.res) {
+                    float r[8];
+                    const uint4 r4 = make_uint4(rres[i].x, rres[i].y, 0u, 0u);
+                    load8<T>(reinterpret_cast<const char*>(&r4), r);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += r[e];
+                }
+                const unsigned off = obase == kOOB ? kOOB : obase + (unsigned)(i * 32);
+                if (a.out_raw) {
+                    const uint2 o = Pack4<T>::pack(v);
+                    __builtin_amdgcn_raw_buffer_store_b64(u32x2{o.x, o.y}, ors, (int)off, 0, 0);
+                }
+                if (a.out_act) {
+                    float u[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float t2 = v[e] * s2[i][e] + b2[i][e];
+                        u[e] = fmaxf(t2, t2 * slope2);
+                    }
+                    const uint2 o = Pack4<T>::pack(u);
+                    __builtin_amdgcn_raw_buffer_store_b64(u32x2{o.x, o.y}, ars, (int)off, 0, 0);
+                }
+            }
+        }
+    };
+
+    // ---- the pipeline: phase p = conv1 of tile p (role 0) beside conv2 of tile p - 1 (role 1); one barrier per phase --------
+    if (role == 0) issue_patch(first, 0);
+    for (int p = 0; p <= n; ++p) {
+        // role 0's patch of tile p has landed (its only outstanding memory operations); everyone's LDS traffic of the previous
+        // phase is complete: the mid tile p - 1 is written, mid tile p - 2 and patch p - 1 are no longer read
+        if (role == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lds_barrier();
+        if (role == 0) {
+            if (p + 1 < n) issue_patch(first + (p + 1) * G, (p + 1) & 1);
+            if (p < n && a.res) issue_res(first + p * G, p & 1);      // read by role 1 in phase p + 1
+            if (p < n) conv1_tile(first + p * G, p & 1);
+        } else if (p >= 1) {
+            conv2_tile(first + (p - 1) * G, (p - 1) & 1);
+        }
+    }
+}
+
+}  // namespace
+
+namespace ppn {
+
+static int g_block64_on = -1;            // -1: not decided yet (PPN_BLOCK64=0 in the environment disables it)
+
+bool block64_enabled() {
+    if (g_block64_on < 0) g_block64_on = (getenv("PPN_BLOCK64") && atoi(getenv("PPN_BLOCK64")) == 0) ? 0 : 1;
+    return g_block64_on != 0;
+}
+
+int block64_launch(const ppn_block_desc* d, hipStream_t st, const char** kname) {
+    if (!d) return ppn::fail(PPN_E_INVALID, "block desc is NULL");
+    if (d->dtype != PPN_BF16 && d->dtype != PPN_F16) return ppn::fail(PPN_E_UNSUPPORTED, "ppn_basicblock64: 16-bit modes only");
+    if (d->channels != 64) return ppn::fail(PPN_E_UNSUPPORTED, "ppn_basicblock64: 64 channels (got %d)", d->channels);
+    if (d->batch < 1 || d->h < 1 || d->w < 1) return ppn::fail(PPN_E_INVALID, "ppn_basicblock64: bad geometry");
+    if (!d->src || !d->weight1 || !d->weight2 || (!d->out_raw && !d->out_act))
+        return ppn::fail(PPN_E_INVALID, "ppn_basicblock64: NULL src/weight/output");
+    for (int act : {d->act_mid, d->act1, d->act2})
+        if (act != PPN_ACT_NONE && act != PPN_ACT_RELU && act != PPN_ACT_LRELU)
+            return ppn::fail(PPN_E_UNSUPPORTED, "ppn_basicblock64: activations none / ReLU / LeakyReLU");
+    const size_t bytes = (size_t)d->batch * d->h * d->w * 64 * 2;
+    if (bytes >= 0x7fffff00ull) return ppn::fail(PPN_E_UNSUPPORTED, "tensor too large for the buffer-addressed kernel");
+    BlkArgs a;
+    a.src = static_cast<const char*>(d->src);
+    a.res = static_cast<const char*>(d->residual);
+    a.w1 = static_cast<const char*>(d->weight1);
+    a.w2 = static_cast<const char*>(d->weight2);
+    a.sm = d->scale_mid; a.bm = d->shift_mid;
+    a.s1 = d->scale1; a.b1 = d->shift1; a.s2 = d->scale2; a.b2 = d->shift2;
+    a.out_raw = static_cast<char*>(d->out_raw);
+    a.out_act = static_cast<char*>(d->out_act);
+    a.B = d->batch; a.H = d->h; a.W = d->w; a.act_mid = d->act_mid; a.act1 = d->act1; a.act2 = d->act2;
+    a.tiles_x = (d->w + TW - 1) / TW; a.tiles_y = (d->h + TH - 1) / TH;
+    const long long nt = (long long)d->batch * a.tiles_x * a.tiles_y;
+    if (nt > 0x7fffffffLL) return ppn::fail(PPN_E_UNSUPPORTED, "too many tiles");
+    a.n_tiles = (int)nt;
+    a.div_tx = make_fastdiv((unsigned)a.tiles_x);
+    a.div_tpi = make_fastdiv((unsigned)(a.tiles_x * a.tiles_y));
+    a.dbg = nullptr;
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        PPN_HIP_CHECK(hipGetDevice(&dev));
+        PPN_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    }
+    const int grid = (int)std::min<long long>(nt, n_cu);            // persistent: one workgroup per CU
+    if (d->dtype == PPN_F16) {
+        if (kname) *kname = "block64_kernel<_Float16>";
+        static int set16 = 0;
+        PPN_LDS_ONCE(set16, reinterpret_cast<const void*>(block64_kernel<_Float16>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        hipLaunchKernelGGL(block64_kernel<_Float16>, dim3(grid), dim3(512), LDS_BYTES, st, a, (unsigned)bytes);
+    } else {
+        if (kname) *kname = "block64_kernel<__bf16>";
+        static int setb = 0;
+        PPN_LDS_ONCE(setb, reinterpret_cast<const void*>(block64_kernel<__bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        hipLaunchKernelGGL(block64_kernel<__bf16>, dim3(grid), dim3(512), LDS_BYTES, st, a, (unsigned)bytes);
+    }
+    PPN_LAUNCH_CHECK();
+    return PPN_OK;
+}
+
+}  // namespace ppn
+
+extern "C" int ppn_basicblock64_fused(const ppn_block_desc* d, void* stream) {
+    return ppn::block64_launch(d, static_cast<hipStream_t>(stream), nullptr);
+}

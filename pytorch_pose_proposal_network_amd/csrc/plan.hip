@@ -9,6 +9,7 @@
 namespace ppn {
 int conv_launch(const ppn_conv_desc* d, hipStream_t st, const char** kname);
 int split_x3_launch(const float* src, long long pixels, int channels, void* dst, hipStream_t st);
+int block64_launch(const ppn_block_desc* d, hipStream_t st, const char** kname);
 int stem_launch(int dtype, int src_is_u8, const void* src, int batch, int h, int w, const float* weight,
                 const float* scale, const float* shift, const float* mean, const float* stdv, void* out,
                 hipStream_t st);
@@ -31,6 +32,7 @@ struct ppn_plan {
         void* ms_ptr = nullptr;
         size_t ms_bytes = 0;
         ppn_conv_desc conv;
+        ppn_block_desc block;      // kind 6: a whole 64-channel BasicBlock (csrc/block64.hip)
         int dtype, src_is_u8, batch, h, w;
         const void* src;
         const float *weight, *scale, *shift;
@@ -81,6 +83,12 @@ static int run_op(ppn_plan::Op& op, hipStream_t st) {
         if (op.kname.empty()) op.kname = "split_x3_kernel";
         return ppn::split_x3_launch(static_cast<const float*>(op.src), (long long)op.ms_bytes, op.batch, op.ms_ptr, st);
     }
+    if (op.kind == 6) {
+        const char* kn = nullptr;
+        int rc = ppn::block64_launch(&op.block, st, &kn);
+        if (rc == PPN_OK && kn && op.kname.empty()) op.kname = kn;
+        return rc;
+    }
     if (op.kind == 0) {
         const char* kn = nullptr;
         int rc = ppn::conv_launch(&op.conv, st, &kn);
@@ -114,6 +122,15 @@ extern "C" int ppn_plan_add_conv(ppn_plan* p, const ppn_conv_desc* d) {
     ppn_plan::Op op{};
     op.kind = 0;
     op.conv = *d;
+    p->ops.push_back(op);
+    return PPN_OK;
+}
+
+extern "C" int ppn_plan_add_block(ppn_plan* p, const ppn_block_desc* d) {
+    if (!p || !d) return ppn::fail(PPN_E_INVALID, "ppn_plan_add_block: NULL argument");
+    ppn_plan::Op op{};
+    op.kind = 6;
+    op.block = *d;
     p->ops.push_back(op);
     return PPN_OK;
 }

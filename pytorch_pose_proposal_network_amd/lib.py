@@ -43,6 +43,17 @@ class ConvDesc(C.Structure):
     ]
 
 
+class BlockDesc(C.Structure):
+    """ppn_block_desc: a whole 64-channel stride-1 BasicBlock as one launch (csrc/block64.hip)."""
+    _fields_ = [
+        ("dtype", C.c_int32), ("batch", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("channels", C.c_int32),
+        ("src", C.c_void_p), ("residual", C.c_void_p), ("weight1", C.c_void_p), ("scale_mid", C.c_void_p),
+        ("shift_mid", C.c_void_p), ("act_mid", C.c_int32), ("weight2", C.c_void_p), ("scale1", C.c_void_p),
+        ("shift1", C.c_void_p), ("act1", C.c_int32), ("scale2", C.c_void_p), ("shift2", C.c_void_p), ("act2", C.c_int32),
+        ("out_raw", C.c_void_p), ("out_act", C.c_void_p), ("flags", C.c_int32),
+    ]
+
+
 class PackItem(C.Structure):
     _fields_ = [("w", C.c_void_p), ("out", C.c_void_p)] + [
         (n, C.c_int32) for n in ("dtype", "cout", "cin", "ksize", "cout_pad", "k_total", "k_order", "k_step",
@@ -112,6 +123,7 @@ _SIGNATURES = {
                                   C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "ppn_conv2d_fused": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     "ppn_set_conv64_enabled": (C.c_int, [C.c_int32]),
+    "ppn_basicblock64_fused": (C.c_int, [C.POINTER(BlockDesc), C.c_void_p]),
     "ppn_conv_split": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.POINTER(C.c_int64)]),
     "ppn_stem7x7": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32] +
                     [C.c_void_p] * 3 + [C.POINTER(C.c_float)] * 2 + [C.c_void_p, C.c_void_p]),
@@ -129,6 +141,7 @@ _SIGNATURES = {
                                 [C.c_void_p] * 3 + [C.POINTER(C.c_float)] * 2 + [C.c_void_p] * 10),
     "ppn_plan_create": (C.c_int, [C.POINTER(C.c_void_p)]),
     "ppn_plan_add_conv": (C.c_int, [C.c_void_p, C.POINTER(ConvDesc)]),
+    "ppn_plan_add_block": (C.c_int, [C.c_void_p, C.POINTER(BlockDesc)]),
     "ppn_plan_add_memset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "ppn_plan_add_split": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
     "ppn_pack_weight_x3": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,

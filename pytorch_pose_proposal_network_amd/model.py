@@ -62,7 +62,8 @@ class PoseProposalNet:
     def __init__(self, backbone="drn_d_22", insize=(384, 384), outsize=(24, 24),
                  keypoint_names=cfg.KEYPOINT_NAMES, local_grid_size=(21, 21), edges=cfg.EDGES,
                  compute_dtype: str = "float32", fuse_stem=None, fuse_shortcut: Optional[bool] = None,
-                 stem_dtype: Optional[str] = None, half_prefix: Optional[int] = None, exact_prefix: int = -1):
+                 stem_dtype: Optional[str] = None, half_prefix: Optional[int] = None, exact_prefix: int = -1,
+                 fuse_block: Optional[bool] = None):
         self.arch = _arch_of(backbone)
         self.insize = insize
         self.outsize = outsize
@@ -78,6 +79,9 @@ class PoseProposalNet:
                               "bf16": L.PPN_BF16, "float16": L.PPN_F16, "fp16": L.PPN_F16, "f16": L.PPN_F16,
                               "float16x3": L.PPN_F16X3, "f16x3": L.PPN_F16X3}[compute_dtype]
         self.training = False
+        # 64-channel stride-1 BasicBlocks (layer3 behind its first block) as one launch each (csrc/block64.hip; PPN_BLOCK64=0 /
+        # fuse_block=False keep the two launches; results are bit-identical)
+        self.fuse_block = (os.environ.get("PPN_BLOCK64", "1") != "0") if fuse_block is None else bool(fuse_block)
         self.device = torch.device("cuda")
         # Type the FUSED stem (csrc/stem012.hip, 16-bit modes) computes in: its MFMA operands and on-chip tensors; its two
         # output tensors are always stored in the trunk's type.  The bf16 mode defaults to IEEE half (round 4): the stem
@@ -348,6 +352,28 @@ class PoseProposalNet:
             return self.compute_dtype
         return L.PPN_F16X3 if (op.k != 7 and op.cin % 64 == 0 and op.cout >= 64) else L.PPN_F32
 
+    def _block64_pair(self, oi: int, store_dt) -> bool:
+        """Do ops oi, oi + 1 form a 64-channel stride-1 BasicBlock that csrc/block64.hip runs as one launch?  (16-bit modes;
+        conv1 64 -> 64 3x3 -> bn2 -> ReLU -> conv2 64 -> 64 3x3 (+ x) with the mid tensor read by conv2 alone.)"""
+        if not self.fuse_block or oi + 1 >= len(self._ops):
+            return False
+        c1, c2 = self._ops[oi], self._ops[oi + 1]
+        odt = self._op_dtype(c1)
+        if odt not in (L.PPN_BF16, L.PPN_F16) or self._op_dtype(c2) != odt:
+            return False
+        for c in (c1, c2):
+            if not (c.cin == 64 and c.cout == 64 and c.k == 3 and c.stride == 1 and c.dilation == 1 and c.pad == 1 and
+                    not c.ds_src and not c.nchw_f32_out and c.next3x3 is None and
+                    self._dev.get(c.name + ".geom") == (576, 64)):
+                return False
+        if not (c1.out_raw and c2.src == c1.out_raw and not c1.out_act and not c1.residual and c1.bias is None):
+            return False
+        if sum(1 for o in self._ops if c1.out_raw in (o.src, o.residual, o.ds_src)) != 1:
+            return False
+        outs = [store_dt[n] for n in (c2.out_raw, c2.out_act) if n]
+        return bool(outs) and all(o == odt for o in outs) and all(a in (A.ACT_NONE, A.ACT_RELU, A.ACT_LRELU)
+                                                                  for a in (c1.act1, c2.act1, c2.act2))
+
     def _head_edge_pad(self) -> int:
         """Rows per edge of the edge-aligned limb tile (448) when the limb window fits it (385..448 values, e.g. the
         reference's 21 x 21), else 0: the chunked epilogue with atomicMax keys.  PPN_HEAD_EDGE=0 forces the latter."""
@@ -451,7 +477,10 @@ class PoseProposalNet:
             if use_pf and t is not None:
                 d.prefetch, d.prefetch_bytes = t.data_ptr(), t.numel() * t.element_size()
         edge_head = fused and bool(self._head_edge_pad())
+        skip = set()
         for oi, op in enumerate(self._ops):
+            if oi in skip:
+                continue
             ih, iw, _ = shapes[op.src]
             oh, ow = A.out_hw(op, ih, iw)
             entries.append((op.name, A.op_flops(op, shapes) * batch))
@@ -459,6 +488,24 @@ class PoseProposalNet:
             nxt = self._ops[oi + 1] if oi + 1 < len(self._ops) else None
             nxt_w = None if nxt is None else self._dev.get(
                 nxt.name + (".w_unary" if (nxt.nchw_f32_out and edge_head) else ".w"))
+            if self._block64_pair(oi, store_dt):
+                # a whole 64-channel stride-1 BasicBlock as ONE launch (csrc/block64.hip, round 5): conv1 -> bn2 -> ReLU -> conv2
+                # (+ x, second output); the tensor between the convolutions stays in LDS.  Bit-identical to the two launches.
+                c2 = self._ops[oi + 1]
+                skip.add(oi + 1)
+                entries[-1] = (f"{op.name}+conv2", (A.op_flops(op, shapes) + A.op_flops(c2, shapes)) * batch)
+                bd = L.BlockDesc()
+                bd.dtype, bd.batch, bd.h, bd.w, bd.channels = odt, batch, ih, iw, 64
+                bd.src, bd.residual = rd(op.src, odt).data_ptr(), (rd(c2.residual, odt).data_ptr() if c2.residual else None)
+                bd.weight1, bd.scale_mid, bd.shift_mid, bd.act_mid = (self._ptr(op.name + ".w"), self._ptr(op.name + ".s1"),
+                                                                     self._ptr(op.name + ".b1"), op.act1)
+                bd.weight2, bd.scale1, bd.shift1, bd.act1 = (self._ptr(c2.name + ".w"), self._ptr(c2.name + ".s1"),
+                                                             self._ptr(c2.name + ".b1"), c2.act1)
+                bd.scale2, bd.shift2, bd.act2 = self._ptr(c2.name + ".s2"), self._ptr(c2.name + ".b2"), c2.act2
+                bd.out_raw = bufs[c2.out_raw].data_ptr() if c2.out_raw else None
+                bd.out_act = bufs[c2.out_act].data_ptr() if c2.out_act else None
+                L.check(lib.ppn_plan_add_block(handle, C.byref(bd)), f"ppn_plan_add_block({op.name})")
+                continue
             if op.k == 7 and op.next_s2 is not None:
                 assert op.src == "input" and self.compute_dtype in (L.PPN_BF16, L.PPN_F16)
                 out_dt = store_dt[op.out_raw or op.out_act]

@@ -54,11 +54,11 @@ def test_library_loads_and_reports_errors_without_gpu():
 def test_ctypes_structs_match_header():
     """sizeof of the ctypes mirrors == sizeof of the C structs (compiled with gcc from include/ppn.h)."""
     lib = _lib()
-    src = '#include <stdio.h>\n#include "ppn.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(ppn_decode_cfg), sizeof(ppn_conv_desc), sizeof(ppn_bn_desc), sizeof(ppn_bn_bwd_desc), sizeof(ppn_loss_cfg), sizeof(ppn_wgrad_desc));return 0;}\n'
+    src = '#include <stdio.h>\n#include "ppn.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu ", sizeof(ppn_decode_cfg), sizeof(ppn_conv_desc), sizeof(ppn_bn_desc), sizeof(ppn_bn_bwd_desc), sizeof(ppn_loss_cfg), sizeof(ppn_wgrad_desc));printf("%zu\\n", sizeof(ppn_block_desc));return 0;}\n'
     exe = os.path.join("/tmp", "ppn_sizeof")
     subprocess.run(["gcc", "-x", "c", "-", "-I", os.path.join(ROOT, "include"), "-o", exe], input=src.encode(), check=True)
-    a, b, c, d, e, f = map(int, subprocess.check_output([exe]).split())
-    assert f == C.sizeof(lib.WgradDesc)
+    a, b, c, d, e, f, g = map(int, subprocess.check_output([exe]).split())
+    assert f == C.sizeof(lib.WgradDesc) and g == C.sizeof(lib.BlockDesc)
     assert a == C.sizeof(lib.DecodeCfg) and b == C.sizeof(lib.ConvDesc)
     assert c == C.sizeof(lib.BnDesc) and d == C.sizeof(lib.BnBwdDesc) and e == C.sizeof(lib.LossCfg)
 
