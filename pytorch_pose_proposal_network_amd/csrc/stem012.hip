@@ -42,7 +42,7 @@
 
 #include "common.h"
 
-// timing-only diagnostics (results wrong): -DPPN_S012_SKIP=mask, 1 convert, 2 layer0, 4 layer1, 8 layer2, 16 requests
+// timing-only diagnostics (results wrong): -DPPN_S012_SKIP=mask, 1 convert, 2 layer0, 4 layer1, 8 layer2, 16 requests, 32 layer-2 epilogue
 #ifndef PPN_S012_SKIP
 #define PPN_S012_SKIP 0
 #endif
@@ -69,10 +69,27 @@ constexpr int W0 = W1 + 8;              // layer-0 columns held: x0 = 2*C2 - 2 +
 // every ds_write_b64: 12.9 M conflict cycles per launch).  Readers fetch a lane's 8 input channels as two ds_read_b64
 // from planes 2h and 2h+1.  With W0 = 120 two planes are 1920 B = 128 (mod 256) apart, so the two lane groups of a
 // ds_read_b64 (h = 0 / h = 1) fall on different halves of the 64 banks.
+// Layer-1 ring (round 5): layer 2 reads it with STRIDE 2 (16 bytes between lanes), so the 16 lanes of one k-group g use every
+// other 8-byte slot of a 256-byte bank row, and the two k-groups of a ds_read_b64 lane group (g = 0 / 1: planes 2(g&1)) must
+// land on opposite slot parities: the planes are W1P = 113 pixels apart (904 B = 8 mod 16) and stored in the physical order
+// q -> [0, 2, 1, 3][q], so that the planes the two k-groups read in the same instruction (q = 0 / 2, then 1 / 3) are
+// NEIGHBOURS.  Before (pitch 112, natural order: 1792 B = 0 mod 256 between them) every layer-2 read was 2- to 4-way
+// conflicted: 3.8 M of the kernel's 5.2 M conflict cycles (profiles/r05/stem_conflicts_by_phase.txt).
+#ifdef PPN_S012_OLD_L1                   // A/B build of the round-4 layer-1 ring (tools/build_variant.py s012old stem012.hip -DPPN_S012_OLD_L1)
+constexpr int W1P = W1;
+#define PPN_S012_PQ(g) (g)
+#define PPN_S012_LO(g) (2 * ((g) & 1))
+constexpr int kHiPlanes = 1;
+#else
+constexpr int W1P = W1 + 1;
+#define PPN_S012_PQ(g) ((((g) & 1) << 1) | ((g) >> 1))
+#define PPN_S012_LO(g) ((g) & 1)
+constexpr int kHiPlanes = 2;
+#endif
 constexpr int WI = W1 + 8;              // input columns held:   xi = 2*C2 - 5 + i   (column i+7 meets a zero weight)
 constexpr int R0 = 6, R1 = 5, RI = 10;  // ring / patch rows
 constexpr int RAWS = 368;               // raw u8 row: 120 px x 3 B = 360 B (+ alignment slack), a multiple of 16
-constexpr int LDS_IN = RI * WI * 8, LDS_L0 = R0 * W0 * 32, LDS_L1 = R1 * W1 * 32, LDS_RAW = RI * RAWS, LDS_LUT = 3 * 256 * 2;
+constexpr int LDS_IN = RI * WI * 8, LDS_L0 = R0 * W0 * 32, LDS_L1 = R1 * 4 * W1P * 8, LDS_RAW = RI * RAWS, LDS_LUT = 3 * 256 * 2;
 constexpr int LDS_CST = 4 * 32 * 4;      // layer-2 epilogue constants [scale2 | shift2 | scale3 | shift3][32] f32
 constexpr int LDS_BYTES = LDS_IN + LDS_L0 + LDS_L1 + LDS_RAW + LDS_LUT + LDS_CST;
 
@@ -431,7 +448,7 @@ __global__ void __launch_bounds__(256, 2) stem012_kernel(Stem012Args a) {
                 s = s >= R0 ? s - R0 : s;
                 rd[kk] = smem_base + (unsigned)(LDS_IN + ((s * 4 + 2 * (g & 1)) * W0 + col + tdx[kk]) * 8);
             }
-            char* wr = l1_p + ((size_t)(((gy + 2 * R1) % R1) * 4 + g) * W1 + col) * 8;
+            char* wr = l1_p + ((size_t)(((gy + 2 * R1) % R1) * 4 + PPN_S012_PQ(g)) * W1P + col) * 8;   // physical plane [0,2,1,3][g]
             u32x2 lo[2][5], hi[2][5];
             auto fetch = [&](auto sgc, auto setc) {
                 constexpr int sg = decltype(sgc)::value, st = decltype(setc)::value;
@@ -475,7 +492,8 @@ __global__ void __launch_bounds__(256, 2) stem012_kernel(Stem012Args a) {
             for (int kk = 0; kk < 5; ++kk) {
                 int s = s0 + tdy[kk];
                 s = s >= R1 ? s - R1 : s;
-                rd[kk] = smem_base + (unsigned)(LDS_IN + LDS_L0 + ((s * 4 + 2 * (g & 1)) * W1 + 2 * (sg0 * 16 + col) + tdx[kk]) * 8);
+                // channels 8(g&1) .. +3 = plane q = 2(g&1) at physical plane g&1; the next four (q + 1) two physical planes on
+                rd[kk] = smem_base + (unsigned)(LDS_IN + LDS_L0 + ((s * 4 + PPN_S012_LO(g)) * W1P + 2 * (sg0 * 16 + col) + tdx[kk]) * 8);
             }
             for (int sg = 0; sg < nsg; ++sg) {
                 const int ox = C2 + (sg0 + sg) * 16 + col;
@@ -483,7 +501,7 @@ __global__ void __launch_bounds__(256, 2) stem012_kernel(Stem012Args a) {
 #pragma unroll
                 for (int kk = 0; kk < 5; ++kk) {
                     lo[kk] = lds_read64<0>(rd[kk] + sg * 256);
-                    hi[kk] = lds_read64<W1 * 8>(rd[kk] + sg * 256);
+                    hi[kk] = lds_read64<kHiPlanes * W1P * 8>(rd[kk] + sg * 256);
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
@@ -495,6 +513,10 @@ __global__ void __launch_bounds__(256, 2) stem012_kernel(Stem012Args a) {
 #pragma unroll
                     for (int ct = 0; ct < 2; ++ct)
                         acc[ct] = mfma16(wa2[ct][kk], xb, acc[ct], 0, 0, 0);
+                }
+                if constexpr ((PPN_S012_SKIP & 32) != 0) {            // timing / counter builds: no layer-2 epilogue
+                    asm volatile("" ::"v"(acc[0]), "v"(acc[1]));
+                    continue;
                 }
                 if (oy < a.Ho && ox < a.Wo) {
                     const size_t pix = ((size_t)b * a.Ho + oy) * a.Wo + ox;
