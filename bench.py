@@ -64,6 +64,48 @@ def pmc_traffic(kernel_name):
     return None
 
 
+def mfma_busy(kernel_name, achieved_tflops, peak_tflops):
+    """MFMA utilisation BY COUNTER (north_star: "rocprof reports ... MFMA utilisation for the conv stack") and the roofline
+    fraction against the peak AT THE CLOCK THE CHIP HOLDS under this kernel.  Committed constants with provenance, like
+    `traffic`: bench.py cannot run the profiler on itself.  SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs) per
+    dispatch, one SQ + GRBM pass of tools/pmc_mfma.sh -> tools/pmc_mfma_summary.py -> profiles/rNN_mfma_busy.json; the held
+    clock is the in-kernel s_memtime / s_memrealtime ratio of the same launches inside the forward pass
+    (tools/clock_conv_seq.py -> profiles/r05/conv_in_sequence_vs_back_to_back.txt)."""
+    import glob
+    here = os.path.dirname(os.path.abspath(__file__))
+    files = sorted(glob.glob(os.path.join(here, "profiles", "r*_mfma_busy.json")))
+    if not files:
+        return {"mfma_busy": None, "frac_of_held_clock_peak": None}
+    d = json.load(open(files[-1]))
+
+    def norm(n):
+        return "".join(ch for ch in n if ch.isalnum()).lower()
+    want = norm(kernel_name)
+    busy = None
+    for k, v in d.get("kernels", {}).items():
+        # rocprofv3 reports the mangled name: conv_igemm_big_kernelIDF16bLi192ELi256ELi8ELb0ELb0E... <-> <__bf16, 192, 256, 8, false>
+        if "conv_igemm_big_kernel" in kernel_name and "conv_igemm_big_kernel" in k:
+            tile = kernel_name.split("<")[1].split(">")[0].replace(" ", "").split(",")
+            tag = {"__bf16": "DF16b", "_Float16": "DF16_", "float": "f"}.get(tile[0], "?")
+            if f"I{tag}Li{tile[1]}ELi{tile[2]}ELi{tile[3]}ELb{1 if tile[4] == 'true' else 0}ELb0E" in k:
+                busy = v
+        elif norm(k).startswith(want[:20]):
+            busy = v
+    held = d.get("held_clock_ghz_in_sequence")
+    out = {"mfma_busy": (busy or {}).get("mfma_busy"),
+           "mfma_busy_conv_stack": d.get("conv_stack_mfma_busy"),
+           "mfma_busy_source": os.path.basename(files[-1]),
+           "mfma_busy_provenance": ("a COMMITTED constant, not measured by this run: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x "
+                                    "1024 SIMDs), one rocprofv3 --kernel-trace --pmc pass of `python3 bench.py --lanes 1 --shared-plan "
+                                    "--no-extras --no-verify --no-cpu-baseline` (tools/pmc_mfma.sh, file date " + str(d.get("_date")) +
+                                    "); `mfma_busy` = this kernel, `mfma_busy_conv_stack` = stem + all convolutions + head, time-weighted"),
+           "held_clock_ghz": held,
+           "frac_of_held_clock_peak": (round(achieved_tflops / (peak_tflops * held / 2.4), 4) if held else None),
+           "held_clock_note": "peak x held clock / 2.4 GHz: what the matrix pipes could deliver at the clock the power management "
+                              "holds under this kernel inside the forward pass (in-kernel s_memtime / s_memrealtime)"}
+    return out
+
+
 def cpu_baseline(arch, sample, size):
     """The oracle timed on this host's cores on `sample` frames of the same workload (reported, not a target)."""
     from oracle import decode_ref as D, forward_ref as Fr
@@ -108,6 +150,24 @@ def cpu_baseline_train(arch, size):
     return {"value": round(b * reps / dt, 3), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{reps} x {b} frames {size}x{size}: torch-CPU fp32 oracle train step "
                       f"(train-mode forward, loss, backward, 5 GradNorm probe gradients), {dt:.1f} s"}
+
+
+def _per_rank_stats(dist, backend, dev, world, rate, aux=0.0):
+    """N > 1: every rank's own images/s (its K steps until ITS GPU was done, before the closing barrier) and one auxiliary
+    per-rank number, gathered on all ranks: a straggler, or a rank that fell back to something slow, shows as min << median."""
+    if dist is None:
+        return None
+    t = torch.tensor([rate, aux], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+    got = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(got, t)
+    rates = sorted(float(g[0].item()) for g in got)
+    auxs = sorted(float(g[1].item()) for g in got)
+
+    def mmm(v, nd):
+        return {"min": round(v[0], nd), "median": round(v[len(v) // 2], nd), "max": round(v[-1], nd)}
+    return {"rates": dict(mmm(rates, 2), unit="images/sec per rank (own completion time, before the closing barrier)",
+                          ranks=[round(float(g[0].item()), 2) for g in got]),
+            "aux": dict(mmm(auxs, 4), ranks=[round(float(g[1].item()), 4) for g in got])}
 
 
 def _fail_hook(rank):
@@ -163,17 +223,25 @@ def main_train(args):
 
     def fence():
         torch.cuda.synchronize(dev)
+        t_local = time.perf_counter()                 # this rank's own GPU is done (before it waits for the others)
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(dev)
+        return t_local
 
+    from pytorch_pose_proposal_network_amd import train as T_
+    T_.BucketedAllReduce.measure = dist is not None
     fence()
+    T_.BucketedAllReduce.exposed_ms()                 # drop the warm-up's events
     t0 = time.perf_counter()
     for _ in range(args.steps):
         losses, w = tr.train_step(x, tg)
     host_submit = time.perf_counter() - t0
-    fence()
+    t_local = fence()
     dt = time.perf_counter() - t0
+    exposed = T_.BucketedAllReduce.exposed_ms()
+    per_rank = _per_rank_stats(dist, backend, dev, world, B * args.steps / (t_local - t0),
+                               (sum(exposed) / len(exposed)) if exposed else 0.0)
     if dist is not None:
         t = torch.tensor([dt, host_submit], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -203,6 +271,13 @@ def main_train(args):
                          "traffic": None},
             "losses": [round(float(v), 4) for v in losses.tolist()], "task_weights": [round(float(v), 4) for v in w.tolist()],
         }
+        if per_rank is not None:
+            result["per_rank"] = per_rank["rates"]
+            result["allreduce_exposed_ms_per_step"] = per_rank["aux"]
+            result["allreduce_exposed_ms_per_step"]["what"] = (
+                "time the main stream sits idle in BucketedAllReduce.finish() until the last gradient bucket has arrived (two "
+                "timing events around the waits), mean over the timed steps, per rank: what the exchange adds to the step "
+                "beyond what ran under the backward")
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline_train(args.arch, S)
         print(json.dumps(result), flush=True)
@@ -350,8 +425,14 @@ def extra_sections(args, dev, net, frames, dec):
         res = {"what": f"DRN-D-54 (Bottleneck trunk) end to end, batch {B}, fused decode, one lane; people_vs_f32 = this "
                        "mode's people on the benchmark frames against the f32 pipeline's (same root / reproduced exactly)"}
         ref_people = None
-        for mode, key, steps in (("float32", "f32", 2), ("float16x3", "f16x3", 3), ("float16", "f16", 5), ("bfloat16", "bf16", 5)):
-            n54 = model.PoseProposalNet(drn.drn_d_54(), insize=(S, S), outsize=(S // 16, S // 16), compute_dtype=mode).cuda(dev)
+        # round 5: D-54's 16-bit POLICY is float16 behind an exact prefix up to layer4 (6.2 % of its FLOPs as f32 / float16x3
+        # launches): the CPU study tests/precision_study_d54.py (profiles/r05/precision_d54_*.txt) puts the 16-bit error of the
+        # Bottleneck trunk in the same place as D-22's -- the first layers -- only ~20x more amplified: same root 40 -> 71 of 77
+        # f32 people with that prefix (f16 tail), while no prefix below 24 % of the FLOPs rescues a bf16 tail (14 -> 46 -> 71)
+        for mode, key, steps, kw in (("float32", "f32", 2, {}), ("float16x3", "f16x3", 3, {}),
+                                     ("float16", "f16_exact_prefix4", 4, {"exact_prefix": 4}),
+                                     ("float16", "f16", 5, {}), ("bfloat16", "bf16", 5, {})):
+            n54 = model.PoseProposalNet(drn.drn_d_54(), insize=(S, S), outsize=(S // 16, S // 16), compute_dtype=mode, **kw).cuda(dev)
             n54.load_state_dict(sd54)
             d54_ = decode.Decoder(B, (S // 16, S // 16), (S, S), device=dev)
 
@@ -371,8 +452,11 @@ def extra_sections(args, dev, net, frames, dec):
                         "tflops": round(fl / dt / 1e12, 1),
                         "frac_of_mfma_peak": round(fl / dt / 1e12 / peak, 4) if mode != "float16x3" else None,
                         "people_vs_f32": {"f32_people": int(tot[0]), "reproduced_exactly": int(tot[1]),
-                                          "same_root": int(tot[2])},
+                                          "same_root": int(tot[2]), "same_root_frac": round(float(tot[2]) / max(int(tot[0]), 1), 4)},
                         "task_equivalent": bool(mode in ("float32", "float16x3") or tot[1] >= 0.85 * tot[0])}
+            if kw:
+                res[key]["policy"] = ("D-54's 16-bit policy: PoseProposalNet(drn_d_54(), compute_dtype='float16', exact_prefix=4) -- "
+                                      "stem + layer3 + layer4 exact; shipped because it lifts the same-root share above 0.90")
             del n54, d54_
             torch.cuda.empty_cache()
         return res
@@ -731,17 +815,20 @@ def main():
 
     def fence():
         torch.cuda.synchronize(dev)
+        t_local = time.perf_counter()                 # this rank's own GPU is done (before it waits for the others)
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(dev)
+        return t_local
 
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
     host_submit = time.perf_counter() - t0                      # this rank's host time enqueueing the K steps
-    fence()
+    t_local = fence()
     dt = time.perf_counter() - t0
+    per_rank = _per_rank_stats(dist, backend, dev, world, B * args.steps / (t_local - t0))
     if dist is not None:
         t = torch.tensor([dt, host_submit], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -886,6 +973,7 @@ def main():
                                               "(`pcie_inclusive` is the rate with both)",
                        "parallelism": f"frames sharded over {world} GPU(s), no data-path collective"},
             "rccl_ranks": world if (dist is not None and backend == "nccl") else (1 if world == 1 else 0),
+            **({"per_rank": per_rank["rates"]} if per_rank is not None else {}),
             "roofline": {"bound": "mfma", "kernel": dk, "launches_per_step": dn // reps,
                          "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4),
@@ -907,7 +995,8 @@ def main():
                                                 str((pmc_traffic(dk) or {}).get("source")) + " (file date " +
                                                 str((pmc_traffic(dk) or {}).get("date")) + "); bench.py cannot run the profiler on itself"),
                          "avg_launch_us": round(dms / dn * 1e3, 2),
-                         "flops_per_launch_avg": round(dfl / dn)},
+                         "flops_per_launch_avg": round(dfl / dn),
+                         **mfma_busy(dk, achieved, peak)},
             "step_tflops": round(fwd_flops / ms_per_step / 1e9, 2),      # conv FLOPs / whole-step time (lanes overlap)
             "conv_stack": {"ms": round(fwd_ms, 4), "tflops": round(fwd_flops / fwd_ms / 1e9, 2),
                            "frac_of_mfma_peak": round(fwd_flops / fwd_ms / 1e9 / peak, 4),

@@ -316,10 +316,18 @@ __global__ void __launch_bounds__(512, 2) block64_kernel(BlkArgs a, unsigned ten
             // the residual of this pixel tile, as INLINE ASM: hipcc puts s_waitcnt vmcnt(0) in front of every LDS read it knows of
             // that may alias an LDS-DMA target (role 0 fills this buffer) -- here that would wait for the stores just issued
             u32x2 rres[2];
+#ifdef PPN_B64_GLOBAL_RES
+            rres[0] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rrs, (int)obase, 0, 0));
+            rres[1] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rrs, (int)(obase == kOOB ? kOOB : obase + 32u), 0, 0));
+#elif defined(PPN_B64_PLAIN_RES)
+            rres[0] = *reinterpret_cast<const u32x2*>(smem + rbo + rk0 + (unsigned)(j * 16 * 128));
+            rres[1] = *reinterpret_cast<const u32x2*>(smem + rbo + rk1 + (unsigned)(j * 16 * 128));
+#else
             asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %3\n\ts_waitcnt lgkmcnt(0)"
                          : "=&v"(rres[0]), "=&v"(rres[1])
                          : "v"(lds_base + rbo + rk0 + (unsigned)(j * 16 * 128)), "v"(lds_base + rbo + rk1 + (unsigned)(j * 16 * 128))
                          : "memory");
+#endif
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 float v[4];

@@ -339,7 +339,19 @@ __global__ void __launch_bounds__(256, 2) stem012_kernel(Stem012Args a) {
                     asm volatile("ds_read_u8 %0, %1 offset:1" : "=v"(v[k][1]) : "v"(ad));
                     asm volatile("ds_read_u8 %0, %1 offset:2" : "=v"(v[k][2]) : "v"(ad));
                 }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                // The wait is TIED to the 15 values ("+v"): the reads are inline asm, so the compiler does not know that their
+                // results arrive later, and an untied s_waitcnt lets it schedule the first USE of a value (the table address
+                // below, the integer conversion) in front of the wait.  Round 4's batched reads did exactly that in the bf16
+                // instantiation: ~0.06 % of the stem's outputs differed from run to run (stale registers as table indices), the
+                // all-bf16 pipeline fell from 95 to 37-60 of the reference's 260 people and was no longer deterministic
+                // (tests/test_16bit_floors_gpu.py::test_every_16bit_configuration_is_deterministic).
+#define PPN_S012_WAIT15(v)                                                                                                   \
+    asm volatile("s_waitcnt lgkmcnt(0)"                                                                                     \
+                 : "+v"(v[0][0]), "+v"(v[0][1]), "+v"(v[0][2]), "+v"(v[1][0]), "+v"(v[1][1]), "+v"(v[1][2]), "+v"(v[2][0]),   \
+                   "+v"(v[2][1]), "+v"(v[2][2]), "+v"(v[3][0]), "+v"(v[3][1]), "+v"(v[3][2]), "+v"(v[4][0]), "+v"(v[4][1]),   \
+                   "+v"(v[4][2])::"memory")
+                static_assert(RI / 2 == 5, "PPN_S012_WAIT15 names 5 x 3 values");
+                PPN_S012_WAIT15(v);
                 if constexpr (!kExactIn) {
                     const unsigned lb = smem_base + (unsigned)(LDS_IN + LDS_L0 + LDS_L1 + LDS_RAW);
 #pragma unroll
@@ -349,7 +361,7 @@ __global__ void __launch_bounds__(256, 2) stem012_kernel(Stem012Args a) {
                             const unsigned ad = lb + 512 * c + 2 * v[k][c];
                             asm volatile("ds_read_u16 %0, %1" : "=v"(v[k][c]) : "v"(ad));
                         }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    PPN_S012_WAIT15(v);
                 }
 #pragma unroll
                 for (int k = 0; k < RI / 2; ++k) {

@@ -698,6 +698,19 @@ class PoseProposalNet:
         return [(name, self._lib.ppn_plan_kernel_name(plan.handle, i).decode(), float(ms[i]), fl)
                 for i, (name, fl) in enumerate(plan.entries)]
 
+    def half_range_report(self, frames: torch.Tensor) -> Dict[str, float]:
+        """max |value| / 65504 of every tensor a plan stores in IEEE half for these u8 frames (the bf16 mode's half PREFIX --
+        stem + layer3-4 -- and every tensor of the float16 mode).  Half stores CLAMP at +-65504 instead of overflowing
+        (csrc/conv_common.h clamp_f16), so a checkpoint whose early activations exceed that range saturates silently: a
+        value of 1.0 here says it did (tests/test_16bit_floors_gpu.py::test_half_prefix_saturates_at_65504); run such a
+        checkpoint with half_prefix=-1, stem_dtype="bfloat16" (pure bf16: the f32 exponent range) or in float32."""
+        self.forward_u8(frames)
+        b, h, w, _ = frames.shape
+        plan = self._get_plan(b, h, w, True)
+        torch.cuda.synchronize(self.device)
+        return {name: float(t.abs().max().item()) / 65504.0 for name, t in plan.buffers.items()
+                if isinstance(t, torch.Tensor) and t.dtype == torch.float16 and not name.endswith("#x3")}
+
     def graph_captures(self) -> Dict[tuple, int]:
         """How often each plan (batch, h, w, u8, fused, slot) has captured its launch sequence into a hipGraph."""
         return {k: int(self._lib.ppn_plan_graph_captures(p.handle)) for k, p in self._plans.items()}

@@ -618,10 +618,31 @@ class BucketedAllReduce:
             self.handles.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
             self.next += 1
 
+    # Exposed (non-overlapped) exchange time: BucketedAllReduce.measure = True makes finish() bracket its waits with two
+    # timing events on the current stream -- the time that stream sits idle until the last bucket has arrived, i.e. what the
+    # all-reduce adds to the step beyond what ran under the backward (bench.py --workload train --gpus N reports the mean).
+    measure = False
+    exposed_events: list = []
+
+    @classmethod
+    def exposed_ms(cls, reset: bool = True):
+        """Per finish() call since the last reset: milliseconds the issuing stream waited for the exchange."""
+        out = [a.elapsed_time(b) for a, b in cls.exposed_events]
+        if reset:
+            cls.exposed_events = []
+        return out
+
     def finish(self, before_issue=None) -> float:
         self.ready(0, before_issue)
+        timed = self.enabled and BucketedAllReduce.measure and self.flat.is_cuda
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         for h in self.handles:
             h.wait()
+        if timed:
+            e1.record()
+            BucketedAllReduce.exposed_events.append((e0, e1))
         self.handles, self.next = [], 0
         return 1.0 / self.world
 
