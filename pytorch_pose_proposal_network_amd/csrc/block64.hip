@@ -363,26 +363,55 @@ __global__ void __launch_bounds__(512, 2) block64_kernel(BlkArgs a, unsigned ten
     };
 
     // ---- the pipeline: phase p = conv1 of tile p (role 0) beside conv2 of tile p - 1 (role 1); one barrier per phase --------
+#ifdef PPN_CLOCK
+    unsigned long long ck_work = 0, ck_dma = 0, ck_bar = 0, ck_issue = 0;
+    const unsigned long long ck_begin = __builtin_amdgcn_s_memtime();
+#define B64_T(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#else
+#define B64_T(v) do { } while (0)
+#endif
     if (role == 0) issue_patch(first, 0);
     for (int p = 0; p <= n; ++p) {
         // role 0's patch of tile p has landed (its only outstanding memory operations); everyone's LDS traffic of the previous
         // phase is complete: the mid tile p - 1 is written, mid tile p - 2 and patch p - 1 are no longer read
+        B64_T(t0_);
         if (role == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        B64_T(t1_);
         lds_barrier();
+        B64_T(t2_);
         if (role == 0) {
             if (p + 1 < n) issue_patch(first + (p + 1) * G, (p + 1) & 1);
             if (p < n && a.res) issue_res(first + p * G, p & 1);      // read by role 1 in phase p + 1
+            B64_T(t3_);
             if (p < n) conv1_tile(first + p * G, p & 1);
+#ifdef PPN_CLOCK
+            ck_issue += t3_ - t2_; ck_work += __builtin_amdgcn_s_memtime() - t3_;
+#endif
         } else if (p >= 1) {
             conv2_tile(first + (p - 1) * G, (p - 1) & 1);
+#ifdef PPN_CLOCK
+            ck_work += __builtin_amdgcn_s_memtime() - t2_;
+#endif
         }
+#ifdef PPN_CLOCK
+        ck_dma += t1_ - t0_; ck_bar += t2_ - t1_;
+#endif
     }
+#ifdef PPN_CLOCK
+    if (lane == 0 && a.dbg) {
+        unsigned long long* d = a.dbg + ((size_t)blockIdx.x * 8 + wave) * 8;
+        d[0] = ck_work; d[1] = ck_dma; d[2] = ck_bar; d[3] = ck_issue; d[4] = n; d[5] = __builtin_amdgcn_s_memtime() - ck_begin;
+    }
+#endif
 }
 
 }  // namespace
 
 namespace ppn {
 
+#ifdef PPN_CLOCK
+static unsigned long long* g_block64_dbg = nullptr;   // tools/clock_block64.py: [workgroup][wave][8] u64
+#endif
 static int g_block64_on = -1;            // -1: not decided yet (PPN_BLOCK64=0 in the environment disables it)
 
 bool block64_enabled() {
@@ -418,7 +447,11 @@ int block64_launch(const ppn_block_desc* d, hipStream_t st, const char** kname) 
     a.n_tiles = (int)nt;
     a.div_tx = make_fastdiv((unsigned)a.tiles_x);
     a.div_tpi = make_fastdiv((unsigned)(a.tiles_x * a.tiles_y));
+#ifdef PPN_CLOCK
+    a.dbg = g_block64_dbg;
+#else
     a.dbg = nullptr;
+#endif
     static int n_cu = 0;
     if (!n_cu) {
         int dev = 0;
@@ -443,6 +476,9 @@ int block64_launch(const ppn_block_desc* d, hipStream_t st, const char** kname) 
 
 }  // namespace ppn
 
+#ifdef PPN_CLOCK
+extern "C" int ppn_block64_set_debug(void* p) { ppn::g_block64_dbg = static_cast<unsigned long long*>(p); return PPN_OK; }
+#endif
 extern "C" int ppn_basicblock64_fused(const ppn_block_desc* d, void* stream) {
     return ppn::block64_launch(d, static_cast<hipStream_t>(stream), nullptr);
 }

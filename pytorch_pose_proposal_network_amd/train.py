@@ -337,8 +337,26 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, stride: int = 1, dilation: int
         if add.shape != out.shape or add.dtype != x.dtype or not add.is_contiguous():
             raise ValueError("conv2d_nhwc: `add` must match the output")
         d.residual = add.data_ptr()
+    if _PREFETCH and key is not None:
+        # prefetch hint (ppn_conv_desc.prefetch): a training iteration launches the same convolutions in the same order on each
+        # stream, so the packed weight that FOLLOWED this one on this stream in the previous iteration is the one to pull into the
+        # Infinity Cache now (a wrong guess costs a few MB of reads, nothing else).  Only cached packs take part: their buffers
+        # live as long as their trainer's registration (unregister_param_storage clears the chain).
+        pp = packed.data_ptr()
+        prev = _chain_last.get(st)
+        if prev is not None and prev != pp:
+            _chain_next[(st, prev)] = (pp, packed.numel() * packed.element_size())
+        _chain_last[st] = pp
+        nxt = _chain_next.get((st, pp))
+        if nxt is not None:
+            d.prefetch, d.prefetch_bytes = nxt
     L.check(lib.ppn_conv2d_fused(C.byref(d), st), "ppn_conv2d_fused")
     return out
+
+
+_PREFETCH = os.environ.get("PPN_PREFETCH", "1") != "0"
+_chain_next: dict = {}              # (stream, packed weight) -> (packed weight launched next on that stream, bytes)
+_chain_last: dict = {}              # stream -> packed weight of its latest launch
 
 
 _zero_pages = {}
@@ -367,6 +385,8 @@ def unregister_param_storage(sp):
     for key in [k for k, v in _pack_cache.items() if v[2] == sp]:
         del _pack_cache[key]
     _pack_tables.clear()
+    _chain_next.clear()                 # no prefetch hint may outlive the buffers it points at
+    _chain_last.clear()
 
 
 def bump_param_version():
