@@ -331,6 +331,10 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, stride: int = 1, dilation: int
     d.ksize, d.stride, d.dilation, d.pad = k, stride, dilation, pad
     d.k_total, d.cout_pad, d.act1, d.out_nchw_f32 = ktot, cpad, act, 1 if nchw_f32 else 0
     d.src, d.weight, d.zero_page, d.out_raw = x.data_ptr(), packed.data_ptr(), zero.data_ptr(), out.data_ptr()
+    # input-gradient convolutions run beside the side stream's weight-gradient kernels: leave out the tiles that only shorten a
+    # LONE launch (PPN_CONV_SHARED_GPU: the 144 x 256 tile costs +19 % CU-time); PPN_TRAIN_SHARED=0 / 2: never / every convolution
+    if _TRAIN_SHARED == 2 or (_TRAIN_SHARED == 1 and dgrad_of):
+        d.flags = L.PPN_CONV_SHARED_GPU
     if bias is not None:
         d.shift1 = _f32(bias, cout, "bias")       # v = act(conv + bias)
     if add is not None:
@@ -355,6 +359,7 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, stride: int = 1, dilation: int
 
 
 _PREFETCH = os.environ.get("PPN_PREFETCH", "1") != "0"
+_TRAIN_SHARED = int(os.environ.get("PPN_TRAIN_SHARED", "1"))
 _chain_next: dict = {}              # (stream, packed weight) -> (packed weight launched next on that stream, bytes)
 _chain_last: dict = {}              # stream -> packed weight of its latest launch
 
