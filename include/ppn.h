@@ -342,6 +342,18 @@ typedef struct ppn_block_desc {
     void* out_raw;               /* or NULL */
     void* out_act;               /* or NULL */
     int32_t flags;               /* 0 */
+    /* stride 2 (round 5; 0 / 1 = the stride-1 block above): the FIRST block of layer3 (drn.py:168-190) -- conv1 is a 3x3
+     * stride-2 convolution from 32 channels, `src` = relu(bn1(x)) NHWC [batch][in_h][in_w][32], weight1 packed [64][w1_ld] with
+     * k = tap * 32 + ci (ppn_pack_weight k_order 0); the shortcut is bn_ds(conv1x1_stride2(x)): `proj_src` = x AT THE EVEN
+     * PIXELS, NHWC [batch][h][w][32] (what the fused stem writes under PPN_STEM_RAW_S2), proj_weight packed [64][proj_ld] with
+     * k = ci, proj_scale / proj_shift the folded BN; `residual` must be NULL.  Outputs [batch][h][w][64], h = (in_h - 1) / 2 + 1.
+     * Bit-identical to the three ppn_conv2d_fused launches it replaces (downsample, conv1, conv2 + residual). */
+    int32_t stride, in_h, in_w;
+    const void* proj_src;
+    const void* proj_weight;
+    const float* proj_scale;
+    const float* proj_shift;
+    int32_t w1_ld, proj_ld;
 } ppn_block_desc;
 int ppn_basicblock64_fused(const ppn_block_desc* d, void* stream);
 
@@ -455,6 +467,11 @@ int ppn_plan_add_stem012(ppn_plan* p, int32_t src_is_u8, const void* src, int32_
  * type; PPN_STEM_IO(PPN_F16, PPN_BF16) = IEEE-half operands and on-chip tensors, bf16 OUTPUT tensors (what the bf16 mode runs
  * since round 4: the stem's rounding noise is amplified by every layer behind it, csrc/stem012.hip). */
 #define PPN_STEM_IO(internal, out) ((internal) | (((out) + 1) << 8))
+/* PPN_STEM_RAW_S2 (or-ed into the dtype of the *_dt entry points; round 5): out_raw receives only the pixels with even row AND
+ * column, as NHWC [batch, (Ho + 1) / 2, (Wo + 1) / 2, 32] -- when the raw stem output's only reader is the first BasicBlock's
+ * 1x1 stride-2 projection (drn.py:53-54, 176-181), which reads exactly those pixels: 19 instead of 75 MB written at batch 32,
+ * and the projection becomes a stride-1 launch over a dense tensor instead of a gather of half-used 128-byte lines. */
+#define PPN_STEM_RAW_S2 (1 << 16)
 int ppn_stem012_dt(int32_t dtype, int32_t src_is_u8, const void* src, int32_t batch, int32_t h, int32_t w, const float* w0,
                    const float* scale0, const float* shift0, const float* mean, const float* std_, const float* w1,
                    const float* scale1, const float* shift1, const float* w2, const float* scale2, const float* shift2,

@@ -102,6 +102,7 @@ struct Stem012Args {
     void* out_raw;                      // NHWC bf16 [B,Ho,Wo,32] or NULL
     void* out_act;                      // NHWC bf16 [B,Ho,Wo,32] or NULL
     int B, H, W, Ho, Wo, src_is_u8;
+    int raw_s2;                         // PPN_STEM_RAW_S2: out_raw holds only the even (row, column) pixels, [B,(Ho+1)/2,(Wo+1)/2,32]
     float mean[3], stdv[3];
     int nstrips, nbands;
 };
@@ -548,7 +549,12 @@ __global__ void __launch_bounds__(256, 2) stem012_kernel(Stem012Args a) {
                             ou[r] = to_store<HO>(w2 > 0.f ? w2 : 0.f);          // next block's relu(bn1(x)) (drn.py:45-46)
                         }
                         const size_t o = pix * 32 + ct * 16 + 4 * g;
-                        if (a.out_raw) *reinterpret_cast<hox4*>(static_cast<HO*>(a.out_raw) + o) = ov;
+                        if (a.out_raw) {
+                            if (!a.raw_s2) *reinterpret_cast<hox4*>(static_cast<HO*>(a.out_raw) + o) = ov;
+                            else if (((oy | ox) & 1) == 0)      // the raw tensor's only reader is a 1x1 stride-2 convolution
+                                *reinterpret_cast<hox4*>(static_cast<HO*>(a.out_raw) + ((((size_t)b * ((a.Ho + 1) >> 1) + (oy >> 1)) *
+                                                         ((a.Wo + 1) >> 1) + (ox >> 1)) * 32 + ct * 16 + 4 * g)) = ov;
+                        }
                         if (a.out_act) *reinterpret_cast<hox4*>(static_cast<HO*>(a.out_act) + o) = ou;
                     }
                 }
@@ -616,7 +622,8 @@ int stem012_launch(int dtype, int src_is_u8, const void* src, int batch, int h, 
     static const int per_cu = getenv("PPN_S012_WGS") ? atoi(getenv("PPN_S012_WGS")) : 2;   // tuning knob
     const unsigned grid = (unsigned)(units < 256 * per_cu ? units : 256 * per_cu);   // persistent: 2 workgroups per CU
     // dtype: the stem's internal type in the low byte; PPN_STEM_IO(internal, out) adds a different OUTPUT storage type
-    const int din = dtype & 0xff, dout = (dtype >> 8) ? (dtype >> 8) - 1 : din;
+    const int din = dtype & 0xff, dout = ((dtype >> 8) & 0xff) ? ((dtype >> 8) & 0xff) - 1 : din;
+    a.raw_s2 = (dtype & PPN_STEM_RAW_S2) ? 1 : 0;
     if ((din != PPN_BF16 && din != PPN_F16) || (dout != PPN_BF16 && dout != PPN_F16) || (din == PPN_BF16 && dout != PPN_BF16))
         return fail(PPN_E_INVALID, "ppn_stem012: dtype must be PPN_BF16, PPN_F16 or PPN_STEM_IO(PPN_F16, PPN_BF16)");
     int rc;

@@ -13,6 +13,7 @@ PPN_MAX_KP = 32
 PPN_F32, PPN_BF16, PPN_F16, PPN_F16X3 = 0, 1, 2, 3
 PPN_CONV_NO_FILTER_BANK, PPN_CONV_SHARED_GPU, PPN_CONV_OUT_BF16, PPN_CONV_X3_PLAIN_OUT = 1, 2, 4, 8   # ppn_conv_desc.flags
 PPN_ACT_NONE, PPN_ACT_RELU, PPN_ACT_LRELU, PPN_ACT_SIGMOID = 0, 1, 2, 3
+PPN_STEM_RAW_S2 = 1 << 16           # ppn_*stem012_dt dtype flag: out_raw holds only the even (row, column) pixels
 
 
 class DecodeCfg(C.Structure):
@@ -51,6 +52,9 @@ class BlockDesc(C.Structure):
         ("shift_mid", C.c_void_p), ("act_mid", C.c_int32), ("weight2", C.c_void_p), ("scale1", C.c_void_p),
         ("shift1", C.c_void_p), ("act1", C.c_int32), ("scale2", C.c_void_p), ("shift2", C.c_void_p), ("act2", C.c_int32),
         ("out_raw", C.c_void_p), ("out_act", C.c_void_p), ("flags", C.c_int32),
+        ("stride", C.c_int32), ("in_h", C.c_int32), ("in_w", C.c_int32),
+        ("proj_src", C.c_void_p), ("proj_weight", C.c_void_p), ("proj_scale", C.c_void_p), ("proj_shift", C.c_void_p),
+        ("w1_ld", C.c_int32), ("proj_ld", C.c_int32),
     ]
 
 

@@ -374,6 +374,37 @@ class PoseProposalNet:
         return bool(outs) and all(o == odt for o in outs) and all(a in (A.ACT_NONE, A.ACT_RELU, A.ACT_LRELU)
                                                                   for a in (c1.act1, c2.act1, c2.act2))
 
+    def _block64_first(self, oi: int, store_dt, s2_tensor) -> bool:
+        """Do ops oi .. oi + 2 form layer3's first block -- 1x1 stride-2 projection of the (subsampled) raw stem output, conv1 3x3
+        stride 2 from 32 channels, conv2 64 -> 64 + the projection -- that csrc/block64.hip runs as one launch?"""
+        if not self.fuse_block or s2_tensor is None or oi + 2 >= len(self._ops):
+            return False
+        ds, c1, c2 = self._ops[oi], self._ops[oi + 1], self._ops[oi + 2]
+        odt = self._op_dtype(ds)
+        if odt not in (L.PPN_BF16, L.PPN_F16) or self._op_dtype(c1) != odt or self._op_dtype(c2) != odt:
+            return False
+        if not (ds.src == s2_tensor and ds.k == 1 and ds.stride == 2 and ds.cin == 32 and ds.cout == 64 and ds.out_raw and
+                not ds.out_act and ds.act1 == A.ACT_NONE and ds.bias is None and not ds.residual):
+            return False
+        if not (c1.cin == 32 and c1.cout == 64 and c1.k == 3 and c1.stride == 2 and c1.dilation == 1 and c1.pad == 1 and
+                c1.out_raw and not c1.out_act and not c1.residual and c1.bias is None and not c1.ds_src and
+                c1.src == self._ops[0].out_act):
+            return False
+        if not (c2.src == c1.out_raw and c2.residual == ds.out_raw and c2.cin == 64 and c2.cout == 64 and c2.k == 3 and
+                c2.stride == 1 and c2.dilation == 1 and c2.pad == 1 and not c2.ds_src and not c2.nchw_f32_out and
+                self._dev.get(c2.name + ".geom") == (576, 64)):
+            return False
+        for t_ in (ds.out_raw, c1.out_raw):                    # read by conv2 alone
+            if sum(1 for o in self._ops if t_ in (o.src, o.residual, o.ds_src)) != 1:
+                return False
+        for c in (ds, c1):                                     # tap-major packed rows [64][k_total]
+            _, _, korder, _, cpad = L.conv_tiling(odt, c.cin, c.cout, c.k)
+            if korder != 0 or cpad < 64:
+                return False
+        outs = [store_dt[n] for n in (c2.out_raw, c2.out_act) if n]
+        return bool(outs) and all(o == odt for o in outs) and all(a in (A.ACT_NONE, A.ACT_RELU, A.ACT_LRELU)
+                                                                  for a in (c1.act1, c2.act1, c2.act2))
+
     def _head_edge_pad(self) -> int:
         """Rows per edge of the edge-aligned limb tile (448) when the limb window fits it (385..448 values, e.g. the
         reference's 21 x 21), else 0: the chunked epilogue with atomicMax keys.  PPN_HEAD_EDGE=0 forces the latter."""
@@ -436,9 +467,21 @@ class PoseProposalNet:
                 assert rs <= {BF16}, f"{name}: a bf16 tensor read by {rs}"
                 store_dt[name] = BF16
         x3 = bool(need_split) or any(v == X3 for v in store_dt.values())       # the plan holds split launches
+        # round 5: when the fused stem's RAW output is read by nothing but the first BasicBlock's 1x1 stride-2 projection
+        # (drn.py:53-54), the stem writes only the pixels that projection reads (even row and column: PPN_STEM_RAW_S2) and the
+        # projection runs at stride 1 over the dense quarter-size tensor -- same values, 19 instead of 75 MB written and read
+        s2_tensor = None
+        stem = self._ops[0]
+        if (stem.k == 7 and stem.next_s2 is not None and stem.out_raw and os.environ.get("PPN_STEM_RAW_S2", "1") != "0"):
+            rd_ops = [o for o in self._ops if stem.out_raw in (o.src, o.residual, o.ds_src)]
+            if (len(rd_ops) == 1 and rd_ops[0].src == stem.out_raw and rd_ops[0].k == 1 and rd_ops[0].stride == 2 and
+                    rd_ops[0].pad == 0 and not rd_ops[0].ds_src and store_dt[stem.out_raw] in (BF16, F16)):
+                s2_tensor = stem.out_raw
         for name, (th, tw, tc) in shapes.items():
             if name == "input":
                 continue
+            if name == s2_tensor:
+                th, tw = (th + 1) // 2, (tw + 1) // 2
             if name == "head":
                 bufs[name] = torch.empty(batch, tc, th, tw, dtype=torch.float32, device=dev)
             elif store_dt[name] == X3:
@@ -488,6 +531,29 @@ class PoseProposalNet:
             nxt = self._ops[oi + 1] if oi + 1 < len(self._ops) else None
             nxt_w = None if nxt is None else self._dev.get(
                 nxt.name + (".w_unary" if (nxt.nchw_f32_out and edge_head) else ".w"))
+            if self._block64_first(oi, store_dt, s2_tensor):
+                # layer3's FIRST block as one launch (csrc/block64.hip, stride 2): the 1x1 stride-2 projection + BN of the raw
+                # stem output (read at the even pixels the stem wrote), conv1 3x3 stride 2 from the pre-activated stem output,
+                # bn2 + ReLU, conv2 + shortcut, second output.  Bit-identical to the three launches.
+                ds, c1, c2 = self._ops[oi], self._ops[oi + 1], self._ops[oi + 2]
+                skip.update((oi + 1, oi + 2))
+                entries[-1] = (f"{ds.name}+conv1+conv2", sum(A.op_flops(o, shapes) for o in (ds, c1, c2)) * batch)
+                ih1, iw1, _ = shapes[c1.src]
+                oh1, ow1 = A.out_hw(c1, ih1, iw1)
+                bd = L.BlockDesc()
+                bd.dtype, bd.batch, bd.h, bd.w, bd.channels, bd.stride, bd.in_h, bd.in_w = odt, batch, oh1, ow1, 64, 2, ih1, iw1
+                bd.src, bd.proj_src = rd(c1.src, odt).data_ptr(), bufs[ds.src].data_ptr()
+                bd.weight1, bd.w1_ld = self._ptr(c1.name + ".w"), self._dev[c1.name + ".geom"][0]
+                bd.scale_mid, bd.shift_mid, bd.act_mid = self._ptr(c1.name + ".s1"), self._ptr(c1.name + ".b1"), c1.act1
+                bd.proj_weight, bd.proj_ld = self._ptr(ds.name + ".w"), self._dev[ds.name + ".geom"][0]
+                bd.proj_scale, bd.proj_shift = self._ptr(ds.name + ".s1"), self._ptr(ds.name + ".b1")
+                bd.weight2, bd.scale1, bd.shift1, bd.act1 = (self._ptr(c2.name + ".w"), self._ptr(c2.name + ".s1"),
+                                                             self._ptr(c2.name + ".b1"), c2.act1)
+                bd.scale2, bd.shift2, bd.act2 = self._ptr(c2.name + ".s2"), self._ptr(c2.name + ".b2"), c2.act2
+                bd.out_raw = bufs[c2.out_raw].data_ptr() if c2.out_raw else None
+                bd.out_act = bufs[c2.out_act].data_ptr() if c2.out_act else None
+                L.check(lib.ppn_plan_add_block(handle, C.byref(bd)), f"ppn_plan_add_block({ds.name})")
+                continue
             if self._block64_pair(oi, store_dt):
                 # a whole 64-channel stride-1 BasicBlock as ONE launch (csrc/block64.hip, round 5): conv1 -> bn2 -> ReLU -> conv2
                 # (+ x, second output); the tensor between the convolutions stays in LDS.  Bit-identical to the two launches.
@@ -512,6 +578,8 @@ class PoseProposalNet:
                 sdt = self.stem_dtype if self.stem_dtype is not None else self.compute_dtype
                 if sdt != out_dt:
                     sdt = sdt | ((out_dt + 1) << 8)                                  # PPN_STEM_IO(internal, out)
+                if s2_tensor is not None:
+                    sdt = sdt | L.PPN_STEM_RAW_S2
                 L.check(lib.ppn_plan_add_stem012_dt(handle, sdt, 1 if src_is_u8 else 0, src.data_ptr(), batch, h, w,
                                                  self._ptr(op.name + ".w"), self._ptr(op.name + ".s1"),
                                                  self._ptr(op.name + ".b1"), self._mean, self._std,
@@ -558,6 +626,8 @@ class PoseProposalNet:
             d.batch, d.in_h, d.in_w, d.cin = batch, ih, iw, op.cin
             d.out_h, d.out_w, d.cout = oh, ow, op.cout
             d.ksize, d.stride, d.dilation, d.pad = op.k, op.stride, op.dilation, op.pad
+            if op.src == s2_tensor:                  # the stem wrote only the pixels this 1x1 stride-2 projection reads
+                d.in_h, d.in_w, d.stride = (ih + 1) // 2, (iw + 1) // 2, 1
             d.k_total, d.cout_pad = self._dev[op.name + ".geom"]
             d.act1, d.act2 = op.act1, op.act2
             d.out_nchw_f32 = 1 if op.nchw_f32_out else 0
