@@ -312,3 +312,43 @@ def test_per_launch_dtype_policies_of_the_inference_modes():
     # Bottleneck trunks lower the same way
     d54 = model.PoseProposalNet("drn_d_54", compute_dtype="bfloat16")
     assert d54._op_dtype(d54._ops[-1]) == L.PPN_BF16 and d54._op_dtype(d54._ops[0]) == L.PPN_F16
+
+
+_PER_RANK_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as dist
+import bench
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+r = bench._per_rank_stats(dist, "gloo", torch.device("cpu"), world, 1000.0 * (rank + 1), 0.25 * (rank + 1))
+if rank == 0:
+    print("RESULT", r)
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def test_per_rank_statistics_of_the_bench_line(tmp_path):
+    """bench.py N > 1 (round 5): every rank's own rate and one auxiliary per-rank number (training: the exposed all-reduce time)
+    are gathered on all ranks, so a straggler or a rank that fell back is visible -- rehearsed with 3 gloo ranks on CPU
+    (/root/reference/main.py:240-245,769-771 is the DDP set-up whose exchange this instruments)."""
+    script = tmp_path / "worker.py"
+    script.write_text(_PER_RANK_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29641", WORLD_SIZE="3")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(3)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    r = eval([l for l in outs[0].splitlines() if l.startswith("RESULT")][0][len("RESULT "):])
+    assert r["rates"]["ranks"] == [1000.0, 2000.0, 3000.0] and (r["rates"]["min"], r["rates"]["median"], r["rates"]["max"]) == (1000.0, 2000.0, 3000.0)
+    assert r["aux"]["ranks"] == [0.25, 0.5, 0.75] and r["aux"]["max"] == 0.75
+
+
+def test_mfma_busy_constants_resolve_for_the_dominant_kernel():
+    """roofline.mfma_busy / frac_of_held_clock_peak (round 5) are committed constants with provenance: the newest
+    profiles/r*_mfma_busy.json must hold the benchmarked kernel and a held clock."""
+    import bench
+    r = bench.mfma_busy("conv_igemm_big_kernel<__bf16, 192, 256, 8, false>", 1250.0, 2500.0)
+    assert 0.3 < r["mfma_busy"] < 0.9 and 0.2 < r["mfma_busy_conv_stack"] < 0.9
+    assert 1.5 < r["held_clock_ghz"] < 2.5 and abs(r["frac_of_held_clock_peak"] - 0.5 * 2.4 / r["held_clock_ghz"]) < 1e-3
+    assert "tools/pmc_mfma.sh" in r["mfma_busy_provenance"]
