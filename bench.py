@@ -728,9 +728,12 @@ def main():
                     help="skip the extra sections (materialized_head, decode_stress, f32_parity_mode, d54_end_to_end, "
                          "train_shard) reported beside the headline at N=1")
     ap.add_argument("--layers", action="store_true", help="print the per-layer table to stderr")
-    ap.add_argument("--lanes", type=int, default=int(os.environ.get("PPN_LANES", "3")),
+    ap.add_argument("--lanes", type=int, default=int(os.environ.get("PPN_LANES", "2")),
                     help="stream lanes successive steps alternate between (rt.MultiLaneInference); 1 = one lane with "
-                         "the same kernels (what the rocprofv3 per-kernel durations are compared with)")
+                         "the same kernels (what the rocprofv3 per-kernel durations are compared with).  Default 2 since round 5: "
+                         "with the weight-prefetch hint and the persistent one-launch BasicBlocks two lanes run 11.4 k images/s "
+                         "where three run 11.15-11.2 k (three interleaved pairs on one box, profiles/r05/lanes_x_policy.txt); "
+                         "rounds 2-4 ran three")
     ap.add_argument("--shared-plan", action="store_true",
                     help="with --lanes 1: run the MULTI-lane plan (generic 64 -> 64 kernel, no lone-launch tiles) with one launch in "
                          "flight -- profiler runs, so that per-kernel durations describe the kernels the multi-lane headline runs")

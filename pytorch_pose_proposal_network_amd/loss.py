@@ -21,6 +21,7 @@ from . import config as cfg
 from . import lib as L
 
 _LIMB_COMPACT = os.environ.get("PPN_LOSS_COMPACT_TARGETS", "1") != "0"      # A/B switch: read te / weight_ij as f32
+_CHECK_LIMB_C = os.environ.get("PPN_CHECK_LIMB_C", "0") == "1"
 
 TARGET_KEYS = ("delta", "weight", "weight_ij", "tx_half", "ty_half", "tx", "ty", "tw", "th", "te")
 
@@ -206,6 +207,16 @@ class PPNLoss:
         if (lc.dtype != torch.uint8 or tuple(lc.shape) != (B, c.E, c.sH, c.sW, c.H, c.W) or not lc.is_cuda or
                 not lc.is_contiguous()):
             raise ValueError("targets['limb_c'] must be a contiguous uint8 CUDA tensor of te's shape")
+        # `limb_c` is DERIVED from te / weight_ij (bit 0: te == 1, bit 1: weight_ij == 1; targets.encode_targets writes all three)
+        # and must be dropped from the dict whenever either is edited or replaced: the kernels that stream it never look at the
+        # f32 maps, the GradNorm probes and the untrusted fallback do.  PPN_CHECK_LIMB_C=1 verifies the agreement on every call
+        # (two full-size comparisons: a debugging aid, not for timed runs).
+        if _CHECK_LIMB_C:
+            te, wij = targets["te"], targets["weight_ij"]
+            want = (te == 1).to(torch.uint8) | ((wij == 1).to(torch.uint8) << 1)
+            if not torch.equal(want, lc) or bool(((te != 0) & (te != 1)).any()):
+                raise ValueError("targets['limb_c'] does not agree with targets['te'] / ['weight_ij'] (edited after "
+                                 "encode_targets? drop 'limb_c' from the dict)")
         return lc
 
     def limb_dual_nhwc(self, feature_map: torch.Tensor, tz: torch.Tensor, targets: Dict[str, torch.Tensor], c4: float,

@@ -192,6 +192,9 @@ class MultiLaneInference:
         # profiler run needs so that its per-kernel durations describe the kernels the multi-lane headline ran
         shared = lanes > 1 if shared_plan is None else bool(shared_plan)
         self._conv_flags = (L.PPN_CONV_NO_FILTER_BANK | L.PPN_CONV_SHARED_GPU) if shared else 0
+        import os
+        if shared and os.environ.get("PPN_LANES_LONE_TILES") == "1":      # A/B knob: keep the tiles that shorten a lone launch
+            self._conv_flags = L.PPN_CONV_NO_FILTER_BANK
 
     def close(self):
         from . import lib as L

@@ -442,29 +442,35 @@ class PPNTrainer:
         # v_i divided on the device; the host then waits for the 17 floats (pinned, asynchronous copy) while the GPU
         # works through ~1.5 ms of tangent convolutions, and enqueues the reverse half behind them.  If the host values
         # say otherwise (a stream inactive, the limb remainder untrusted: rare), the speculative tensors are dropped and
-        # the tangents are rebuilt for the streams that are active -- the results are those of the non-speculative order.
+        # the tangents are rebuilt for the streams that are active -- bitwise the results of the non-speculative order (both multiply by
+        # the SAME device-computed reciprocal, see inv_dev).
         total = self.G["conv1.weight"]
         trusted = coeff[4] > 1e-3 * max(coeff)
         spec = None
         if trusted:
             gw4, st = T.probe_stats(gw, total.contiguous(), coeff)
-            dev_vec = torch.cat([st, so["losses"].reshape(5), self.base.reshape(5)])
+            # 1 / ||g_i|| is computed ONCE, on the device, and travels to the host with the other scalars: the speculative
+            # tangents (g_i * inv_i with the device value) and the rebuilt ones (g_i * inv_i with the same bits read back) are then
+            # bitwise equal, so whether a step keeps its speculation never changes its result
+            inv_dev = torch.reciprocal(torch.sqrt(st[:5]))
+            dev_vec = torch.cat([st, so["losses"].reshape(5), self.base.reshape(5), inv_dev])
             if self._so_pin is None:
-                self._so_pin = torch.empty(17, dtype=torch.float32, pin_memory=True)
+                self._so_pin = torch.empty(22, dtype=torch.float32, pin_memory=True)
             self._so_pin.copy_(dev_vec, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(main)
             if self._speculate_tail:
-                gn_dev = torch.sqrt(st[:5])
-                spec = self._tail_tangents(c, [(g / gn_dev[i]) for i, g in enumerate(gw + [gw4])], list(range(5)))
+                spec = self._tail_tangents(c, [(g * inv_dev[i]) for i, g in enumerate(gw + [gw4])], list(range(5)))
             ev.synchronize()
             host = self._so_pin.tolist()
             if self.compute_dtype != L.PPN_F32:
                 # bf16: `total` and the unary probes come from differently rounded passes (relative noise ~2^-8 each);
                 # a remainder that is not clearly above that noise cannot be trusted (see _limb_probe)
                 trusted = host[5] > (16.0 * 2.0 ** -8) ** 2 * host[6]
+        inv_h = None
         if trusted:
             ss = host[:5]
+            inv_h = host[17:22]
             gw.append(gw4)
         else:
             spec = None
@@ -493,7 +499,9 @@ class PPNTrainer:
             return None, None
         n = len(act)
         if spec is None or act != [0, 1, 2, 3, 4]:
-            spec = self._tail_tangents(c, [(gw[i] / gn_h[i]).contiguous() for i in act], act)
+            if inv_h is None:                                     # (the untrusted path has no device reciprocals: exact host ones)
+                inv_h = [float(f32(1.0) / f32(v)) if v != 0.0 else 0.0 for v in gn_h]
+            spec = self._tail_tangents(c, [(gw[i] * inv_h[i]).contiguous() for i in act], act)
         vs, u2, TH2, TA3, TC2, TH3, tz_groups = spec
 
         # ---- head space per stream: gradient and Hessian-vector product of loss i through the sigmoid.  The unary
