@@ -976,7 +976,12 @@ bool big_tile_for(int cout, long long m, BigTile* out, int ksteps, bool shared_g
         // (round 4, measured and dropped: under PPN_CONV_SHARED_GPU, launches with fewer tiles than CUs -- the 24 x 24 layers --
         // priced by efficiency alone, i.e. 256 x 256 tiles on 144 of the CUs: 10.79 / 10.79 k images/s against 10.83 / 10.84 k
         // with the whole-round rule, interleaved runs on one box, and 3.25 vs 3.16 ms for the conv stack in sequence)
-        const double rounds = g_tile_policy == 1 ? (double)tiles / 256.0 : (double)((tiles + 255) / 256);
+        // PPN_POLICY1_MASK (experiment knob, with policy 1): bit 0 = 512-wide layers at >= 65 536 pixels, bit 1 = 512-wide below that,
+        // bit 2 = the narrower layers: which classes are priced by fractional rounds
+        static const int p1mask = getenv("PPN_POLICY1_MASK") ? atoi(getenv("PPN_POLICY1_MASK")) : 7;
+        const int cls = cout >= 512 ? (m >= 65536 ? 1 : 2) : 4;
+        const bool frac = g_tile_policy == 1 && (p1mask & cls);
+        const double rounds = frac ? (double)tiles / 256.0 : (double)((tiles + 255) / 256);
         const double cost = rounds * cd.bp * cd.bc / cd.eff;
         if (cost < best) { best = cost; out->bp = cd.bp; out->bc = cd.bc; }
     }

@@ -8,7 +8,7 @@ echo "[1/6] bench (unprofiled, with per-launch table and CPU baseline)"
 python3 $R/bench.py --layers > $O/bench.json 2> $O/bench_layers.txt
 echo "[2/6] rocprofv3 kernel stats of bench.py: one lane on the multi-lane plan (--shared-plan: per-dispatch durations comparable with the HIP-event table of the headline) and the default lanes"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras --no-verify --lanes 1 --shared-plan > $O/bench_profiled.json 2> $O/bench_profiled.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats2 -o bench2 -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras --no-verify > $O/bench_profiled_2lanes.json 2> $O/bench_profiled_2lanes.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats2 -o bench2 -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras --no-verify > $O/bench_profiled_lanes.json 2> $O/bench_profiled_lanes.err
 echo "[3/6] PMC pass FETCH_SIZE"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras --no-verify --lanes 1 --shared-plan > $O/fetch.json 2> $O/fetch.err
 echo "[4/6] PMC pass WRITE_SIZE"
@@ -36,5 +36,10 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/train_stats_so -o tra
 (cd $R && python3 tools/train_timeline.py $(find $O/train_stats_so -name "*kernel_trace.csv" | head -1)) > $O/train_timeline.txt 2>&1 || true
 (cd $R && python3 tools/host_timeline.py) 2>&1 | grep -v -i "warn\|amdgpu\|local_pass" > $O/train_host_timeline.txt || true
 python3 $R/tools/pmc_traffic_summary.py $O $O/pmc_traffic.json > $O/pmc_traffic.txt 2>&1 || true
+echo "[9] MFMA utilisation by counter (one SQ + GRBM pass over bench.py --lanes 1 --shared-plan): tools/pmc_mfma.sh"
+(cd $R && bash tools/pmc_mfma.sh $T/pmc_mfma > $O/pmc_mfma.log 2>&1 && cp $O/pmc_mfma/mfma_busy.txt $O/mfma_busy.txt && cp $O/pmc_mfma/mfma_busy.json $O/mfma_busy.json) || true
+echo "[10] in sequence vs back to back (tools/clock_conv_seq.py, -DPPN_CLOCK=2 build) and the one-launch BasicBlock's phase stamps"
+if [ -f $R/tools/bin/libppn_clock2.so ]; then (cd $R && python3 tools/clock_conv_seq.py) 2>&1 | grep -v amdgpu.ids > $O/conv_in_sequence.txt || true; fi
+if [ -f $R/tools/bin/libppn_clockb64.so ]; then (cd $R && python3 tools/clock_block64.py) 2>&1 | grep -v amdgpu.ids > $O/block64_clock.txt || true; fi
 find $O -name "*.csv" -size +3M -delete
 echo done
