@@ -649,6 +649,7 @@ def extra_sections(args, dev, net, frames, dec):
         try:
             for _ in range(3 * lanes):
                 pipe1.submit(frames)
+            torch.cuda.synchronize(dev)
             dts = sorted(_time_steps(lambda: pipe1.submit(frames), dev, 20, warmup=3) for _ in range(3))
             last = pipe1.submit(frames)
             pipe1.flush()

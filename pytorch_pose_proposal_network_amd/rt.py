@@ -159,6 +159,24 @@ class InferencePipeline:
         self.side.synchronize()
 
 
+_LANE_STREAMS: dict = {}
+
+
+def _lane_streams(dev, lanes: int):
+    """The lane streams of a device, created once per process and shared by every MultiLaneInference on it.  The runtime maps
+    streams onto a handful of hardware queues (four by default); a pipeline whose lanes get fresh streams late in a process can
+    find two of them on ONE queue, i.e. serialised: bench.py's `tile_policy_1` section, the third pipeline of its process, ran its
+    two lanes at the one-lane rate (9.5 k instead of 11.6 k images/s, round 5).  Pipelines on the same device therefore reuse the
+    first `lanes` streams of one pool (correct for any use -- a stream orders its work -- and what a server wants anyway)."""
+    key = torch.device(dev)
+    if key.index is None:
+        key = torch.device(key.type, torch.cuda.current_device())
+    pool = _LANE_STREAMS.setdefault(key, [])
+    while len(pool) < lanes:
+        pool.append(torch.cuda.Stream(device=key))
+    return pool[:lanes]
+
+
 class MultiLaneInference:
     """Independent inference lanes on separate HIP streams, batches go round-robin: while one lane is in a
     launch that cannot fill the GPU (the 14-22 us neck convolutions, the last partial round of workgroups of a
@@ -173,7 +191,7 @@ class MultiLaneInference:
         h, w = insize_hw[0] // 16, insize_hw[1] // 16
         self.decoders = [D.Decoder(batch, (h, w), insize_hw, model.local_grid_size, detection_thresh, device=dev)
                          for _ in range(lanes)]
-        self.streams = [torch.cuda.Stream(device=dev) for _ in range(lanes)]
+        self.streams = _lane_streams(dev, lanes)
         self._stages = [None] * lanes                     # pinned read-back buffers, created on first use
         self.k = 0
         # tile_policy 1: conv tiles chosen by efficiency alone instead of whole rounds of workgroups (process-wide
