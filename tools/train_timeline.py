@@ -46,3 +46,25 @@ gaps = [(round((a['e'] - T0) / 1e6, 2), round((b['s'] - a['e']) / 1e3), short(a[
 print(f"main-stream gaps: {sum(max(0, b['s'] - a['e']) for a, b in zip(main, main[1:])) / 1e6:.3f} ms in all; {len(gaps)} above 15 us = {sum(g[1] for g in gaps)} us:")
 for g in gaps:
     print("   at %.2f ms: %4d us  after %s, before %s" % g)
+
+if len(sys.argv) > 2 and sys.argv[2] == '--small':
+    # every launch of the named families on the main stream with its neighbours: where do the copies / repacks / tiny kernels sit?
+    fam = sys.argv[3].split(',') if len(sys.argv) > 3 else ['copyBuffer', 'pack_weight', 'elementwise', 'reduce_kernel', 'Fill', 'Cat']
+    per = collections.Counter(); tot = collections.Counter()
+    for r in it:
+        k = short(r['Kernel_Name']); per[(k, r['Queue_Id'] == mq)] += 1; tot[(k, r['Queue_Id'] == mq)] += (r['e'] - r['s']) / 1e3
+    print("launches per iteration by family (main stream / other streams):")
+    for (k, m), n in sorted(per.items(), key=lambda kv: -tot[kv[0]]):
+        print(f"   {k:26s} {'main ' if m else 'other'} {n:4d} launches {tot[(k, m)]:8.1f} us")
+    print("named families, in order, with the launch before and after on the same queue:")
+    byq = collections.defaultdict(list)
+    for r in it:
+        byq[r['Queue_Id']].append(r)
+    for q, sub in byq.items():
+        for i, r in enumerate(sub):
+            k = short(r['Kernel_Name'])
+            if k in fam:
+                a = short(sub[i - 1]['Kernel_Name']) if i else '-'
+                b = short(sub[i + 1]['Kernel_Name']) if i + 1 < len(sub) else '-'
+                gap = (r['s'] - sub[i - 1]['e']) / 1e3 if i else 0
+                print(f"   q{q} {(r['s'] - T0) / 1e6:7.3f} ms {k:14s} {(r['e'] - r['s']) / 1e3:6.1f} us (gap before {gap:5.1f}) after {a}, before {b}")
