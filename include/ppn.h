@@ -286,6 +286,20 @@ typedef struct ppn_conv_desc {
      * Results do not depend on it.  NULL / 0: none. */
     const void* prefetch;
     int64_t prefetch_bytes;
+    /* Train-mode BatchNorm statistics from this launch's epilogue (round 5; large-tile kernel, 16-bit single-output NHWC launches
+     * without a residual -- elsewhere the launch runs as usual and reports 0 tiles).  Each pixel tile folds, per output channel,
+     * two sums over ITS pixels of the values it stores (v, after rounding to the tensor's type) and writes them as f64 pairs
+     * stats_partial[(tile * cout + c) * 2 + {0, 1}] -- the layout ppn_bn_train_fwd / ppn_bn_train_bwd fold their own reduction
+     * pass from, so that pass is skipped (ppn_bn_desc.stats_blocks):
+     *   stats_mode 1 (the convolution that FEEDS a BatchNorm, drn.py:47-63):   { sum v, sum v^2 }
+     *   stats_mode 2 (the input-gradient convolution whose result is dy of a BatchNorm + activation over stats_x):
+     *                { sum g, sum g * xhat },  g = v * act'(x * gamma * rstd + beta - mean * gamma * rstd),  xhat = (x - mean) * rstd
+     * *stats_tiles (HOST int) receives the number of pixel tiles written, 0 if this launch does not produce statistics. */
+    void* stats_partial;
+    int32_t stats_mode, stats_act;
+    const void* stats_x;                       /* mode 2: the BatchNorm's input, NHWC like this launch's output */
+    const float *stats_gamma, *stats_beta, *stats_mean, *stats_rstd;
+    int32_t* stats_tiles;
 } ppn_conv_desc;
 #define PPN_CONV_NO_FILTER_BANK 1
 /* PPN_CONV_SHARED_GPU: this launch runs beside other streams' launches (rt.MultiLaneInference): the tile chooser then
@@ -563,6 +577,9 @@ typedef struct ppn_bn_desc {
     float* shift;
     void* y;
     void* workspace;              /* >= ppn_bn_workspace_bytes(channels) */
+    /* > 0: the workspace already holds that many blocks of partial sums { sum x, sum x^2 } per channel, written by the
+     * convolution that produced x (ppn_conv_desc.stats_mode 1, *stats_tiles): the reduction pass over x is skipped. */
+    int32_t stats_blocks;
 } ppn_bn_desc;
 
 size_t ppn_bn_workspace_bytes(int32_t channels);
@@ -590,6 +607,9 @@ typedef struct ppn_bn_bwd_desc {
     float* dbeta;
     void* dx;
     void* workspace;              /* >= ppn_bn_workspace_bytes(channels) */
+    /* > 0: the workspace already holds that many blocks of { sum g, sum g * xhat } per channel, written by the input-gradient
+     * convolution that produced dy (ppn_conv_desc.stats_mode 2): the reduction pass over x and dy is skipped (single stream only). */
+    int32_t stats_blocks;
 } ppn_bn_bwd_desc;
 
 int ppn_bn_train_bwd(const ppn_bn_bwd_desc* d, void* stream);

@@ -557,6 +557,15 @@ extern "C" int ppn_conv_tiling(int32_t dtype, int32_t cin, int32_t cout, int32_t
 
 int ppn::conv_launch(const ppn_conv_desc* d, hipStream_t st, const char** kname) {
     if (!d) return ppn::fail(PPN_E_INVALID, "conv desc is NULL");
+    if (d->stats_mode != 0) {
+        // BatchNorm statistics from the epilogue: a request, not a demand -- *stats_tiles says whether this launch delivered
+        if (d->stats_mode < 1 || d->stats_mode > 2 || !d->stats_partial || !d->stats_tiles)
+            return ppn::fail(PPN_E_INVALID, "stats_mode 1 or 2 needs stats_partial and stats_tiles");
+        if (d->stats_mode == 2 && (!d->stats_x || !d->stats_gamma || !d->stats_beta || !d->stats_mean || !d->stats_rstd ||
+                                   d->stats_act < PPN_ACT_NONE || d->stats_act > PPN_ACT_LRELU))
+            return ppn::fail(PPN_E_INVALID, "stats_mode 2 needs stats_x, gamma, beta, mean, rstd and act none / relu / lrelu");
+        *d->stats_tiles = 0;
+    }
     if (d->dtype != PPN_F32 && d->dtype != PPN_BF16 && d->dtype != PPN_F16 && d->dtype != PPN_F16X3)
         return ppn::fail(PPN_E_INVALID, "bad dtype %d", d->dtype);
     const bool x3 = d->dtype == PPN_F16X3;
@@ -612,7 +621,7 @@ int ppn::conv_launch(const ppn_conv_desc* d, hipStream_t st, const char** kname)
         if (d->out_nchw_f32 && ((d->out_h * d->out_w) & 3) == 0 && ((m_lo & 3) != 0 || ((m_hi & 3) != 0 && m_hi != m_all)))
             return ppn::fail(PPN_E_INVALID, "NCHW output: pixel range [%d, +%d) must begin on a multiple of 4 and end on one "
                                             "(or at the last pixel)", d->m_begin, d->m_count);
-    } else if (!smallc) {
+    } else if (!smallc && d->stats_mode == 0) {
         // whole tensor: two launches with different tiles where that saves a round of workgroups (ppn_conv_split)
         const long long cut = big_split_for(d->cout, m_all);
         if (cut > 0 && cut < m_all) {
@@ -702,6 +711,18 @@ int ppn::conv_launch(const ppn_conv_desc* d, hipStream_t st, const char** kname)
     a.pf_lines = (d->prefetch && d->prefetch_bytes > 0) ? (unsigned)std::min<long long>(d->prefetch_bytes / 128, 1 << 24) : 0u;
     a.pf_per_wg = 0;                                                  // set by launch_big (it knows the grid)
     a.out_bf16 = (d->flags & PPN_CONV_OUT_BF16) ? 1 : 0;
+    a.st_partial = nullptr; a.st_mode = 0; a.st_act = 0; a.st_x = nullptr;
+    a.st_gamma = a.st_beta = a.st_mean = a.st_rstd = nullptr;
+    if (d->stats_mode != 0 && big && big_stats_ok(d->dtype, bt) && !d->out_nchw_f32 && !d->residual && !d->out_act && d->out_raw &&
+        d->cout % 8 == 0 && !a.out_bf16 && !d->src2 && !d->argmax_keys && d->m_count == 0 && a.n_ptiles <= 1024) {
+        // the conditions of the single-output 16-bit epilogue (conv_big.hip `fast`) + one launch over the whole tensor +
+        // no more pixel tiles than a BatchNorm workspace has partial blocks (train.hip kMaxBlocks)
+        a.st_partial = static_cast<double*>(d->stats_partial);
+        a.st_mode = d->stats_mode; a.st_act = d->stats_act;
+        a.st_x = static_cast<const char*>(d->stats_x);
+        a.st_gamma = d->stats_gamma; a.st_beta = d->stats_beta; a.st_mean = d->stats_mean; a.st_rstd = d->stats_rstd;
+        *d->stats_tiles = a.n_ptiles;
+    }
     if (a.out_bf16 && (d->dtype != PPN_F16 || !big || d->out_nchw_f32))
         return ppn::fail(PPN_E_UNSUPPORTED, "PPN_CONV_OUT_BF16: a PPN_F16 launch of the large-tile kernel with NHWC outputs");
     if (x3 && !big) return ppn::fail(PPN_E_UNSUPPORTED, "PPN_F16X3 is implemented by the large-tile kernel only");

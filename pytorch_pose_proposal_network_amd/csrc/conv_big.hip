@@ -30,6 +30,12 @@ namespace {
 
 using namespace ppnconv;
 
+// the tiles whose single-output 16-bit epilogue exists (the whole tile as 16-bit rows in the staging LDS) AND that carry the
+// BatchNorm-statistics instantiation: kFastFits of the kernel, restated for the host
+constexpr bool stats_tile_ok(int bp, int bc) {
+    return bc >= 128 && (size_t)bp * (size_t)(bc * 2 + 16) <= 2 * (size_t)(bp + bc) * 128;
+}
+
 // Build-time diagnostics (tools/build_variant.py NAME conv_big.hip -DPPN_DIAG=n): TIMING ONLY, results are wrong.
 //   1 = no wait for the DMA, 2 = no DMA in the K loop, 3 = 32x32x16 MFMAs (half the MFMA issue slots) on the same reads,
 //   4 = 2 and 3 together, 5 = 2 without the per-step barrier, 6 = 2 without the LDS fragment reads,
@@ -110,10 +116,15 @@ __device__ __forceinline__ void bufload_lds16(__amdgpu_buffer_rsrc_t rsrc, char*
 // (a_hi, w_hi), (a_hi, w_lo), (a_lo', w_hi * 2^-11) -- i.e. acc += a_hi w_hi + a_hi w_lo + a_lo w_hi in f32: products of
 // 22-bit operands minus the lo x lo term (2^-22 relative), at a third of the f16 MFMA rate = ~5x the exact-f32 MFMA rate.
 // Same loop, same staging: only the slab bookkeeping of advance() and the epilogue's loads / stores differ.
-template <typename T, int BP, int BC, int NW, bool SC, bool X3 = false>
-__global__ void __launch_bounds__(64 * NW, NW / 4)
+// ST: the single-output 16-bit epilogue additionally folds train-mode BatchNorm partial sums per pixel tile and channel
+// (ppn_conv_desc.stats_mode); its own instantiations, so the inference kernels are the code they were.
+// (the 192 x 128 tile runs two workgroups per CU = four waves per SIMD at 126 VGPRs; its ST twin came out at 129, i.e. ONE
+// workgroup per CU, so that instantiation states the four waves it needs)
+template <typename T, int BP, int BC, int NW, bool SC, bool X3 = false, bool ST = false>
+__global__ void __launch_bounds__(64 * NW, (ST && BP == 192 && BC == 128) ? 4 : NW / 4)
 conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
     static_assert(!X3 || (std::is_same<T, _Float16>::value && !SC), "X3 is the split-f16 mode without a fused shortcut");
+    static_assert(!ST || (sizeof(T) == 2 && !SC && !X3 && NW == 8 && BC >= 128), "ST: plain 16-bit launches of the 8-wave tiles");
     constexpr int EPC = Elem<T>::EPC;
     constexpr int BK = 8 * EPC;
     constexpr int ES = sizeof(T);
@@ -464,6 +475,9 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
 #else
     constexpr bool kFastFits = !X3 && sizeof(T) == 2 && BC >= 128 && (size_t)BP * RS16 <= 2 * (size_t)STAGE;
 #endif
+#ifndef PPN_NO_FAST_EPI
+    static_assert(!ST || kFastFits, "ST lives in the single-output 16-bit epilogue");
+#endif
     bool fast = false;
     if constexpr (kFastFits) fast = !a.nchw && !a.residual && !a.out_act && a.out_raw && (a.Cout & 7) == 0 && !a.out_bf16;
     if (fast) {
@@ -498,19 +512,132 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
                     store4<T>(smem + px * RS16 + chl * 2, v);
                 }
             }
-            lds_barrier();
             constexpr int CPR = BC / 8;                              // 16-byte chunks per tile row
             constexpr int NQ = BP * CPR / NT;                        // chunks per thread
             static_assert(BP * CPR % NT == 0, "tile must split into whole 16-byte chunks per thread");
             const size_t row_bytes = (size_t)a.Cout * 2;
+            // ---- ST: BatchNorm partial sums of this tile (ppn_conv_desc.stats_mode) ----------------------------------
+            // A thread stores the SAME 8 channels (chunk tid % CPR) of NQ pixels, so it folds them as it goes: mode 1
+            // {sum v, sum v^2}, mode 2 {sum g, sum g * xhat} with g = v * act'(x * sc + sh), xhat = (x - mean) * rstd over the
+            // BatchNorm input x at the same positions -- of the ROUNDED values v the tile stores, i.e. of what the separate
+            // reduction pass (train.hip bn_reduce_kernel) would read back.  Then: the 64 / CPR lanes of a wave that share a
+            // chunk (butterfly), the NW waves through LDS in wave order, one f64 pair per channel and tile -- a fixed order.
+            static_assert(!ST || NT % CPR == 0, "ST: a thread keeps its chunk column");
+            uint4 sx[ST ? NQ : 1];
+            float st_sc[8], st_sh[8], st_mu[8], st_rs[8], st_s0[8], st_s1[8];
+            float st_neg = 1.f;
+            const int st_mode = ST ? a.st_mode : 0;
+            // (every loop over the NQ chunks below is a static_for: a `#pragma unroll` loop with the sums inside stayed a loop and
+            // indexed sx[] through a branch ladder -- +9..26 us per launch)
+            if constexpr (ST) {
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) {
+                for (int j = 0; j < 8; ++j) st_s0[j] = st_s1[j] = 0.f;
+                if (st_mode == 2) {
+                    const int cc = tid % CPR, c = c0 + cc * 8;
+                    const bool vc = c < a.Cout;                      // Cout % 8 == 0: the whole chunk or nothing
+                    static_for<NQ>([&](auto qc) {
+                        constexpr int q = decltype(qc)::value;
+                        const int m = m0 + q * (NT / CPR) + tid / CPR;
+                        sx[q] = (vc && m < a.M) ? *reinterpret_cast<const uint4*>(a.st_x + (size_t)m * row_bytes + (size_t)c * 2)
+                                                : make_uint4(0u, 0u, 0u, 0u);
+                    });
+                    const int cb = vc ? c : 0;                       // 8 consecutive floats of each per-channel vector: 2 x 16 bytes
+                    float ga[8], be[8];
+                    auto vec8 = [&](const float* p, float* o) {
+                        if ((reinterpret_cast<size_t>(p) & 15) == 0) {
+                            const float4 lo = *reinterpret_cast<const float4*>(p + cb), hi = *reinterpret_cast<const float4*>(p + cb + 4);
+                            o[0] = lo.x; o[1] = lo.y; o[2] = lo.z; o[3] = lo.w; o[4] = hi.x; o[5] = hi.y; o[6] = hi.z; o[7] = hi.w;
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) o[j] = p[cb + j];
+                        }
+                    };
+                    vec8(a.st_mean, st_mu); vec8(a.st_rstd, st_rs); vec8(a.st_gamma, ga); vec8(a.st_beta, be);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        st_sc[j] = ga[j] * st_rs[j];
+                        st_sh[j] = be[j] - st_mu[j] * st_sc[j];
+                    }
+                    st_neg = a.st_act == PPN_ACT_RELU ? 0.f : (a.st_act == PPN_ACT_LRELU ? 0.1f : 1.f);
+                }
+            }
+            lds_barrier();
+            auto store_chunk = [&](auto qc, auto modec) {
+                constexpr int q = decltype(qc)::value;
+                constexpr int MODE = decltype(modec)::value;
                 const int id = q * NT + tid;
                 const int px = id / CPR, cc = id % CPR;
                 const int m = m0 + px, c = c0 + cc * 8;
                 if (m < a.M && c < a.Cout) {
                     const uint4 o = *reinterpret_cast<const uint4*>(smem + px * RS16 + cc * 16);
                     *reinterpret_cast<uint4*>(a.out_raw + (size_t)m * row_bytes + (size_t)c * 2) = o;
+                    if constexpr (MODE != 0) {
+                        float v[8];
+                        load8<T>(reinterpret_cast<const char*>(&o), v);
+                        if constexpr (MODE == 1) {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                st_s0[j] += v[j];
+                                st_s1[j] = fmaf(v[j], v[j], st_s1[j]);
+                            }
+                        } else {
+                            float x[8];
+                            load8<T>(reinterpret_cast<const char*>(&sx[q]), x);
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                const float z = fmaf(x[j], st_sc[j], st_sh[j]);
+                                const float g = v[j] * (z > 0.f ? 1.f : st_neg);
+                                const float xh = (x[j] - st_mu[j]) * st_rs[j];
+                                st_s0[j] += g;
+                                st_s1[j] = fmaf(g, xh, st_s1[j]);
+                            }
+                        }
+                    }
+                }
+            };
+            if constexpr (!ST) {                                     // the inference kernels: the loop they always had
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const int id = q * NT + tid;
+                    const int px = id / CPR, cc = id % CPR;
+                    const int m = m0 + px, c = c0 + cc * 8;
+                    if (m < a.M && c < a.Cout) {
+                        const uint4 o = *reinterpret_cast<const uint4*>(smem + px * RS16 + cc * 16);
+                        *reinterpret_cast<uint4*>(a.out_raw + (size_t)m * row_bytes + (size_t)c * 2) = o;
+                    }
+                }
+            } else {
+                if (st_mode == 0) static_for<NQ>([&](auto qc) { store_chunk(qc, std::integral_constant<int, 0>{}); });
+                if (st_mode == 1) static_for<NQ>([&](auto qc) { store_chunk(qc, std::integral_constant<int, 1>{}); });
+                if (st_mode == 2) static_for<NQ>([&](auto qc) { store_chunk(qc, std::integral_constant<int, 2>{}); });
+            }
+            if constexpr (ST) {
+                if (st_mode != 0) {
+#pragma unroll
+                    for (int off = 32; off >= CPR; off >>= 1)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            st_s0[j] += __shfl_xor(st_s0[j], off, 64);
+                            st_s1[j] += __shfl_xor(st_s1[j], off, 64);
+                        }
+                    lds_barrier();                                   // every wave has read its chunks of the tile: LDS is free
+                    float* red = reinterpret_cast<float*>(smem);     // [NW][CPR][16]
+                    if (lane < CPR) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            red[(wave * CPR + lane) * 16 + j] = st_s0[j];
+                            red[(wave * CPR + lane) * 16 + 8 + j] = st_s1[j];
+                        }
+                    }
+                    lds_barrier();
+                    if (tid < CPR * 16) {
+                        const int ccx = tid >> 4, j = tid & 15;
+                        double acc = 0.0;
+#pragma unroll
+                        for (int w = 0; w < NW; ++w) acc += (double)red[(w * CPR + ccx) * 16 + j];
+                        const int ch = c0 + ccx * 8 + (j & 7);
+                        if (ch < a.Cout) a.st_partial[((size_t)ptile * a.Cout + ch) * 2 + (j >> 3)] = acc;
+                    }
                 }
             }
         }
@@ -820,17 +947,17 @@ conv_igemm_big_kernel(ConvKArgs a, unsigned src_bytes, unsigned wgt_bytes) {
 #endif
 }
 
-template <typename T, int BP, int BC, int NW, bool SC, bool X3 = false>
+template <typename T, int BP, int BC, int NW, bool SC, bool X3 = false, bool ST = false>
 int launch_sc(const ConvKArgs& a, hipStream_t st, const char** kname) {
     constexpr size_t lds = 2 * (size_t)(BP + BC) * 128;
     static char name[96];
     if (!name[0])
         snprintf(name, sizeof(name), "conv_igemm_big_kernel<%s, %d, %d, %d, %s%s>", elem_name<T>(),
-                 BP, BC, NW, SC ? "true" : "false", X3 ? ", true" : "");
+                 BP, BC, NW, SC ? "true" : "false", X3 ? ", true" : (ST ? ", false, true" : ""));
     if (kname) *kname = name;
     const size_t src_bytes = (size_t)a.B * a.H * a.W * a.Cin * sizeof(T);
     const size_t wgt_bytes = (size_t)a.n_ctiles * BC * a.Ktot * sizeof(T);
-    auto k = conv_igemm_big_kernel<T, BP, BC, NW, SC, X3>;
+    auto k = conv_igemm_big_kernel<T, BP, BC, NW, SC, X3, ST>;
     {
         static int max_lds_set = 0;   // the attribute sticks to the function: set it when it grows
         PPN_LDS_ONCE(max_lds_set, reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -854,12 +981,23 @@ int launch_one(const ConvKArgs& a, hipStream_t st, const char** kname) {
     } else {
         if (a.src2) return ppn::fail(PPN_E_UNSUPPORTED, "fused shortcut needs the 8-wave 128/256-channel tiles");
     }
+    if (a.st_mode != 0) {                              // conv_launch only asks where stats_tile_ok() said yes
+        if constexpr (std::is_same<T, __bf16>::value && NW == 8 && stats_tile_ok(BP, BC))
+            return launch_sc<T, BP, BC, NW, false, false, true>(a, st, kname);
+        else
+            return ppn::fail(PPN_E_UNSUPPORTED, "BatchNorm statistics: no such instantiation of the large-tile kernel");
+    }
     return launch_sc<T, BP, BC, NW, false>(a, st, kname);
+}
+
+int conv_waves() {
+    static const int nw = getenv("PPN_CONV_WAVES") ? atoi(getenv("PPN_CONV_WAVES")) : 8;   // tuning knob
+    return nw;
 }
 
 template <typename T>
 int launch_T(const ConvKArgs& a, BigTile t, hipStream_t st, const char** kname) {
-    static const int nw = getenv("PPN_CONV_WAVES") ? atoi(getenv("PPN_CONV_WAVES")) : 8;   // tuning knob
+    const int nw = conv_waves();
     if (nw == 4 && t.bp != 144) {
         if (t.bc == 256) {
             if (t.bp == 256) return launch_one<T, 256, 256, 4>(a, st, kname);
@@ -1025,6 +1163,12 @@ long long big_split_for(int cout, long long m) {
         if (cost < best) { best = cost; cut = m1; }
     }
     return cut;
+}
+
+// Does a launch of this tile carry the BatchNorm-statistics epilogue (ppn_conv_desc.stats_mode)?  The caller (conv_launch) adds
+// the per-launch conditions of the single-output 16-bit epilogue.
+bool big_stats_ok(int dtype, BigTile t) {
+    return dtype == PPN_BF16 && conv_waves() == 8 && stats_tile_ok(t.bp, t.bc);
 }
 
 int launch_big(const ConvKArgs& a, int dtype, BigTile t, hipStream_t st, const char** kname) {

@@ -62,6 +62,11 @@ struct ConvKArgs {
     int out_plain;                    // PPN_F16X3 launch whose NHWC outputs are stored as plain half (PPN_CONV_X3_PLAIN_OUT)
     const char* pf_ptr;               // ppn_conv_desc.prefetch: the next launch's weights, touched line by line (large-tile kernel)
     unsigned pf_lines, pf_per_wg;     // 128-byte lines in all / per workgroup (at most 2 per thread)
+    // ppn_conv_desc.stats_*: BatchNorm partial sums from the epilogue (large-tile kernel, ST instantiations)
+    double* st_partial;
+    int st_mode, st_act;
+    const char* st_x;
+    const float *st_gamma, *st_beta, *st_mean, *st_rstd;
 };
 
 template <typename T>
@@ -199,5 +204,6 @@ bool big_tile_for(int cout, long long m, BigTile* out, int ksteps = 0, bool shar
 // tile, the rest a smaller tile that fills one more round (conv_big.hip).
 long long big_split_for(int cout, long long m);
 int launch_big(const ConvKArgs& a, int dtype, BigTile t, hipStream_t st, const char** kname);
+bool big_stats_ok(int dtype, BigTile t);   // the tile has the BatchNorm-statistics epilogue (ppn_conv_desc.stats_mode)
 
 }  // namespace ppnconv

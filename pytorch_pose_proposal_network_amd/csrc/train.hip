@@ -819,14 +819,18 @@ int ppn_bn_train_fwd(const ppn_bn_desc* d, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     double* partial = reinterpret_cast<double*>(d->workspace);
     const int C = d->channels;
-    if (d->dtype == PPN_F32)
+    if (d->stats_blocks < 0 || d->stats_blocks > kMaxBlocks)
+        return ppn::fail(PPN_E_INVALID, "ppn_bn_train_fwd: stats_blocks must be in [0, %d]", kMaxBlocks);
+    const int nfold = d->stats_blocks > 0 ? d->stats_blocks : s.nblocks;     // partials from the producing convolution's epilogue
+    if (d->stats_blocks > 0) {
+    } else if (d->dtype == PPN_F32)
         bn_reduce_kernel<float, 0><<<s.nblocks, kThreads, 0, st>>>((const float*)d->x, nullptr, nullptr, nullptr,
                                                                    nullptr, nullptr, 0, d->pixels, C, s, partial);
     else
         bn_reduce_kernel<__bf16, 0><<<s.nblocks, kThreads, 0, st>>>((const __bf16*)d->x, nullptr, nullptr, nullptr,
                                                                     nullptr, nullptr, 0, d->pixels, C, s, partial);
     PPN_LAUNCH_CHECK();
-    bn_fwd_finalize_kernel<<<(C + 3) / 4, 256, 0, st>>>(partial, s.nblocks, C, d->pixels, d->gamma, d->beta, d->eps,
+    bn_fwd_finalize_kernel<<<(C + 3) / 4, 256, 0, st>>>(partial, nfold, C, d->pixels, d->gamma, d->beta, d->eps,
                                                          d->momentum, d->running_mean, d->running_var, d->save_mean,
                                                          d->save_rstd, d->scale, d->shift);
     PPN_LAUNCH_CHECK();
@@ -860,7 +864,11 @@ static int bn_train_bwd_impl(const ppn_bn_bwd_desc* d, int nstreams, void* strea
     float* coef = reinterpret_cast<float*>(reinterpret_cast<char*>(d->workspace) +
                                            (size_t)nstreams * pstride * sizeof(double));
     const dim3 grid(s.nblocks, nstreams), fgrid((C + 3) / 4, nstreams);
-    if (d->dtype == PPN_F32)
+    if (d->stats_blocks < 0 || d->stats_blocks > kMaxBlocks || (d->stats_blocks > 0 && nstreams != 1))
+        return ppn::fail(PPN_E_INVALID, "ppn_bn_train_bwd: stats_blocks must be in [0, %d] and needs a single stream", kMaxBlocks);
+    const int nfold = d->stats_blocks > 0 ? d->stats_blocks : s.nblocks;     // partials from the input-gradient convolution's epilogue
+    if (d->stats_blocks > 0) {
+    } else if (d->dtype == PPN_F32)
         bn_reduce_kernel<float, 1><<<grid, kThreads, 0, st>>>((const float*)d->x, (const float*)d->dy, d->gamma,
                                                               d->beta, d->save_mean, d->save_rstd, d->act,
                                                               d->pixels, C, s, partial, sstride, pstride);
@@ -869,7 +877,7 @@ static int bn_train_bwd_impl(const ppn_bn_bwd_desc* d, int nstreams, void* strea
                                                                d->gamma, d->beta, d->save_mean, d->save_rstd,
                                                                d->act, d->pixels, C, s, partial, sstride, pstride);
     PPN_LAUNCH_CHECK();
-    bn_bwd_finalize_kernel<<<fgrid, 256, 0, st>>>(partial, s.nblocks, C, d->pixels, d->gamma, d->save_mean,
+    bn_bwd_finalize_kernel<<<fgrid, 256, 0, st>>>(partial, nfold, C, d->pixels, d->gamma, d->save_mean,
                                                    d->save_rstd, d->dgamma, d->dbeta, coef, pstride);
     PPN_LAUNCH_CHECK();
     if (d->dtype == PPN_F32)

@@ -41,6 +41,9 @@ class ConvDesc(C.Structure):
         ("limb_window", C.c_int32), ("m_begin", C.c_int32), ("m_count", C.c_int32), ("limb_edge_pad", C.c_int32),
         ("flags", C.c_int32),
         ("prefetch", C.c_void_p), ("prefetch_bytes", C.c_int64),
+        ("stats_partial", C.c_void_p), ("stats_mode", C.c_int32), ("stats_act", C.c_int32), ("stats_x", C.c_void_p),
+        ("stats_gamma", C.c_void_p), ("stats_beta", C.c_void_p), ("stats_mean", C.c_void_p), ("stats_rstd", C.c_void_p),
+        ("stats_tiles", C.POINTER(C.c_int32)),
     ]
 
 
@@ -75,13 +78,13 @@ class BnDesc(C.Structure):
     _fields_ = [("dtype", C.c_int32), ("channels", C.c_int32), ("pixels", C.c_int64), ("act", C.c_int32),
                 ("eps", C.c_float), ("momentum", C.c_float)] + [
         (n, C.c_void_p) for n in ("x", "gamma", "beta", "running_mean", "running_var", "save_mean", "save_rstd",
-                                  "scale", "shift", "y", "workspace")]
+                                  "scale", "shift", "y", "workspace")] + [("stats_blocks", C.c_int32)]
 
 
 class BnBwdDesc(C.Structure):
     _fields_ = [("dtype", C.c_int32), ("channels", C.c_int32), ("pixels", C.c_int64), ("act", C.c_int32)] + [
         (n, C.c_void_p) for n in ("x", "dy", "dx_add", "gamma", "beta", "save_mean", "save_rstd", "dgamma", "dbeta",
-                                  "dx", "workspace")]
+                                  "dx", "workspace")] + [("stats_blocks", C.c_int32)]
 
 
 class WgradDesc(C.Structure):

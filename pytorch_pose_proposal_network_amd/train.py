@@ -49,6 +49,29 @@ def _workspace(channels: int, device, nstreams: int = 1) -> torch.Tensor:
     return ws
 
 
+class ConvStats:
+    """BatchNorm partial sums a convolution's epilogue left in the BatchNorm workspace of its stream (ppn_conv_desc.stats_mode):
+    `blocks` pixel tiles (0: the launch had no such epilogue -- the BatchNorm call then runs its own reduction pass), in the
+    workspace tensor `ws`.  Hand it to the bn_train_forward / bn_train_backward call that FOLLOWS the convolution on the same
+    stream, with no other BatchNorm of that channel count in between (they share the workspace)."""
+    __slots__ = ("ws", "blocks", "mode", "tensor")
+
+    def __init__(self, ws, blocks, mode, tensor):
+        self.ws, self.blocks, self.mode, self.tensor = ws, blocks, mode, tensor
+
+
+_FUSE_STATS = os.environ.get("PPN_TRAIN_FUSE_STATS", "1") != "0"      # A/B switch of the trainer's use of ConvStats
+_FUSE_STATS_BWD = os.environ.get("PPN_TRAIN_FUSE_STATS", "1") != "2"  # "2": the forward sums only
+
+
+def _stats_blocks(stats, ws, mode: int, tensor: torch.Tensor) -> int:
+    if stats is None or stats.blocks == 0:
+        return 0
+    if stats.mode != mode or stats.ws is not ws or stats.tensor.data_ptr() != tensor.data_ptr():
+        raise ValueError("ConvStats belongs to another tensor / workspace / pass")
+    return stats.blocks
+
+
 class BnSaved:
     """What the backward needs: batch mean, 1/sqrt(var+eps) and the folded affine (y = act(x*scale+shift))."""
 
@@ -61,10 +84,11 @@ class BnSaved:
 
 def bn_train_forward(x: torch.Tensor, gamma, beta, running_mean=None, running_var=None, act: str = "none",
                      eps: float = 1e-5, momentum: float = 0.1, out: Optional[torch.Tensor] = None,
-                     want_output: bool = True):
+                     want_output: bool = True, stats: Optional[ConvStats] = None):
     """y = act(batch_norm(x)) with batch statistics; running stats updated in place (nn.BatchNorm2d defaults).
 
-    Returns (y, BnSaved).  x: NHWC contiguous, channels last."""
+    Returns (y, BnSaved).  x: NHWC contiguous, channels last.  stats: the ConvStats of the convolution that produced x
+    (conv2d_nhwc(..., stats="fwd")): its epilogue already folded the per-tile sums, the reduction pass over x is skipped."""
     lib = L.load()
     if not x.is_cuda or not x.is_contiguous():
         raise ValueError("x must be a contiguous device tensor (channels last)")
@@ -82,7 +106,9 @@ def bn_train_forward(x: torch.Tensor, gamma, beta, running_mean=None, running_va
     if want_output:
         y = out if out is not None else torch.empty_like(x)
         d.y = y.data_ptr()
-    d.workspace = _workspace(c, x.device).data_ptr()
+    ws = _workspace(c, x.device)
+    d.workspace = ws.data_ptr()
+    d.stats_blocks = _stats_blocks(stats, ws, 1, x)
     L.check(lib.ppn_bn_train_fwd(C.byref(d), L.current_stream_ptr()), "ppn_bn_train_fwd")
     return y, saved
 
@@ -96,8 +122,10 @@ def _stacked(x: torch.Tensor, t: torch.Tensor, nstreams: int, name: str):
 
 def bn_train_backward(x: torch.Tensor, dy: torch.Tensor, gamma, beta, saved: BnSaved, act: str = "none",
                       dx_add: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-                      dgamma: Optional[torch.Tensor] = None, dbeta: Optional[torch.Tensor] = None, nstreams: int = 1):
+                      dgamma: Optional[torch.Tensor] = None, dbeta: Optional[torch.Tensor] = None, nstreams: int = 1,
+                      stats: Optional[ConvStats] = None):
     """Returns (dx, dgamma, dbeta) for y = act(batch_norm(x)); dx_add (same shape) is added to dx.
+    stats: the ConvStats of the input-gradient convolution that produced dy (conv_dgrad(..., bn=...)): skips the reduction pass.
     dgamma / dbeta: optional f32[C] destinations (e.g. views of the flat gradient buffer), overwritten.
     nstreams > 1: dy (dx, dx_add) hold that many gradient streams over the SAME x, stacked along dim 0; one set of
     launches (ppn_bn_train_bwd_streams); dgamma / dbeta are [nstreams, C]; stream s == the single call on its slices."""
@@ -119,7 +147,9 @@ def bn_train_backward(x: torch.Tensor, dy: torch.Tensor, gamma, beta, saved: BnS
     d.gamma, d.beta = _f32(gamma, c, "gamma"), _f32(beta, c, "beta")
     d.save_mean, d.save_rstd = saved.mean.data_ptr(), saved.rstd.data_ptr()
     d.dgamma, d.dbeta, d.dx = _f32(dgamma, nstreams * c, "dgamma"), _f32(dbeta, nstreams * c, "dbeta"), dx.data_ptr()
-    d.workspace = _workspace(c, x.device, nstreams).data_ptr()
+    ws = _workspace(c, x.device, nstreams)
+    d.workspace = ws.data_ptr()
+    d.stats_blocks = _stats_blocks(stats, ws, 2, dy)
     if nstreams == 1:
         L.check(lib.ppn_bn_train_bwd(C.byref(d), L.current_stream_ptr()), "ppn_bn_train_bwd")
     else:
@@ -284,10 +314,14 @@ class GradNormWeights:
 
 def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, stride: int = 1, dilation: int = 1, pad: int = 0,
                 add: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None, act: int = 0,
-                nchw_f32: bool = False, dgrad_of: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                nchw_f32: bool = False, dgrad_of: bool = False, out: Optional[torch.Tensor] = None, stats=None):
     """Raw convolution (no folded BN: train mode keeps BN separate) of an NHWC tensor with a reference-layout
     f32 weight [cout,cin,k,k] on the device, + `add` (NHWC, the residual).  Packs the weight for the MFMA
-    kernels on the fly: in training the weights change every step anyway."""
+    kernels on the fly: in training the weights change every step anyway.
+
+    stats: ask the epilogue for the BatchNorm partial sums of the output (ppn_conv_desc.stats_mode) -- "fwd" ({sum v, sum v^2}: the
+    output feeds a BatchNorm) or a tuple (x, gamma, beta, BnSaved, act) ({sum g, sum g * xhat}: the output is dy of that BatchNorm
+    + activation over x).  Returns (out, ConvStats) then; ConvStats.blocks == 0 where the launch has no such epilogue."""
     lib = L.load()
     dt = _dtype_code(x)
     B, H, W, cin = x.shape
@@ -354,8 +388,27 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, stride: int = 1, dilation: int
         nxt = _chain_next.get((st, pp))
         if nxt is not None:
             d.prefetch, d.prefetch_bytes = nxt
+    if stats is None:
+        L.check(lib.ppn_conv2d_fused(C.byref(d), st), "ppn_conv2d_fused")
+        return out
+    if nchw_f32:
+        raise ValueError("conv2d_nhwc: statistics are for NHWC outputs")
+    ws = _workspace(cout, x.device)
+    tiles = C.c_int32(0)
+    d.stats_partial, d.stats_tiles = ws.data_ptr(), C.pointer(tiles)
+    if isinstance(stats, str):
+        if stats != "fwd":
+            raise ValueError("conv2d_nhwc: stats is 'fwd' or (x, gamma, beta, saved, act)")
+        d.stats_mode = 1
+    else:
+        bx, gamma, beta, saved, bact = stats
+        if bx.shape != out.shape or bx.dtype != out.dtype or not bx.is_contiguous():
+            raise ValueError("conv2d_nhwc: the BatchNorm input of `stats` must match the output")
+        d.stats_mode, d.stats_act, d.stats_x = 2, ACT[bact], bx.data_ptr()
+        d.stats_gamma, d.stats_beta = _f32(gamma, cout, "gamma"), _f32(beta, cout, "beta")
+        d.stats_mean, d.stats_rstd = saved.mean.data_ptr(), saved.rstd.data_ptr()
     L.check(lib.ppn_conv2d_fused(C.byref(d), st), "ppn_conv2d_fused")
-    return out
+    return out, ConvStats(ws, tiles.value, d.stats_mode, out)
 
 
 _PREFETCH = os.environ.get("PPN_PREFETCH", "1") != "0"
@@ -447,7 +500,7 @@ def _zero_page(device) -> torch.Tensor:
 
 
 def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, in_hw, stride: int = 1, dilation: int = 1, pad: int = 0,
-               add: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+               add: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, bn=None):
     """dL/dx of y = conv2d(x, w, stride, dilation, pad) given dy (NHWC): the same implicit-GEMM kernel run on dy
     with the weights transposed (cin <-> cout) and flipped; a strided convolution first spreads dy over a
     zero-filled grid (the transposed-convolution identity).  `add` (NHWC like x) is added (skip-path gradient)."""
@@ -460,16 +513,19 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, in_hw, stride: int = 1, dilati
     # four short-K launches and four strided copies cost what the 2.25x fewer FLOPs save) and keep the zero-upsampled form
     # With a skip-path gradient to add, the 16-bit modes keep the zero-upsampled form: its epilogue adds in f32 and rounds
     # ONCE, whereas the parity form could only add after its sub-convolutions have been rounded (two roundings).
+    # bn = (x, gamma, beta, BnSaved, act): the result is dy of that BatchNorm + activation over x; returns (dx, ConvStats) for
+    # bn_train_backward(..., stats=) -- blocks == 0 wherever the launch that writes dx cannot fold the sums
     if (_S2_PARITY and stride == 2 and dilation == 1 and pad == k // 2 and (k == 1 or (k == 3 and cin <= 16)) and
             (add is None or dy.dtype == torch.float32) and
             Ho == (H + 2 * pad - k) // 2 + 1 and Wo == (W + 2 * pad - k) // 2 + 1):
         if out is not None:
             raise ValueError("conv_dgrad: `out` is for the stride-1 form")
-        return _dgrad_stride2(dy, w, H, W, add)
+        dx = _dgrad_stride2(dy, w, H, W, add)
+        return dx if bn is None else (dx, ConvStats(None, 0, 2, dx))
     hup, wup = H + 2 * pad - eff + 1, W + 2 * pad - eff + 1
     if stride > 1 or (hup, wup) != (Ho, Wo):
         dy = upsample_zero(dy, stride, hup, wup)
-    return conv2d_nhwc(dy, w, 1, dilation, eff - 1 - pad, add=add, dgrad_of=True, out=out)
+    return conv2d_nhwc(dy, w, 1, dilation, eff - 1 - pad, add=add, dgrad_of=True, out=out, stats=bn)
 
 
 def upsample_zero(src: torch.Tensor, stride: int, dst_h: int, dst_w: int) -> torch.Tensor:

@@ -101,6 +101,7 @@ class PPNTrainer:
         self._so_pin = None
         self._w3p = {}                               # _w3_padded
         self._wg0_main = os.environ.get("PPN_TRAIN_WG0_MAIN", "1") != "0"
+        self._fuse_stats = T._FUSE_STATS and self.tdt == torch.bfloat16
         self._tail_wgrad_side = os.environ.get("PPN_TRAIN_TAIL_WGRAD_SIDE", "1") != "0"
         pri = int(os.environ.get("PPN_TRAIN_PROBE_PRIORITY", "0"))
         self._probe_stream = torch.cuda.Stream(device=self.device, priority=pri) if self._side is not None else None
@@ -228,18 +229,35 @@ class PPNTrainer:
         return self.opt.lr
 
     # ---- small helpers ------------------------------------------------------------------------------------------
-    def _bn(self, x, prefix, act):
+    def _bn(self, x, prefix, act, stats=None):
         y, saved = T.bn_train_forward(x, self.P[prefix + ".weight"], self.P[prefix + ".bias"],
                                       self.buffers[prefix + ".running_mean"], self.buffers[prefix + ".running_var"],
-                                      act=act)
+                                      act=act, stats=stats)
         return y, saved
 
-    def _bn_bwd(self, x, dy, prefix, act, saved, dx_add=None, keep=True):
+    def _bn_bwd(self, x, dy, prefix, act, saved, dx_add=None, keep=True, stats=None):
         # parameter gradients land directly in the flat gradient buffer (probe passes discard them)
         dx, _, _ = T.bn_train_backward(x, dy, self.P[prefix + ".weight"], self.P[prefix + ".bias"], saved, act=act,
                                        dx_add=dx_add, dgamma=self.G[prefix + ".weight"] if keep else None,
-                                       dbeta=self.G[prefix + ".bias"] if keep else None)
+                                       dbeta=self.G[prefix + ".bias"] if keep else None, stats=stats)
         return dx
+
+    # BatchNorm statistics from the neighbouring convolution's epilogue (train.ConvStats; 16-bit mode, PPN_TRAIN_FUSE_STATS=0: off):
+    # a forward convolution that feeds a BatchNorm folds {sum y, sum y^2} per pixel tile, an input-gradient convolution whose result
+    # is a BatchNorm's dy folds {sum g, sum g * xhat} -- the BatchNorm call that follows then skips its own pass over the tensor(s).
+    def _conv_bn(self, x, wname, *args, **kw):
+        """conv2d_nhwc whose output feeds a BatchNorm: (y, ConvStats or None)"""
+        if self._fuse_stats:
+            return T.conv2d_nhwc(x, self.P[wname], *args, stats="fwd", **kw)
+        return T.conv2d_nhwc(x, self.P[wname], *args, **kw), None
+
+    def _dgrad_bn(self, dy, wname_or_w, in_hw, stride, dil, pad, x, prefix, act, saved, fuse=True):
+        """conv_dgrad whose result is dy of the BatchNorm `prefix` (+ act) over x: (dx, ConvStats or None)"""
+        w = self.P[wname_or_w] if isinstance(wname_or_w, str) else wname_or_w
+        if self._fuse_stats and fuse and T._FUSE_STATS_BWD:
+            return T.conv_dgrad(dy, w, in_hw, stride, dil, pad,
+                                bn=(x, self.P[prefix + ".weight"], self.P[prefix + ".bias"], saved, act))
+        return T.conv_dgrad(dy, w, in_hw, stride, dil, pad), None
 
     def _on_side(self, fn, *tensors):
         """Run fn() on the side stream once everything queued on the current stream so far is done.  Weight gradients
@@ -294,21 +312,22 @@ class PPNTrainer:
                     L.check(lib.ppn_stem7x7(self.compute_dtype, 0, x.data_ptr(), B, H, W, self.P[wn].data_ptr(), None,
                                             None, None, None, y.data_ptr(), L.current_stream_ptr()), "ppn_stem7x7")
                     src = xin8
+                    yst = None
                 else:
                     src = cur
-                    y = T.conv2d_nhwc(cur, self.P[wn], u.stride, d, d)
-                z, saved = self._bn(y, bnp, "relu")
+                    y, yst = self._conv_bn(cur, wn, u.stride, d, d)
+                z, saved = self._bn(y, bnp, "relu", stats=yst)
                 tape.append(("cbr", u, dict(x=src, y=y, saved=saved)))
                 cur = z
             elif u.kind == "basic":
                 p = u.prefix
                 a, s1 = self._bn(cur, p + ".bn1", "relu")
-                c1 = T.conv2d_nhwc(a, self.P[p + ".conv1.weight"], u.stride, u.dil[0], u.dil[0])
-                b, s2 = self._bn(c1, p + ".bn2", "relu")
+                c1, c1st = self._conv_bn(a, p + ".conv1.weight", u.stride, u.dil[0], u.dil[0])
+                b, s2 = self._bn(c1, p + ".bn2", "relu", stats=c1st)
                 ctx = dict(x=cur, a=a, s1=s1, c1=c1, b=b, s2=s2)
                 if u.downsample:
-                    dsy = T.conv2d_nhwc(cur, self.P[p + ".downsample.0.weight"], u.stride, 1, 0)
-                    r, s3 = self._bn(dsy, p + ".downsample.1", "none")
+                    dsy, dst = self._conv_bn(cur, p + ".downsample.0.weight", u.stride, 1, 0)
+                    r, s3 = self._bn(dsy, p + ".downsample.1", "none", stats=dst)
                     ctx.update(dsy=dsy, s3=s3)
                 else:
                     r = cur
@@ -317,16 +336,16 @@ class PPNTrainer:
                 cur = out
             elif u.kind == "bottleneck":                              # drn.py:77-97 (post-activation)
                 p, pl = u.prefix, u.planes
-                y1 = T.conv2d_nhwc(cur, self.P[p + ".conv1.weight"])
-                h1, s1 = self._bn(y1, p + ".bn1", "relu")
-                y2 = T.conv2d_nhwc(h1, self.P[p + ".conv2.weight"], u.stride, u.dil[1], u.dil[1])
-                h2, s2 = self._bn(y2, p + ".bn2", "relu")
-                y3 = T.conv2d_nhwc(h2, self.P[p + ".conv3.weight"])
-                z3, s3 = self._bn(y3, p + ".bn3", "none")
+                y1, st1 = self._conv_bn(cur, p + ".conv1.weight")
+                h1, s1 = self._bn(y1, p + ".bn1", "relu", stats=st1)
+                y2, st2 = self._conv_bn(h1, p + ".conv2.weight", u.stride, u.dil[1], u.dil[1])
+                h2, s2 = self._bn(y2, p + ".bn2", "relu", stats=st2)
+                y3, st3 = self._conv_bn(h2, p + ".conv3.weight")
+                z3, s3 = self._bn(y3, p + ".bn3", "none", stats=st3)
                 ctx = dict(x=cur, y1=y1, h1=h1, s1=s1, y2=y2, h2=h2, s2=s2, y3=y3, s3=s3)
                 if u.downsample:
-                    yd = T.conv2d_nhwc(cur, self.P[p + ".downsample.0.weight"], u.stride, 1, 0)
-                    r, sd = self._bn(yd, p + ".downsample.1", "none")
+                    yd, std = self._conv_bn(cur, p + ".downsample.0.weight", u.stride, 1, 0)
+                    r, sd = self._bn(yd, p + ".downsample.1", "none", stats=std)
                     ctx.update(yd=yd, sd=sd)
                 else:
                     r = cur
@@ -337,13 +356,13 @@ class PPNTrainer:
             else:                                                     # PPN head, model.py:113-136
                 R = cur
                 h0, s0 = self._bn(R, "bn0_1", "lrelu")
-                a1 = T.conv2d_nhwc(h0, self.P["conv1x1_1.weight"])
-                h1, s1 = self._bn(a1, "bn1", "lrelu")
-                a2 = T.conv2d_nhwc(h1, self.P["conv1.weight"], 1, 1, 1)
-                h2, s2 = self._bn(a2, "bn0_2", "lrelu")
+                a1, a1st = self._conv_bn(h0, "conv1x1_1.weight")
+                h1, s1 = self._bn(a1, "bn1", "lrelu", stats=a1st)
+                a2, a2st = self._conv_bn(h1, "conv1.weight", 1, 1, 1)
+                h2, s2 = self._bn(a2, "bn0_2", "lrelu", stats=a2st)
                 a3 = T.conv2d_nhwc(h2, self.P["conv1x1_2.weight"], add=R)
-                c2 = T.conv2d_nhwc(a3, self.P["conv2.weight"], 1, 1, 1, bias=self.P["conv2.bias"])
-                h3, s3 = self._bn(c2, "bn2", "lrelu")
+                c2, c2st = self._conv_bn(a3, "conv2.weight", 1, 1, 1, bias=self.P["conv2.bias"])
+                h3, s3 = self._bn(c2, "bn2", "lrelu", stats=c2st)
                 head = T.conv2d_nhwc(h3, self.P["conv3.weight"], bias=self.P["conv3.bias"], act=L.PPN_ACT_SIGMOID,
                                      nchw_f32=True)
                 tape.append(("head", u, dict(R=R, h0=h0, s0=s0, a1=a1, h1=h1, s1=s1, a2=a2, h2=h2, s2=s2, a3=a3,
@@ -385,8 +404,10 @@ class PPNTrainer:
                 dw3 = T.conv_wgrad(c["h3"], dz, 1)
                 self.G["conv3.weight"].copy_(dw3[:Ch])
             self._on_side(wg3, c["h3"], dz)
-        dh3 = T.conv_dgrad(dz, w3p, (Ho, Wo))
-        dc2 = self._bn_bwd(c["c2"], dh3, "bn2", "lrelu", c["s3"], keep=keep)
+        # (the probe passes keep the separate reduction pass: their stacked form -- _stacked_unary_probe_grads, several gradient
+        # streams per launch -- has no fused sums, and the two forms stay bit-identical)
+        dh3, st3 = self._dgrad_bn(dz, w3p, (Ho, Wo), 1, 1, 0, c["c2"], "bn2", "lrelu", c["s3"], fuse=keep)
+        dc2 = self._bn_bwd(c["c2"], dh3, "bn2", "lrelu", c["s3"], keep=keep, stats=st3)
         if keep:
             ws = T._workspace(dc2.shape[-1], self.device)
             L.check(lib.ppn_colsum(self.compute_dtype, dc2.data_ptr(), dc2.numel() // dc2.shape[-1], dc2.shape[-1],
@@ -396,12 +417,16 @@ class PPNTrainer:
         da3 = T.conv_dgrad(dc2, self.P["conv2.weight"], (Ho, Wo), 1, 1, 1)
         if keep:
             self._wgrad("conv1x1_2.weight", c["h2"], da3, 1)
-        dh2 = T.conv_dgrad(da3, self.P["conv1x1_2.weight"], (Ho, Wo))
-        da2 = self._bn_bwd(c["a2"], dh2, "bn0_2", "lrelu", c["s2"], keep=keep)
+        dh2, st2 = self._dgrad_bn(da3, "conv1x1_2.weight", (Ho, Wo), 1, 1, 0, c["a2"], "bn0_2", "lrelu", c["s2"], fuse=keep)
+        da2 = self._bn_bwd(c["a2"], dh2, "bn0_2", "lrelu", c["s2"], keep=keep, stats=st2)
         if probe_only:
             return T.conv_wgrad(c["h1"], da2, 3, 1, 1, 1)
         self._wgrad("conv1.weight", c["h1"], da2, 3, 1, 1, 1)
-        dh1 = T.conv_dgrad(da2, self.P["conv1.weight"], (Ho, Wo), 1, 1, 1)
+        second = so is not None and "head" in so
+        if second:                                       # the second-order adjoint is added to dh1 below: no sums of the bare dh1
+            dh1, st1 = T.conv_dgrad(da2, self.P["conv1.weight"], (Ho, Wo), 1, 1, 1), None
+        else:
+            dh1, st1 = self._dgrad_bn(da2, "conv1.weight", (Ho, Wo), 1, 1, 1, c["a1"], "bn1", "lrelu", c["s1"])
         skip = da3
         if so is not None and "head" in so:
             # GradNorm's Lgrad.backward(): the second-order adjoints at h1 and at the skip tensor join the first-order
@@ -412,10 +437,10 @@ class PPNTrainer:
             if h1_bar is not None:
                 dh1 = dh1 + h1_bar
                 skip = da3 + r_bar
-        da1 = self._bn_bwd(c["a1"], dh1, "bn1", "lrelu", c["s1"])
+        da1 = self._bn_bwd(c["a1"], dh1, "bn1", "lrelu", c["s1"], stats=st1)
         self._wgrad("conv1x1_1.weight", c["h0"], da1, 1)
-        dh0 = T.conv_dgrad(da1, self.P["conv1x1_1.weight"], (Ho, Wo))
-        return self._bn_bwd(c["R"], dh0, "bn0_1", "lrelu", c["s0"], dx_add=skip)
+        dh0, st0 = self._dgrad_bn(da1, "conv1x1_1.weight", (Ho, Wo), 1, 1, 0, c["R"], "bn0_1", "lrelu", c["s0"])
+        return self._bn_bwd(c["R"], dh0, "bn0_1", "lrelu", c["s0"], dx_add=skip, stats=st0)
 
     # ---- second order ------------------------------------------------------------------------------------------------
     def _second_order_tail(self, c, so):
@@ -643,7 +668,12 @@ class PPNTrainer:
                 torch.cuda.current_stream(self.device).wait_stream(self._side)
 
         g = grad_head
-        for kind, u, c in reversed(self._tape):
+        gst = None                                       # ConvStats of g where g is the dy of the NEXT unit's leading BatchNorm
+        order = list(reversed(self._tape))
+        for ui, (kind, u, c) in enumerate(order):
+            # the unit BEFORE this one in forward order: a conv-BN-ReLU unit's BatchNorm takes this unit's input gradient as its dy
+            below = order[ui + 1] if ui + 1 < len(order) else None
+            below_cbr = below is not None and below[0] == "cbr"
             if exchange is not None and kind != "head":
                 # every unit AFTER this one in forward order has been processed: its slice of the buffer is final
                 nxt = self._next_offset[id(u)]
@@ -658,28 +688,33 @@ class PPNTrainer:
                 p = u.prefix
                 hw = c["x"].shape[1:3]
                 self._wgrad(p + ".conv2.weight", c["b"], g, 3, 1, u.dil[1], u.dil[1])
-                db = T.conv_dgrad(g, self.P[p + ".conv2.weight"], c["b"].shape[1:3], 1, u.dil[1], u.dil[1])
-                dc1 = self._bn_bwd(c["c1"], db, p + ".bn2", "relu", c["s2"])
+                db, dbst = self._dgrad_bn(g, p + ".conv2.weight", c["b"].shape[1:3], 1, u.dil[1], u.dil[1],
+                                          c["c1"], p + ".bn2", "relu", c["s2"])
+                dc1 = self._bn_bwd(c["c1"], db, p + ".bn2", "relu", c["s2"], stats=dbst)
                 self._wgrad(p + ".conv1.weight", c["a"], dc1, 3, u.stride, u.dil[0], u.dil[0])
-                da = T.conv_dgrad(dc1, self.P[p + ".conv1.weight"], hw, u.stride, u.dil[0], u.dil[0])
                 if u.downsample:
                     dds = self._bn_bwd(c["dsy"], g, p + ".downsample.1", "none", c["s3"])
                     self._wgrad(p + ".downsample.0.weight", c["x"], dds, 1, u.stride, 1, 0)
                     dxr = T.conv_dgrad(dds, self.P[p + ".downsample.0.weight"], hw, u.stride, 1, 0)
                 else:
                     dxr = g
-                g = self._bn_bwd(c["x"], da, p + ".bn1", "relu", c["s1"], dx_add=dxr)
+                # (after the shortcut branch: nothing between this launch and the BatchNorm that takes its sums)
+                da, dast = self._dgrad_bn(dc1, p + ".conv1.weight", hw, u.stride, u.dil[0], u.dil[0],
+                                          c["x"], p + ".bn1", "relu", c["s1"])
+                g = self._bn_bwd(c["x"], da, p + ".bn1", "relu", c["s1"], dx_add=dxr, stats=dast)
+                gst = None
             elif kind == "bottleneck":
                 p = u.prefix
                 hw = c["x"].shape[1:3]
                 dsum = T.relu_mask(c["out"], g)                              # through relu(z3 + r)
                 dy3 = self._bn_bwd(c["y3"], dsum, p + ".bn3", "none", c["s3"])
                 self._wgrad(p + ".conv3.weight", c["h2"], dy3, 1)
-                dh2 = T.conv_dgrad(dy3, self.P[p + ".conv3.weight"], c["h2"].shape[1:3])
-                dy2 = self._bn_bwd(c["y2"], dh2, p + ".bn2", "relu", c["s2"])
+                dh2, dh2st = self._dgrad_bn(dy3, p + ".conv3.weight", c["h2"].shape[1:3], 1, 1, 0, c["y2"], p + ".bn2", "relu", c["s2"])
+                dy2 = self._bn_bwd(c["y2"], dh2, p + ".bn2", "relu", c["s2"], stats=dh2st)
                 self._wgrad(p + ".conv2.weight", c["h1"], dy2, 3, u.stride, u.dil[1], u.dil[1])
-                dh1 = T.conv_dgrad(dy2, self.P[p + ".conv2.weight"], c["h1"].shape[1:3], u.stride, u.dil[1], u.dil[1])
-                dy1 = self._bn_bwd(c["y1"], dh1, p + ".bn1", "relu", c["s1"])
+                dh1, dh1st = self._dgrad_bn(dy2, p + ".conv2.weight", c["h1"].shape[1:3], u.stride, u.dil[1], u.dil[1],
+                                            c["y1"], p + ".bn1", "relu", c["s1"])
+                dy1 = self._bn_bwd(c["y1"], dh1, p + ".bn1", "relu", c["s1"], stats=dh1st)
                 self._wgrad(p + ".conv1.weight", c["x"], dy1, 1)
                 if u.downsample:
                     dyd = self._bn_bwd(c["yd"], dsum, p + ".downsample.1", "none", c["sd"])
@@ -688,11 +723,13 @@ class PPNTrainer:
                 else:
                     dxr = dsum
                 g = T.conv_dgrad(dy1, self.P[p + ".conv1.weight"], hw, add=dxr)
+                gst = None
             else:  # cbr
                 wn = f"{u.prefix}.{u.conv_idx}.weight"
                 bnp = f"{u.prefix}.{u.conv_idx + 1}"
                 d = u.dil[0]
-                dy = self._bn_bwd(c["y"], g, bnp, "relu", c["saved"])
+                dy = self._bn_bwd(c["y"], g, bnp, "relu", c["saved"], stats=gst)
+                gst = None
                 if u.k == 7:
                     def wg0(x8=c["x"], dy=dy, wn=wn):
                         dw8 = T.conv_wgrad(x8, dy, 7, 1, 1, 3)            # [16, 4 | 8, 7, 7]; input channels 3.. are zero
@@ -706,7 +743,12 @@ class PPNTrainer:
                     g = None                                               # the input needs no gradient
                 else:
                     self._wgrad(wn, c["x"], dy, 3, u.stride, d, d)
-                    g = T.conv_dgrad(dy, self.P[wn], c["x"].shape[1:3], u.stride, d, d)
+                    if below_cbr:                                          # g is the dy of the conv-BN-ReLU unit below
+                        bu, bc = below[1], below[2]
+                        g, gst = self._dgrad_bn(dy, wn, c["x"].shape[1:3], u.stride, d, d, bc["y"],
+                                                f"{bu.prefix}.{bu.conv_idx + 1}", "relu", bc["saved"])
+                    else:
+                        g = T.conv_dgrad(dy, self.P[wn], c["x"].shape[1:3], u.stride, d, d)
         if self._side is not None:
             torch.cuda.current_stream(self.device).wait_stream(self._side)   # every weight gradient has landed
         return self.grad

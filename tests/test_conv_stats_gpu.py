@@ -1,0 +1,138 @@
+"""BatchNorm partial sums from the convolution epilogue (ppn_conv_desc.stats_mode, ppn_bn_desc.stats_blocks): the fused path
+against the separate reduction pass (train.hip bn_reduce_kernel) and against f64 sums of the stored tensor.  Tolerances: the two
+paths add the SAME per-element terms (of the rounded 16-bit values) in a different order, f32 within a thread's 4-18 pixels and f64
+above -- 1e-5 relative on the statistics; outputs may differ by one 16-bit ulp where a value sits on a rounding boundary."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _mods():
+    from pytorch_pose_proposal_network_amd import train as T
+    return T
+
+
+CASES = [  # B, H, W, cin, cout, k, dil
+    (4, 24, 24, 512, 512, 3, 2),
+    (2, 48, 48, 128, 128, 3, 1),
+    (2, 48, 48, 256, 512, 1, 1),
+    (3, 17, 19, 128, 256, 3, 1),      # pixel count not a multiple of any tile
+    (1, 9, 7, 256, 128, 1, 1),        # fewer pixels than one tile
+]
+
+
+def _ulp_close(a, b, frac=2e-3):
+    """bf16 tensors equal up to rare one-ulp differences"""
+    a, b = a.float(), b.float()
+    # one ulp of the value, or (sums that cancel: dx = ca * g + cb * x + cc + skip) of the terms it is made of
+    bad = (a - b).abs() > 0.0079 * torch.maximum(a.abs(), b.abs()) + 1e-4 * a.abs().max()
+    assert not bad.any(), f"{int(bad.sum())} values differ by more than one bf16 ulp"
+    assert (a != b).float().mean().item() <= frac
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout,k,dil", CASES)
+def test_forward_statistics_match_the_reduction_pass(B, H, W, cin, cout, k, dil):
+    T = _mods()
+    dev = torch.device("cuda")
+    g = torch.Generator(device="cpu").manual_seed(B * 1000 + cout + k)
+    x = (torch.randn(B, H, W, cin, generator=g) * 0.7 + 0.1).to(dev).to(torch.bfloat16)
+    w = (torch.randn(cout, cin, k, k, generator=g) * (1.0 / (cin * k * k) ** 0.5)).to(dev)
+    pad = dil * (k // 2)
+    ref = T.conv2d_nhwc(x, w, 1, dil, pad)
+    out, st = T.conv2d_nhwc(x, w, 1, dil, pad, stats="fwd")
+    assert torch.equal(out, ref)
+    assert st.blocks > 0, "the large-tile kernel's bf16 epilogue should carry the statistics for this shape"
+    gamma, beta = torch.rand(cout, device=dev) + 0.5, torch.randn(cout, device=dev)
+    rm0, rv0 = torch.zeros(cout, device=dev), torch.ones(cout, device=dev)
+    rm1, rv1 = rm0.clone(), rv0.clone()
+    # the BatchNorm that takes the sums comes FIRST: the epilogue left them in the workspace every BatchNorm call of this channel
+    # count on this stream uses (train.ConvStats)
+    y1, s1 = T.bn_train_forward(out, gamma, beta, rm1, rv1, act="relu", stats=st)
+    y0, s0 = T.bn_train_forward(ref, gamma, beta, rm0, rv0, act="relu")
+    torch.testing.assert_close(s1.mean, s0.mean, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(s1.rstd, s0.rstd, rtol=1e-5, atol=0)
+    torch.testing.assert_close(rm1, rm0, rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(rv1, rv0, rtol=1e-5, atol=1e-7)
+    _ulp_close(y1, y0)
+    # against f64 sums of the stored tensor
+    o64 = out.double().reshape(-1, cout)
+    torch.testing.assert_close(s1.mean.double(), o64.mean(0), rtol=1e-5, atol=1e-6)
+    var = o64.var(0, unbiased=False)
+    torch.testing.assert_close(s1.rstd.double(), 1.0 / torch.sqrt(var + 1e-5), rtol=2e-5, atol=0)
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout,k,dil", CASES)
+@pytest.mark.parametrize("act", ["relu", "lrelu", "none"])
+def test_backward_statistics_match_the_reduction_pass(B, H, W, cin, cout, k, dil, act):
+    """forward layer conv(cin -> cout): its input gradient has cin channels and is dy of a BatchNorm over x [.., cin]"""
+    T = _mods()
+    dev = torch.device("cuda")
+    g = torch.Generator(device="cpu").manual_seed(B * 977 + cin + k)
+    xb = (torch.randn(B, H, W, cin, generator=g) * 1.3 - 0.2).to(dev).to(torch.bfloat16)      # the BatchNorm's input
+    gamma, beta = torch.rand(cin, device=dev) + 0.5, torch.randn(cin, device=dev) * 0.3
+    _, saved = T.bn_train_forward(xb, gamma, beta, act=act)
+    w = (torch.randn(cout, cin, k, k, generator=g) * (1.0 / (cout * k * k) ** 0.5)).to(dev)
+    dyc = torch.randn(B, H, W, cout, generator=g).to(dev).to(torch.bfloat16)                   # gradient at the conv's output
+    pad = dil * (k // 2)
+    ref = T.conv_dgrad(dyc, w, (H, W), 1, dil, pad)
+    dz, st = T.conv_dgrad(dyc, w, (H, W), 1, dil, pad, bn=(xb, gamma, beta, saved, act))
+    assert torch.equal(dz, ref)
+    assert st.blocks > 0
+    skip = torch.randn_like(xb)
+    dx1, dg1, db1 = T.bn_train_backward(xb, dz, gamma, beta, saved, act=act, dx_add=skip, stats=st)
+    dx0, dg0, db0 = T.bn_train_backward(xb, ref, gamma, beta, saved, act=act, dx_add=skip)
+    scale = dg0.abs().max().item() + db0.abs().max().item()
+    torch.testing.assert_close(dg1, dg0, rtol=1e-4, atol=1e-5 * scale)
+    torch.testing.assert_close(db1, db0, rtol=1e-4, atol=1e-5 * scale)
+    _ulp_close(dx1, dx0)
+
+
+def test_launches_without_the_epilogue_report_zero_blocks_and_fall_back():
+    T = _mods()
+    dev = torch.device("cuda")
+    x = torch.randn(2, 24, 24, 128, device=dev)
+    w = torch.randn(128, 128, 3, 3, device=dev) * 0.03
+    out, st = T.conv2d_nhwc(x, w, 1, 1, 1, stats="fwd")                     # f32: no 16-bit epilogue
+    assert st.blocks == 0
+    xb = x.to(torch.bfloat16)
+    add = torch.randn(2, 24, 24, 128, device=dev).to(torch.bfloat16)
+    out, st = T.conv2d_nhwc(xb, w, 1, 1, 1, add=add, stats="fwd")            # residual: the chunked epilogue
+    assert st.blocks == 0 and torch.equal(out, T.conv2d_nhwc(xb, w, 1, 1, 1, add=add))
+    w64 = torch.randn(64, 128, 3, 3, device=dev) * 0.03
+    out, st = T.conv2d_nhwc(xb, w64, 1, 1, 1, stats="fwd")                   # 64 output channels: not the large-tile kernel's path
+    assert st.blocks == 0
+    g, b = torch.ones(64, device=dev), torch.zeros(64, device=dev)
+    y0, s0 = T.bn_train_forward(out, g, b, act="relu")
+    y1, s1 = T.bn_train_forward(out, g, b, act="relu", stats=st)              # blocks == 0: the ordinary reduction pass
+    assert torch.equal(y0, y1) and torch.equal(s0.mean, s1.mean)
+
+
+def test_statistics_of_another_tensor_are_refused():
+    T = _mods()
+    dev = torch.device("cuda")
+    xb = torch.randn(2, 24, 24, 128, device=dev).to(torch.bfloat16)
+    w = torch.randn(128, 128, 3, 3, device=dev) * 0.03
+    out, st = T.conv2d_nhwc(xb, w, 1, 1, 1, stats="fwd")
+    assert st.blocks > 0
+    g, b = torch.ones(128, device=dev), torch.zeros(128, device=dev)
+    with pytest.raises(ValueError):
+        T.bn_train_forward(out.clone(), g, b, stats=st)
+    _, saved = T.bn_train_forward(out, g, b, stats=st)
+    with pytest.raises(ValueError):
+        T.bn_train_backward(out, out, g, b, saved, stats=st)                   # forward sums are not backward sums
+
+
+def test_fused_statistics_are_bitwise_reproducible():
+    T = _mods()
+    dev = torch.device("cuda")
+    xb = torch.randn(4, 24, 24, 256, device=dev).to(torch.bfloat16)
+    w = torch.randn(256, 256, 3, 3, device=dev) * 0.02
+    g, b = torch.rand(256, device=dev) + 0.5, torch.randn(256, device=dev)
+    res = []
+    for _ in range(3):
+        out, st = T.conv2d_nhwc(xb, w, 1, 1, 1, stats="fwd")
+        y, s = T.bn_train_forward(out, g, b, act="lrelu", stats=st)
+        res.append((s.mean.clone(), s.rstd.clone(), y.clone()))
+    for r in res[1:]:
+        assert all(torch.equal(a, c) for a, c in zip(r, res[0]))
