@@ -580,6 +580,11 @@ typedef struct ppn_bn_desc {
     /* > 0: the workspace already holds that many blocks of partial sums { sum x, sum x^2 } per channel, written by the
      * convolution that produced x (ppn_conv_desc.stats_mode 1, *stats_tiles): the reduction pass over x is skipped. */
     int32_t stats_blocks;
+    /* non-NULL (HOST int, needs y): the apply pass also folds { sum y, sum y^2 } of the values it stores into the workspace, as
+     * the reduction pass of a BatchNorm over y would (bit for bit); *emit_blocks receives the number of partial blocks -- the
+     * stats_blocks of that next call (same channel count, same workspace, nothing in between).  A pre-activation block's bn1
+     * behind a conv-BN-ReLU unit (drn.py:47-63 after drn.py:205-218). */
+    int32_t* emit_blocks;
 } ppn_bn_desc;
 
 size_t ppn_bn_workspace_bytes(int32_t channels);
@@ -610,6 +615,14 @@ typedef struct ppn_bn_bwd_desc {
     /* > 0: the workspace already holds that many blocks of { sum g, sum g * xhat } per channel, written by the input-gradient
      * convolution that produced dy (ppn_conv_desc.stats_mode 2): the reduction pass over x and dy is skipped (single stream only). */
     int32_t stats_blocks;
+    /* next_x non-NULL: the dx this call writes is the dy of ANOTHER BatchNorm (+ next_act) over next_x [pixels][channels] --
+     * the projection shortcut's BatchNorm of the block below, or the conv-BN-ReLU unit below.  The apply pass folds that
+     * BatchNorm's { sum g, sum g * xhat } from the dx it stores into the workspace (bit for bit what its reduction pass would
+     * compute); *next_blocks (HOST int) receives the number of partial blocks = the stats_blocks of that next call. */
+    const void* next_x;
+    const float *next_gamma, *next_beta, *next_mean, *next_rstd;
+    int32_t next_act;
+    int32_t* next_blocks;
 } ppn_bn_bwd_desc;
 
 int ppn_bn_train_bwd(const ppn_bn_bwd_desc* d, void* stream);

@@ -37,6 +37,31 @@ struct Slab {
     int nblocks;
 };
 
+// A workgroup's per-thread sums a[8], b[8] (thread = one 8-channel column x its rows) -> partial[(block * C + c) * 2 + {0, 1}]:
+// thread (column, j) folds the rpi row-threads of its column in a fixed order.  Shared by the reduction kernel and by the apply
+// kernels that fold the NEXT BatchNorm's sums as they write its input (same slab, same order: the same bits).
+__device__ __forceinline__ void fold_block_partials(const double (&a)[8], const double (&b)[8], const Slab& s, int C,
+                                                    double* __restrict__ partial, double (*red)[17]) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        red[t][j] = a[j];
+        red[t][8 + j] = b[j];
+    }
+    __syncthreads();
+    for (int o = t; o < s.cc * 16; o += kThreads) {
+        const int c_ = o / 16, j = o % 16;
+        double acc = 0.0;
+        for (int r = 0; r < s.rpi; ++r) acc += red[r * s.cc + c_][j];
+        const int c = c_ * 8 + (j & 7);
+        partial[((size_t)blockIdx.x * C + c) * 2 + (j >> 3)] = acc;
+    }
+}
+
+template <typename T> __device__ __forceinline__ float round_to(float v);
+template <> __device__ __forceinline__ float round_to<float>(float v) { return v; }
+template <> __device__ __forceinline__ float round_to<__bf16>(float v) { return (float)(__bf16)v; }
+
 // ---- per-channel reductions: out[b][c] = {sum f(x), sum h(x)} over the workgroup's pixel slab ------------
 // MODE 0: {x, x*x}            (forward statistics)
 // MODE 1: {g, g*x_hat}        (backward: dbeta, dgamma), g = dy*act'(x*scale+shift)
@@ -97,20 +122,7 @@ __global__ void __launch_bounds__(kThreads) bn_reduce_kernel(const T* __restrict
             }
         }
     }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        red[t][j] = a[j];
-        red[t][8 + j] = b[j];
-    }
-    __syncthreads();
-    // thread (col, j) folds the rpi row-threads of its column in a fixed order
-    for (int o = t; o < s.cc * 16; o += kThreads) {
-        const int c_ = o / 16, j = o % 16;
-        double acc = 0.0;
-        for (int r = 0; r < s.rpi; ++r) acc += red[r * s.cc + c_][j];
-        const int c = c_ * 8 + (j & 7);
-        partial[((size_t)blockIdx.x * C + c) * 2 + (j >> 3)] = acc;
-    }
+    fold_block_partials(a, b, s, C, partial, red);
 }
 
 // forward finalize: mean / rstd / folded affine / running statistics
@@ -155,22 +167,27 @@ __global__ void bn_fwd_finalize_kernel(const double* __restrict__ partial, int n
     }
 }
 
-template <typename T>
+// EMIT: also fold {sum y, sum y^2} of the values it STORES (rounded to T) into `partial` -- the reduction pass of a BatchNorm
+// that takes y as its input (a pre-activation block's bn1 behind a conv-BN-ReLU unit, drn.py:47-63), bit for bit
+template <typename T, bool EMIT>
 __global__ void __launch_bounds__(kThreads) bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta,
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, int act, long long P,
-                                                            int C, Slab s, T* __restrict__ y) {
+                                                            int C, Slab s, T* __restrict__ y, double* __restrict__ partial) {
+    __shared__ double red[EMIT ? kThreads : 1][17];
     const int t = threadIdx.x;
     const int col = t % s.cc, roff = t / s.cc;
     const long long p0 = (long long)blockIdx.x * s.slab;
     const long long p1 = p0 + s.slab < P ? p0 + s.slab : P;
     float sc[8], sh[8];
+    double a[8], b[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int c = col * 8 + j;
         sc[j] = gamma[c] * rstd[c];
         sh[j] = beta[c] - mean[c] * sc[j];
+        a[j] = b[j] = 0.0;
     }
     const size_t row_bytes = (size_t)C * sizeof(T);
     const char* xb = reinterpret_cast<const char*>(x) + (size_t)col * 8 * sizeof(T);
@@ -181,7 +198,16 @@ __global__ void __launch_bounds__(kThreads) bn_apply_kernel(const T* __restrict_
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = act_fwd(v[j] * sc[j] + sh[j], act);
         store8<T>(yb + p * row_bytes, v);
+        if constexpr (EMIT) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const double d = (double)round_to<T>(v[j]);
+                a[j] += d;
+                b[j] += d * d;
+            }
+        }
     }
+    if constexpr (EMIT) fold_block_partials(a, b, s, C, partial, red);
 }
 
 // backward finalize: dgamma, dbeta and the three per-channel coefficients of  dx = ca*g + cb*x + cc
@@ -215,7 +241,18 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ partial, int n
     coef[2 * C + c] = (float)(g * r * (m * r * dg - db) / n);
 }
 
+// NEXT: the dx this kernel writes is the dy of ANOTHER BatchNorm (+ activation) over the tensor nx.x of the same shape -- the
+// projection shortcut's BatchNorm of the block below, or the conv-BN-ReLU unit below (trainer.py backward()): fold that
+// BatchNorm's {sum g, sum g * xhat} as bn_reduce_kernel<T, 1> would from the stored dx, bit for bit, into nx.partial.
 template <typename T>
+struct NextBn {
+    const T* x;
+    const float *gamma, *beta, *mean, *rstd;
+    int act;
+    double* partial;
+};
+
+template <typename T, bool NEXT>
 __global__ void __launch_bounds__(kThreads) bn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                                 const T* __restrict__ add,
                                                                 const float* __restrict__ gamma,
@@ -224,7 +261,8 @@ __global__ void __launch_bounds__(kThreads) bn_bwd_apply_kernel(const T* __restr
                                                                 const float* __restrict__ rstd,
                                                                 const float* __restrict__ coef, int act,
                                                                 long long P, int C, Slab s, T* __restrict__ dx,
-                                                                long long sstride = 0) {
+                                                                long long sstride, NextBn<T> nx) {
+    __shared__ double red[NEXT ? kThreads : 1][17];
     dy += (size_t)blockIdx.y * sstride;                // stream blockIdx.y (see bn_reduce_kernel)
     dx += (size_t)blockIdx.y * sstride;
     if (add) add += (size_t)blockIdx.y * sstride;
@@ -234,6 +272,8 @@ __global__ void __launch_bounds__(kThreads) bn_bwd_apply_kernel(const T* __restr
     const long long p0 = (long long)blockIdx.x * s.slab;
     const long long p1 = p0 + s.slab < P ? p0 + s.slab : P;
     float sc[8], sh[8], ca[8], cb[8], cc[8];
+    float sc2[8], sh2[8], mu2[8], rs2[8];
+    double a2[8], b2[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int c = col * 8 + j;
@@ -242,12 +282,20 @@ __global__ void __launch_bounds__(kThreads) bn_bwd_apply_kernel(const T* __restr
         ca[j] = coef[c];
         cb[j] = coef[C + c];
         cc[j] = coef[2 * C + c];
+        if constexpr (NEXT) {
+            mu2[j] = nx.mean[c];
+            rs2[j] = nx.rstd[c];
+            sc2[j] = nx.gamma[c] * rs2[j];
+            sh2[j] = nx.beta[c] - mu2[j] * sc2[j];
+            a2[j] = b2[j] = 0.0;
+        }
     }
     const size_t row_bytes = (size_t)C * sizeof(T);
     const size_t cofs = (size_t)col * 8 * sizeof(T);
     const char* xb = reinterpret_cast<const char*>(x) + cofs;
     const char* db = reinterpret_cast<const char*>(dy) + cofs;
     const char* ab = add ? reinterpret_cast<const char*>(add) + cofs : nullptr;
+    const char* nb = NEXT ? reinterpret_cast<const char*>(nx.x) + cofs : nullptr;
     char* ob = reinterpret_cast<char*>(dx) + cofs;
     for (long long p = p0 + roff; p < p1; p += s.rpi) {
         float v[8], g[8], o[8];
@@ -265,7 +313,20 @@ __global__ void __launch_bounds__(kThreads) bn_bwd_apply_kernel(const T* __restr
             for (int j = 0; j < 8; ++j) o[j] += r[j];
         }
         store8<T>(ob + p * row_bytes, o);
+        if constexpr (NEXT) {
+            float w[8];
+            load8<T>(nb + p * row_bytes, w);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {                            // bn_reduce_kernel MODE 1 on (nx.x, the stored dx)
+                const float z = w[j] * sc2[j] + sh2[j];
+                const float gg = round_to<T>(o[j]) * act_slope(z, nx.act);
+                const float xh = (w[j] - mu2[j]) * rs2[j];
+                a2[j] += (double)gg;
+                b2[j] += (double)gg * (double)xh;
+            }
+        }
     }
+    if constexpr (NEXT) fold_block_partials(a2, b2, s, C, nx.partial, red);
 }
 
 // ---- Adam ---------------------------------------------------------------------------------------------------
@@ -834,16 +895,22 @@ int ppn_bn_train_fwd(const ppn_bn_desc* d, void* stream) {
                                                          d->momentum, d->running_mean, d->running_var, d->save_mean,
                                                          d->save_rstd, d->scale, d->shift);
     PPN_LAUNCH_CHECK();
+    if (d->emit_blocks) *d->emit_blocks = 0;
     if (d->y) {
-        if (d->dtype == PPN_F32)
-            bn_apply_kernel<float><<<s.nblocks, kThreads, 0, st>>>((const float*)d->x, d->gamma, d->beta, d->save_mean,
-                                                                   d->save_rstd, d->act, d->pixels, C, s,
-                                                                   (float*)d->y);
-        else
-            bn_apply_kernel<__bf16><<<s.nblocks, kThreads, 0, st>>>((const __bf16*)d->x, d->gamma, d->beta,
-                                                                    d->save_mean, d->save_rstd, d->act, d->pixels, C,
-                                                                    s, (__bf16*)d->y);
+        // emit_blocks: the apply pass also folds {sum y, sum y^2} of what it stores into the workspace (the finalize launch has
+        // consumed this BatchNorm's own partials by then) -- the reduction pass of a BatchNorm whose input is y
+        const bool emit = d->emit_blocks != nullptr;
+        if (d->dtype == PPN_F32) {
+            auto k = emit ? bn_apply_kernel<float, true> : bn_apply_kernel<float, false>;
+            k<<<s.nblocks, kThreads, 0, st>>>((const float*)d->x, d->gamma, d->beta, d->save_mean, d->save_rstd, d->act, d->pixels, C,
+                                              s, (float*)d->y, partial);
+        } else {
+            auto k = emit ? bn_apply_kernel<__bf16, true> : bn_apply_kernel<__bf16, false>;
+            k<<<s.nblocks, kThreads, 0, st>>>((const __bf16*)d->x, d->gamma, d->beta, d->save_mean, d->save_rstd, d->act, d->pixels,
+                                              C, s, (__bf16*)d->y, partial);
+        }
         PPN_LAUNCH_CHECK();
+        if (emit) *d->emit_blocks = s.nblocks;
     }
     return PPN_OK;
 }
@@ -880,15 +947,28 @@ static int bn_train_bwd_impl(const ppn_bn_bwd_desc* d, int nstreams, void* strea
     bn_bwd_finalize_kernel<<<fgrid, 256, 0, st>>>(partial, nfold, C, d->pixels, d->gamma, d->save_mean,
                                                    d->save_rstd, d->dgamma, d->dbeta, coef, pstride);
     PPN_LAUNCH_CHECK();
-    if (d->dtype == PPN_F32)
-        bn_bwd_apply_kernel<float><<<grid, kThreads, 0, st>>>(
-            (const float*)d->x, (const float*)d->dy, (const float*)d->dx_add, d->gamma, d->beta, d->save_mean,
-            d->save_rstd, coef, d->act, d->pixels, C, s, (float*)d->dx, sstride);
-    else
-        bn_bwd_apply_kernel<__bf16><<<grid, kThreads, 0, st>>>(
-            (const __bf16*)d->x, (const __bf16*)d->dy, (const __bf16*)d->dx_add, d->gamma, d->beta, d->save_mean,
-            d->save_rstd, coef, d->act, d->pixels, C, s, (__bf16*)d->dx, sstride);
+    // next_x: the dx of this call is the dy of the BatchNorm over next_x (same shape): its sums are folded by the apply pass
+    // into the workspace (this BatchNorm's own partials are consumed: the apply pass reads `coef` only)
+    const bool next = d->next_x != nullptr;
+    if (d->next_blocks) *d->next_blocks = 0;
+    if (next && (nstreams != 1 || !d->next_gamma || !d->next_beta || !d->next_mean || !d->next_rstd || !d->next_blocks ||
+                 d->next_act < PPN_ACT_NONE || d->next_act > PPN_ACT_LRELU))
+        return ppn::fail(PPN_E_INVALID, "ppn_bn_train_bwd: next_x needs next_gamma / beta / mean / rstd / blocks, an activation "
+                                        "none / relu / lrelu and a single stream");
+    if (d->dtype == PPN_F32) {
+        const NextBn<float> nx{(const float*)d->next_x, d->next_gamma, d->next_beta, d->next_mean, d->next_rstd, d->next_act, partial};
+        auto k = next ? bn_bwd_apply_kernel<float, true> : bn_bwd_apply_kernel<float, false>;
+        k<<<grid, kThreads, 0, st>>>((const float*)d->x, (const float*)d->dy, (const float*)d->dx_add, d->gamma, d->beta,
+                                     d->save_mean, d->save_rstd, coef, d->act, d->pixels, C, s, (float*)d->dx, sstride, nx);
+    } else {
+        const NextBn<__bf16> nx{(const __bf16*)d->next_x, d->next_gamma, d->next_beta, d->next_mean, d->next_rstd, d->next_act,
+                                partial};
+        auto k = next ? bn_bwd_apply_kernel<__bf16, true> : bn_bwd_apply_kernel<__bf16, false>;
+        k<<<grid, kThreads, 0, st>>>((const __bf16*)d->x, (const __bf16*)d->dy, (const __bf16*)d->dx_add, d->gamma, d->beta,
+                                     d->save_mean, d->save_rstd, coef, d->act, d->pixels, C, s, (__bf16*)d->dx, sstride, nx);
+    }
     PPN_LAUNCH_CHECK();
+    if (next) *d->next_blocks = s.nblocks;
     return PPN_OK;
 }
 

@@ -78,13 +78,16 @@ class BnDesc(C.Structure):
     _fields_ = [("dtype", C.c_int32), ("channels", C.c_int32), ("pixels", C.c_int64), ("act", C.c_int32),
                 ("eps", C.c_float), ("momentum", C.c_float)] + [
         (n, C.c_void_p) for n in ("x", "gamma", "beta", "running_mean", "running_var", "save_mean", "save_rstd",
-                                  "scale", "shift", "y", "workspace")] + [("stats_blocks", C.c_int32)]
+                                  "scale", "shift", "y", "workspace")] + [("stats_blocks", C.c_int32),
+                                                                          ("emit_blocks", C.POINTER(C.c_int32))]
 
 
 class BnBwdDesc(C.Structure):
     _fields_ = [("dtype", C.c_int32), ("channels", C.c_int32), ("pixels", C.c_int64), ("act", C.c_int32)] + [
         (n, C.c_void_p) for n in ("x", "dy", "dx_add", "gamma", "beta", "save_mean", "save_rstd", "dgamma", "dbeta",
-                                  "dx", "workspace")] + [("stats_blocks", C.c_int32)]
+                                  "dx", "workspace")] + [("stats_blocks", C.c_int32)] + [
+        (n, C.c_void_p) for n in ("next_x", "next_gamma", "next_beta", "next_mean", "next_rstd")] + [
+        ("next_act", C.c_int32), ("next_blocks", C.POINTER(C.c_int32))]
 
 
 class WgradDesc(C.Structure):

@@ -84,11 +84,13 @@ class BnSaved:
 
 def bn_train_forward(x: torch.Tensor, gamma, beta, running_mean=None, running_var=None, act: str = "none",
                      eps: float = 1e-5, momentum: float = 0.1, out: Optional[torch.Tensor] = None,
-                     want_output: bool = True, stats: Optional[ConvStats] = None):
+                     want_output: bool = True, stats: Optional[ConvStats] = None, emit_stats: bool = False):
     """y = act(batch_norm(x)) with batch statistics; running stats updated in place (nn.BatchNorm2d defaults).
 
     Returns (y, BnSaved).  x: NHWC contiguous, channels last.  stats: the ConvStats of the convolution that produced x
-    (conv2d_nhwc(..., stats="fwd")): its epilogue already folded the per-tile sums, the reduction pass over x is skipped."""
+    (conv2d_nhwc(..., stats="fwd")): its epilogue already folded the per-tile sums, the reduction pass over x is skipped.
+    emit_stats: y is itself the input of a BatchNorm (a pre-activation block behind a conv-BN-ReLU unit): the apply pass folds
+    that BatchNorm's sums as it stores y; returns (y, BnSaved, ConvStats) -- hand the ConvStats to that next call."""
     lib = L.load()
     if not x.is_cuda or not x.is_contiguous():
         raise ValueError("x must be a contiguous device tensor (channels last)")
@@ -109,7 +111,14 @@ def bn_train_forward(x: torch.Tensor, gamma, beta, running_mean=None, running_va
     ws = _workspace(c, x.device)
     d.workspace = ws.data_ptr()
     d.stats_blocks = _stats_blocks(stats, ws, 1, x)
+    if emit_stats:
+        if y is None:
+            raise ValueError("bn_train_forward: emit_stats needs the output")
+        blocks = C.c_int32(0)
+        d.emit_blocks = C.pointer(blocks)
     L.check(lib.ppn_bn_train_fwd(C.byref(d), L.current_stream_ptr()), "ppn_bn_train_fwd")
+    if emit_stats:
+        return y, saved, ConvStats(ws, blocks.value, 1, y)
     return y, saved
 
 
@@ -123,9 +132,11 @@ def _stacked(x: torch.Tensor, t: torch.Tensor, nstreams: int, name: str):
 def bn_train_backward(x: torch.Tensor, dy: torch.Tensor, gamma, beta, saved: BnSaved, act: str = "none",
                       dx_add: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
                       dgamma: Optional[torch.Tensor] = None, dbeta: Optional[torch.Tensor] = None, nstreams: int = 1,
-                      stats: Optional[ConvStats] = None):
+                      stats: Optional[ConvStats] = None, next_bn=None):
     """Returns (dx, dgamma, dbeta) for y = act(batch_norm(x)); dx_add (same shape) is added to dx.
     stats: the ConvStats of the input-gradient convolution that produced dy (conv_dgrad(..., bn=...)): skips the reduction pass.
+    next_bn = (x2, gamma2, beta2, BnSaved2, act2): dx is the dy of that BatchNorm (+ activation) over x2 (same shape as dx): the
+    apply pass folds ITS sums as it stores dx; returns (dx, dgamma, dbeta, ConvStats) -- the ConvStats for that next backward.
     dgamma / dbeta: optional f32[C] destinations (e.g. views of the flat gradient buffer), overwritten.
     nstreams > 1: dy (dx, dx_add) hold that many gradient streams over the SAME x, stacked along dim 0; one set of
     launches (ppn_bn_train_bwd_streams); dgamma / dbeta are [nstreams, C]; stream s == the single call on its slices."""
@@ -150,6 +161,16 @@ def bn_train_backward(x: torch.Tensor, dy: torch.Tensor, gamma, beta, saved: BnS
     ws = _workspace(c, x.device, nstreams)
     d.workspace = ws.data_ptr()
     d.stats_blocks = _stats_blocks(stats, ws, 2, dy)
+    if next_bn is not None:
+        x2, gamma2, beta2, saved2, act2 = next_bn
+        if nstreams != 1 or x2.shape != dx.shape or x2.dtype != dx.dtype or not x2.is_contiguous():
+            raise ValueError("bn_train_backward: next_bn needs a single stream and a BatchNorm input of dx's shape and type")
+        nblocks = C.c_int32(0)
+        d.next_x, d.next_act, d.next_blocks = x2.data_ptr(), ACT[act2], C.pointer(nblocks)
+        d.next_gamma, d.next_beta = _f32(gamma2, c, "gamma2"), _f32(beta2, c, "beta2")
+        d.next_mean, d.next_rstd = saved2.mean.data_ptr(), saved2.rstd.data_ptr()
+        L.check(lib.ppn_bn_train_bwd(C.byref(d), L.current_stream_ptr()), "ppn_bn_train_bwd")
+        return dx, dgamma, dbeta, ConvStats(ws, nblocks.value, 2, dx)
     if nstreams == 1:
         L.check(lib.ppn_bn_train_bwd(C.byref(d), L.current_stream_ptr()), "ppn_bn_train_bwd")
     else:

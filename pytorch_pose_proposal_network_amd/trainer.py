@@ -229,18 +229,26 @@ class PPNTrainer:
         return self.opt.lr
 
     # ---- small helpers ------------------------------------------------------------------------------------------
-    def _bn(self, x, prefix, act, stats=None):
-        y, saved = T.bn_train_forward(x, self.P[prefix + ".weight"], self.P[prefix + ".bias"],
-                                      self.buffers[prefix + ".running_mean"], self.buffers[prefix + ".running_var"],
-                                      act=act, stats=stats)
-        return y, saved
+    def _bn(self, x, prefix, act, stats=None, emit=False):
+        """emit: the output is the input of the next unit's BatchNorm -> (y, saved, ConvStats) (train.bn_train_forward)"""
+        return T.bn_train_forward(x, self.P[prefix + ".weight"], self.P[prefix + ".bias"],
+                                  self.buffers[prefix + ".running_mean"], self.buffers[prefix + ".running_var"],
+                                  act=act, stats=stats, emit_stats=emit and self._fuse_stats)
 
-    def _bn_bwd(self, x, dy, prefix, act, saved, dx_add=None, keep=True, stats=None):
+    def _bn_bwd(self, x, dy, prefix, act, saved, dx_add=None, keep=True, stats=None, next_bn=None):
+        """next_bn = (x2, prefix2, act2, saved2): dx is the dy of that BatchNorm -> (dx, ConvStats) (train.bn_train_backward)"""
         # parameter gradients land directly in the flat gradient buffer (probe passes discard them)
-        dx, _, _ = T.bn_train_backward(x, dy, self.P[prefix + ".weight"], self.P[prefix + ".bias"], saved, act=act,
-                                       dx_add=dx_add, dgamma=self.G[prefix + ".weight"] if keep else None,
-                                       dbeta=self.G[prefix + ".bias"] if keep else None, stats=stats)
-        return dx
+        if next_bn is not None and self._fuse_stats:
+            x2, p2, act2, saved2 = next_bn
+            nb = (x2, self.P[p2 + ".weight"], self.P[p2 + ".bias"], saved2, act2)
+        else:
+            nb = None
+        r = T.bn_train_backward(x, dy, self.P[prefix + ".weight"], self.P[prefix + ".bias"], saved, act=act,
+                                dx_add=dx_add, dgamma=self.G[prefix + ".weight"] if keep else None,
+                                dbeta=self.G[prefix + ".bias"] if keep else None, stats=stats, next_bn=nb)
+        if next_bn is not None:
+            return r[0], (r[3] if nb is not None else None)
+        return r[0]
 
     # BatchNorm statistics from the neighbouring convolution's epilogue (train.ConvStats; 16-bit mode, PPN_TRAIN_FUSE_STATS=0: off):
     # a forward convolution that feeds a BatchNorm folds {sum y, sum y^2} per pixel tile, an input-gradient convolution whose result
@@ -302,7 +310,9 @@ class PPNTrainer:
         L.check(lib.ppn_image_to_nhwc(self.compute_dtype, x.data_ptr(), B, H, W, xin8.shape[-1], xin8.data_ptr(),
                                       L.current_stream_ptr()), "ppn_image_to_nhwc")
         cur = None
-        for u in self.units:
+        cur_st = None                                  # ConvStats of `cur` where the next unit opens with a BatchNorm over it
+        for ui, u in enumerate(self.units):
+            nxt_kind = self.units[ui + 1].kind if ui + 1 < len(self.units) else None
             if u.kind == "cbr":
                 wn = f"{u.prefix}.{u.conv_idx}.weight"
                 bnp = f"{u.prefix}.{u.conv_idx + 1}"
@@ -316,12 +326,15 @@ class PPNTrainer:
                 else:
                     src = cur
                     y, yst = self._conv_bn(cur, wn, u.stride, d, d)
-                z, saved = self._bn(y, bnp, "relu", stats=yst)
+                emit = self._fuse_stats and nxt_kind in ("basic", "head")   # those open with a BatchNorm over this unit's output
+                r = self._bn(y, bnp, "relu", stats=yst, emit=emit)
+                z, saved, cur_st = r[0], r[1], (r[2] if emit else None)
                 tape.append(("cbr", u, dict(x=src, y=y, saved=saved)))
                 cur = z
             elif u.kind == "basic":
                 p = u.prefix
-                a, s1 = self._bn(cur, p + ".bn1", "relu")
+                a, s1 = self._bn(cur, p + ".bn1", "relu", stats=cur_st)
+                cur_st = None
                 c1, c1st = self._conv_bn(a, p + ".conv1.weight", u.stride, u.dil[0], u.dil[0])
                 b, s2 = self._bn(c1, p + ".bn2", "relu", stats=c1st)
                 ctx = dict(x=cur, a=a, s1=s1, c1=c1, b=b, s2=s2)
@@ -355,7 +368,8 @@ class PPNTrainer:
                 cur = out
             else:                                                     # PPN head, model.py:113-136
                 R = cur
-                h0, s0 = self._bn(R, "bn0_1", "lrelu")
+                h0, s0 = self._bn(R, "bn0_1", "lrelu", stats=cur_st)
+                cur_st = None
                 a1, a1st = self._conv_bn(h0, "conv1x1_1.weight")
                 h1, s1 = self._bn(a1, "bn1", "lrelu", stats=a1st)
                 a2, a2st = self._conv_bn(h1, "conv1.weight", 1, 1, 1)
@@ -379,7 +393,7 @@ class PPNTrainer:
         return cur
 
     # ---- backward ------------------------------------------------------------------------------------------------
-    def _head_backward(self, c, grad_head, probe_only: bool, channels_used: Optional[int] = None, so=None):
+    def _head_backward(self, c, grad_head, probe_only: bool, channels_used: Optional[int] = None, so=None, next_bn=None):
         """Backward of the head unit.  probe_only: stop at conv1.weight and return its gradient (GradNorm);
         channels_used: only the first so many head channels carry a gradient (6K for the unary losses)."""
         lib = L.load()
@@ -440,7 +454,8 @@ class PPNTrainer:
         da1 = self._bn_bwd(c["a1"], dh1, "bn1", "lrelu", c["s1"], stats=st1)
         self._wgrad("conv1x1_1.weight", c["h0"], da1, 1)
         dh0, st0 = self._dgrad_bn(da1, "conv1x1_1.weight", (Ho, Wo), 1, 1, 0, c["R"], "bn0_1", "lrelu", c["s0"])
-        return self._bn_bwd(c["R"], dh0, "bn0_1", "lrelu", c["s0"], dx_add=skip, stats=st0)
+        # next_bn: the BatchNorm of the unit below that takes this gradient as its dy -> (dR, ConvStats)
+        return self._bn_bwd(c["R"], dh0, "bn0_1", "lrelu", c["s0"], dx_add=skip, stats=st0, next_bn=next_bn)
 
     # ---- second order ------------------------------------------------------------------------------------------------
     def _second_order_tail(self, c, so):
@@ -674,12 +689,22 @@ class PPNTrainer:
             # the unit BEFORE this one in forward order: a conv-BN-ReLU unit's BatchNorm takes this unit's input gradient as its dy
             below = order[ui + 1] if ui + 1 < len(order) else None
             below_cbr = below is not None and below[0] == "cbr"
+            # ... and a block with a projection shortcut takes it as the dy of the shortcut's BatchNorm: (x2, prefix2, act2, saved2)
+            if below_cbr:
+                below_bn = (below[2]["y"], f"{below[1].prefix}.{below[1].conv_idx + 1}", "relu", below[2]["saved"])
+            elif below is not None and below[0] == "basic" and below[1].downsample:
+                below_bn = (below[2]["dsy"], below[1].prefix + ".downsample.1", "none", below[2]["s3"])
+            else:
+                below_bn = None
             if exchange is not None and kind != "head":
                 # every unit AFTER this one in forward order has been processed: its slice of the buffer is final
                 nxt = self._next_offset[id(u)]
                 exchange.ready(nxt, before_issue=join_side)
             if kind == "head":
-                g = self._head_backward(c, g, probe_only=False, so=so)
+                if below_bn is not None:
+                    g, gst = self._head_backward(c, g, probe_only=False, so=so, next_bn=below_bn)
+                else:
+                    g = self._head_backward(c, g, probe_only=False, so=so)
                 if exchange is not None and exchange.enabled:
                     # the GradNorm probes need THIS rank's d loss/d conv1.weight; keep it before its bucket is summed
                     join_side()
@@ -687,22 +712,26 @@ class PPNTrainer:
             elif kind == "basic":
                 p = u.prefix
                 hw = c["x"].shape[1:3]
+                if u.downsample:
+                    # first: its BatchNorm may take the sums the unit above folded while it wrote g (gst), and they sit in the
+                    # workspace every BatchNorm / statistics epilogue of this channel count uses
+                    dds = self._bn_bwd(c["dsy"], g, p + ".downsample.1", "none", c["s3"], stats=gst)
+                    self._wgrad(p + ".downsample.0.weight", c["x"], dds, 1, u.stride, 1, 0)
+                    dxr = T.conv_dgrad(dds, self.P[p + ".downsample.0.weight"], hw, u.stride, 1, 0)
+                else:
+                    dxr = g
+                gst = None
                 self._wgrad(p + ".conv2.weight", c["b"], g, 3, 1, u.dil[1], u.dil[1])
                 db, dbst = self._dgrad_bn(g, p + ".conv2.weight", c["b"].shape[1:3], 1, u.dil[1], u.dil[1],
                                           c["c1"], p + ".bn2", "relu", c["s2"])
                 dc1 = self._bn_bwd(c["c1"], db, p + ".bn2", "relu", c["s2"], stats=dbst)
                 self._wgrad(p + ".conv1.weight", c["a"], dc1, 3, u.stride, u.dil[0], u.dil[0])
-                if u.downsample:
-                    dds = self._bn_bwd(c["dsy"], g, p + ".downsample.1", "none", c["s3"])
-                    self._wgrad(p + ".downsample.0.weight", c["x"], dds, 1, u.stride, 1, 0)
-                    dxr = T.conv_dgrad(dds, self.P[p + ".downsample.0.weight"], hw, u.stride, 1, 0)
-                else:
-                    dxr = g
-                # (after the shortcut branch: nothing between this launch and the BatchNorm that takes its sums)
                 da, dast = self._dgrad_bn(dc1, p + ".conv1.weight", hw, u.stride, u.dil[0], u.dil[0],
                                           c["x"], p + ".bn1", "relu", c["s1"])
-                g = self._bn_bwd(c["x"], da, p + ".bn1", "relu", c["s1"], dx_add=dxr, stats=dast)
-                gst = None
+                if below_bn is not None:
+                    g, gst = self._bn_bwd(c["x"], da, p + ".bn1", "relu", c["s1"], dx_add=dxr, stats=dast, next_bn=below_bn)
+                else:
+                    g = self._bn_bwd(c["x"], da, p + ".bn1", "relu", c["s1"], dx_add=dxr, stats=dast)
             elif kind == "bottleneck":
                 p = u.prefix
                 hw = c["x"].shape[1:3]
@@ -743,10 +772,9 @@ class PPNTrainer:
                     g = None                                               # the input needs no gradient
                 else:
                     self._wgrad(wn, c["x"], dy, 3, u.stride, d, d)
-                    if below_cbr:                                          # g is the dy of the conv-BN-ReLU unit below
-                        bu, bc = below[1], below[2]
-                        g, gst = self._dgrad_bn(dy, wn, c["x"].shape[1:3], u.stride, d, d, bc["y"],
-                                                f"{bu.prefix}.{bu.conv_idx + 1}", "relu", bc["saved"])
+                    if below_bn is not None:                               # g is the dy of a BatchNorm of the unit below
+                        g, gst = self._dgrad_bn(dy, wn, c["x"].shape[1:3], u.stride, d, d, below_bn[0], below_bn[1],
+                                                below_bn[2], below_bn[3])
                     else:
                         g = T.conv_dgrad(dy, self.P[wn], c["x"].shape[1:3], u.stride, d, d)
         if self._side is not None:

@@ -136,3 +136,50 @@ def test_fused_statistics_are_bitwise_reproducible():
         res.append((s.mean.clone(), s.rstd.clone(), y.clone()))
     for r in res[1:]:
         assert all(torch.equal(a, c) for a, c in zip(r, res[0]))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("shape", [(2, 48, 48, 32), (3, 17, 19, 512), (4, 24, 24, 128)])
+def test_apply_pass_emits_the_next_batchnorm_sums_bit_for_bit(dtype, shape):
+    """bn_train_forward(emit_stats=True): same slab, same per-thread order as the reduction pass over the stored y"""
+    T = _mods()
+    dev = torch.device("cuda")
+    c = shape[-1]
+    g = torch.Generator(device="cpu").manual_seed(c)
+    x = (torch.randn(*shape, generator=g) * 2 + 0.3).to(dev).to(dtype)
+    g1, b1 = torch.rand(c, device=dev) + 0.5, torch.randn(c, device=dev)
+    g2, b2 = torch.rand(c, device=dev) + 0.5, torch.randn(c, device=dev)
+    y, saved, st = T.bn_train_forward(x, g1, b1, act="relu", emit_stats=True)
+    assert st.blocks > 0
+    ya, sa = T.bn_train_forward(y, g2, b2, act="relu", stats=st)
+    yr, savedr = T.bn_train_forward(x, g1, b1, act="relu")
+    yb, sb = T.bn_train_forward(yr, g2, b2, act="relu")
+    assert torch.equal(y, yr) and torch.equal(saved.mean, savedr.mean)
+    assert torch.equal(sa.mean, sb.mean) and torch.equal(sa.rstd, sb.rstd) and torch.equal(ya, yb)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("act2", ["none", "relu"])
+@pytest.mark.parametrize("shape", [(2, 48, 48, 32), (3, 17, 19, 512), (4, 24, 24, 128)])
+def test_backward_apply_pass_folds_the_next_batchnorm_sums_bit_for_bit(dtype, act2, shape):
+    """bn_train_backward(next_bn=...): dx is the dy of another BatchNorm over x2 (the shortcut's BatchNorm of the block below / the
+    conv-BN-ReLU unit below): its dgamma, dbeta, dx equal the unfused call's bit for bit"""
+    T = _mods()
+    dev = torch.device("cuda")
+    c = shape[-1]
+    g = torch.Generator(device="cpu").manual_seed(c + 7)
+    x = (torch.randn(*shape, generator=g) * 1.5).to(dev).to(dtype)
+    x2 = (torch.randn(*shape, generator=g) * 0.8 - 0.4).to(dev).to(dtype)
+    dy = torch.randn(*shape, generator=g).to(dev).to(dtype)
+    skip = torch.randn(*shape, generator=g).to(dev).to(dtype)
+    g1, b1 = torch.rand(c, device=dev) + 0.5, torch.randn(c, device=dev)
+    g2, b2 = torch.rand(c, device=dev) + 0.5, torch.randn(c, device=dev)
+    _, s1 = T.bn_train_forward(x, g1, b1, act="relu")
+    _, s2 = T.bn_train_forward(x2, g2, b2, act=act2)
+    dx, dg, db, st = T.bn_train_backward(x, dy, g1, b1, s1, act="relu", dx_add=skip, next_bn=(x2, g2, b2, s2, act2))
+    assert st.blocks > 0
+    dxa, dga, dba = T.bn_train_backward(x2, dx, g2, b2, s2, act=act2, stats=st)
+    dxr, dgr, dbr = T.bn_train_backward(x, dy, g1, b1, s1, act="relu", dx_add=skip)
+    dxb, dgb, dbb = T.bn_train_backward(x2, dxr, g2, b2, s2, act=act2)
+    assert torch.equal(dx, dxr) and torch.equal(dg, dgr) and torch.equal(db, dbr)
+    assert torch.equal(dga, dgb) and torch.equal(dba, dbb) and torch.equal(dxa, dxb)

@@ -165,10 +165,10 @@ def test_bf16_gradients_track_f32():
             return o if k.get("nchw_f32") else rb(o)
 
         def bnf(*a, **k):
-            y, sv = orig_bnf(*a, **k)
-            if emulate and y is not None:
-                y.copy_(rb(y))
-            return y, sv
+            r = orig_bnf(*a, **k)              # (y, saved) or, with emit_stats (16-bit mode only), (y, saved, ConvStats)
+            if emulate and r[0] is not None:
+                r[0].copy_(rb(r[0]))
+            return r
 
         T.conv2d_nhwc, T.bn_train_forward = convf, bnf
         try:
