@@ -447,9 +447,9 @@ class PPNTrainer:
             # ones here, so everything upstream is back-propagated once
             if so.get("launch_probes") is not None:
                 so.pop("launch_probes")()
-            h1_bar, r_bar = self._second_order_tail(c, so)
-            if h1_bar is not None:
-                dh1 = dh1 + h1_bar
+            h1_sum, r_bar = self._second_order_tail(c, so, dh1)
+            if h1_sum is not None:
+                dh1 = h1_sum                             # first-order seed + second-order adjoint (added in a conv epilogue)
                 skip = da3 + r_bar
         da1 = self._bn_bwd(c["a1"], dh1, "bn1", "lrelu", c["s1"], stats=st1)
         self._wgrad("conv1x1_1.weight", c["h0"], da1, 1)
@@ -458,7 +458,7 @@ class PPNTrainer:
         return self._bn_bwd(c["R"], dh0, "bn0_1", "lrelu", c["s0"], dx_add=skip, stats=st0, next_bn=next_bn)
 
     # ---- second order ------------------------------------------------------------------------------------------------
-    def _second_order_tail(self, c, so):
+    def _second_order_tail(self, c, so, dh1=None):
         """d Lgrad / d theta restricted to what the probe weight W = conv1.weight can influence: the head's tail.
         so = dict(head, targets, losses, coeff, unary=[dL_i/dW for i < 4]).  Accumulates into the tail parameters'
         gradients and returns the adjoints (at h1, at the skip tensor R) to be added to the first-order seeds.
@@ -612,7 +612,8 @@ class PPNTrainer:
                         c["h1"], a2sum)
         # adjoint at h1: through W (primal) and through u_i = conv(h1, v_i) per stream; every convolution adds the sum so
         # far in its epilogue (f32, one rounding) instead of a separate elementwise pass
-        h1_bar = T.conv_dgrad(a2sum, P["conv1.weight"], (Ho, Wo), 1, 1, 1)
+        # (dh1: the first-order gradient at h1 joins here, in the first epilogue of the chain, instead of a pass of its own)
+        h1_bar = T.conv_dgrad(a2sum, P["conv1.weight"], (Ho, Wo), 1, 1, 1, add=dh1)
         for j, v in enumerate(vs):
             h1_bar = T.conv_dgrad(U_bar[j * B:(j + 1) * B], v, (Ho, Wo), 1, 1, 1, add=h1_bar)
         r_bar = a3sum
