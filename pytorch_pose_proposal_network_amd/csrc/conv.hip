@@ -392,18 +392,73 @@ struct PackItemDev {
     void* out;
     unsigned long long n;                 // cout_pad * k_total
     int cout, cin, ntaps, ktot, korder, kstep, transposed, otype;   // otype: 0 f32, 1 bf16, 2 f16
-    int first_block, pad_;
+    int first_block, tiled;               // tiled: pack_tile() units of 8 rows x one 64-channel chunk (see there)
 };
 static_assert(sizeof(PackItemDev) == PPN_PACK_ITEM_BYTES, "ppn.h: PPN_PACK_ITEM_BYTES");
 constexpr int kPackChunk = 2048;
 
+// The MFMA layers' 16-bit packs (k_order 1, 64-channel chunks, no K padding, <= 9 taps): a workgroup owns 8 packed rows x one
+// 64-channel chunk = 8 x 64 x ntaps elements, which are CONTIGUOUS runs on both sides -- forward layout: 8 runs of 64 * ntaps
+// floats in, 8 runs of ntaps * 64 halves out; input-gradient layout (channel roles swapped, filter rotated): 64 runs of 8 * ntaps
+// floats in -- and differ by a [channel][tap] <-> [tap][channel] transposition, done in LDS.  The element-wise form below gathers
+// 8 floats at a stride of ntaps (or cout * ntaps) floats per thread: ~1.4 TB/s of useful traffic, 165 us per training iteration
+// for DRN-D-22's two layouts; same values, same rounding.
+constexpr int kTileRows = 8, kTileMaxTaps = 9;
+// NT: the tap count as a compile-time constant (1 and 9: the index arithmetic is divisions by nt -- by run-time values it costs
+// more than the memory traffic), 0 = any
+template <int NT>
+__device__ __forceinline__ void pack_tile(const PackItemDev& it, int unit, float* tile) {
+    const int t = threadIdx.x, nt = NT > 0 ? NT : it.ntaps;
+    const int nchunks = it.cin / 64;
+    const int co0 = (unit / nchunks) * kTileRows, ci0 = (unit % nchunks) * 64;
+    const int E = kTileRows * 64 * nt;
+    if (!it.transposed) {
+        for (int e = t; e < E; e += 256) {
+            const int r = e / (64 * nt), off = e - r * (64 * nt);
+            tile[e] = co0 + r < it.cout ? it.w[((size_t)(co0 + r) * it.cin + ci0) * nt + off] : 0.f;
+        }
+    } else {
+        for (int e = t; e < E; e += 256) {
+            const int ci = e / (kTileRows * nt), off = e - ci * (kTileRows * nt);
+            const int r = off / nt, tp = off - r * nt;
+            const float v = co0 + r < it.cout ? it.w[((size_t)(ci0 + ci) * it.cout + co0) * nt + off] : 0.f;
+            tile[(r * 64 + ci) * nt + (nt - 1 - tp)] = v;
+        }
+    }
+    __syncthreads();
+    for (int g = t; g < kTileRows * nt * 8; g += 256) {
+        const int r = g / (nt * 8), rem = g - r * (nt * 8), tap = rem >> 3, c8 = rem & 7;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = tile[(r * 64 + c8 * 8 + j) * nt + tap];
+        const size_t o = (size_t)(co0 + r) * it.ktot + (size_t)((ci0 / 64) * nt + tap) * 64 + c8 * 8;
+        if (it.otype == 1) {
+            ppnconv::store8<__bf16>(reinterpret_cast<char*>(static_cast<__bf16*>(it.out) + o), v);
+        } else {
+            typedef __attribute__((ext_vector_type(8))) _Float16 h8;
+            h8 q;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) q[j] = (_Float16)v[j];     // as ppn_pack_weight converts (no clamp)
+            *reinterpret_cast<h8*>(static_cast<_Float16*>(it.out) + o) = q;
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) pack_table_kernel(const PackItemDev* __restrict__ tab, int n_items) {
+    __shared__ float tile[kTileRows * 64 * kTileMaxTaps];
     int lo = 0, hi = n_items - 1;
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
         if (tab[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
     }
     const PackItemDev it = tab[lo];
+    if (it.tiled) {
+        const int unit = (int)blockIdx.x - it.first_block;
+        if (it.ntaps == 9) pack_tile<9>(it, unit, tile);
+        else if (it.ntaps == 1) pack_tile<1>(it, unit, tile);
+        else pack_tile<0>(it, unit, tile);
+        return;
+    }
     const size_t base = (size_t)((int)blockIdx.x - it.first_block) * kPackChunk;
     // 8 consecutive k of one output row share their tap when the channel index runs fastest over a multiple of 8 (every
     // MFMA layer: k_order 1 with 64-channel chunks, k_order 0 with cin % 8 == 0): ONE index decomposition (six integer
@@ -829,8 +884,12 @@ extern "C" int ppn_pack_table_build(const ppn_pack_item* items, int32_t n, void*
         d.cout = s.cout; d.cin = s.cin; d.ntaps = s.ksize * s.ksize; d.ktot = s.k_total; d.korder = s.k_order;
         d.kstep = s.k_step > 0 ? s.k_step : 1; d.transposed = s.transposed ? 1 : 0;
         d.otype = (s.k_order == 2 || s.dtype == PPN_F32) ? 0 : (s.dtype == PPN_BF16 ? 1 : 2);   // k_order 2 stays f32
-        d.first_block = (int)blocks; d.pad_ = 0;
-        blocks += (long long)((d.n + kPackChunk - 1) / kPackChunk);
+        d.first_block = (int)blocks;
+        static const bool tiles_on = !(getenv("PPN_PACK_TILED") && atoi(getenv("PPN_PACK_TILED")) == 0);   // A/B switch
+        d.tiled = (tiles_on && d.korder == 1 && d.kstep == 64 && d.cin % 64 == 0 && d.ktot == d.ntaps * d.cin &&
+                   d.ntaps <= kTileMaxTaps && d.otype != 0 && s.cout_pad % kTileRows == 0) ? 1 : 0;
+        blocks += d.tiled ? (long long)(s.cout_pad / kTileRows) * (d.cin / 64)
+                          : (long long)((d.n + kPackChunk - 1) / kPackChunk);
         if (blocks > 0x7fffffffLL) return ppn::fail(PPN_E_UNSUPPORTED, "ppn_pack_table_build: too many elements");
         t[i] = d;
     }
