@@ -473,13 +473,16 @@ def bump_param_version():
     _param_version[0] += 1
 
 
-_pack_tables: dict = {}             # device -> (device table, entries, grid, keys): rebuilt when the cache gains a key
+_pack_tables: dict = {}             # (device, storages) -> (device table, entries, grid, keys): rebuilt when the cache gains a key
 _BATCHED_PACK = os.environ.get("PPN_TRAIN_BATCHED_PACK", "1") != "0"
 
 
-def repack_all(device) -> int:
-    """Refresh EVERY cached packed weight on `device` from the current parameter values with one launch on the current
+def repack_all(device, storages=None) -> int:
+    """Refresh the cached packed weights on `device` from the current parameter values with one launch on the current
     stream (ppn_pack_table_run) and stamp them with the current parameter version; returns the number of entries.
+    storages: the registered storages (register_param_storage keys) whose views to refresh -- a trainer passes ITS OWN (its flat
+    parameter buffer and its padded conv3 copies), so another live trainer's packed weights, which its kernels may still be
+    reading on its streams, are never rewritten from here; None: every registered storage.
     conv2d_nhwc packs a weight view the first time it meets it and on every parameter version after that -- ~86 launches
     of ~8 us per DRN-D-22 iteration (each layer's forward and input-gradient layout); called at the head of a pass (after
     bump_param_version, when every consumer of the previous copies has finished: the trainer joins its side streams
@@ -490,11 +493,13 @@ def repack_all(device) -> int:
     device = torch.device(device)
     if device.index is None:
         device = torch.device(device.type, torch.cuda.current_device())
-    keys = [k for k, v in _pack_cache.items() if v[1].device == device]
+    scope = None if storages is None else frozenset(storages)
+    keys = [k for k, v in _pack_cache.items() if v[1].device == device and (scope is None or v[2] in scope)]
     if not keys:
         return 0
     lib = L.load()
-    tab = _pack_tables.get(device)
+    tkey = (device, scope)
+    tab = _pack_tables.get(tkey)
     if tab is None or tab[3] != keys:
         items = (L.PackItem * len(keys))()
         for it, k in zip(items, keys):
@@ -503,7 +508,7 @@ def repack_all(device) -> int:
         host = torch.empty(len(keys) * L.PPN_PACK_ITEM_BYTES, dtype=torch.uint8)
         grid = C.c_int32(0)
         L.check(lib.ppn_pack_table_build(items, len(keys), host.data_ptr(), C.byref(grid)), "ppn_pack_table_build")
-        tab = _pack_tables[device] = (host.to(device), len(keys), grid.value, keys)
+        tab = _pack_tables[tkey] = (host.to(device), len(keys), grid.value, keys)
     L.check(lib.ppn_pack_table_run(tab[0].data_ptr(), tab[1], tab[2], L.current_stream_ptr()), "ppn_pack_table_run")
     ver = _param_version[0]
     for k in keys:

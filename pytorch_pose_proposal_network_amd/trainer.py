@@ -302,7 +302,8 @@ class PPNTrainer:
         T.bump_param_version()        # parameters may have been edited in place since the last pass: repack once per forward
         for used in list(self._w3p):  # the padded copies of conv3.weight follow the parameters BEFORE they are repacked
             self._w3_padded(used)
-        T.repack_all(self.device)     # ... every weight view the previous passes met, in one launch
+        # ... every weight view the previous passes of THIS trainer met, in one launch
+        T.repack_all(self.device, [self._storage_key] + [ent[2] for ent in self._w3p.values()])
         tape = []
         # the 7x7 stem reads NCHW f32; its weight gradient reads an NHWC copy padded with zero channels: 4 channels for
         # the dedicated bf16 kernel (csrc/stem_wgrad.hip: two MFMAs per filter row), 8 for the generic f32 kernel

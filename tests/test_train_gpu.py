@@ -421,3 +421,36 @@ def test_data_movement_kernels_equal_the_torch_copies(dtype):
         L.check(L.load().ppn_image_to_nhwc(code, x.data_ptr(), 3, 11, 14, cp, got.data_ptr(), L.current_stream_ptr()), "image")
         assert torch.equal(got, want)
     torch.cuda.synchronize()
+
+
+def test_repack_all_is_scoped_to_the_given_storages():
+    """train.repack_all(device, storages): one trainer's batched repack must not rewrite (and stamp as current) the packed
+    weights of another registered storage, whose kernels may still be reading them on its own streams."""
+    from pytorch_pose_proposal_network_amd import train as T
+    dev = torch.device("cuda")
+    fa = torch.randn(128 * 128 * 9, device=dev) * 0.05
+    fb = torch.randn(128 * 128 * 9, device=dev) * 0.05
+    ka, kb = T.register_param_storage(fa), T.register_param_storage(fb)
+    try:
+        x = torch.randn(1, 8, 8, 128, device=dev).to(torch.bfloat16)
+        wa, wb = fa.view(128, 128, 3, 3), fb.view(128, 128, 3, 3)
+        T.conv2d_nhwc(x, wa, 1, 1, 1)
+        T.conv2d_nhwc(x, wb, 1, 1, 1)
+        ents = {v[2]: k for k, v in T._pack_cache.items() if v[2] in (ka, kb)}
+        assert set(ents) == {ka, kb}
+        before_b = T._pack_cache[ents[kb]][1].clone()
+        fa.mul_(2.0); fb.mul_(3.0)
+        T.bump_param_version()
+        n = T.repack_all(dev, [ka])
+        assert n == 1
+        ver = T._param_version[0]
+        assert T._pack_cache[ents[ka]][0] == ver and T._pack_cache[ents[kb]][0] != ver
+        assert torch.equal(T._pack_cache[ents[kb]][1], before_b)             # untouched
+        ya = T.conv2d_nhwc(x, wa, 1, 1, 1)                                   # the refreshed copy
+        yb = T.conv2d_nhwc(x, wb, 1, 1, 1)                                   # stale entry: repacked on use
+        assert T._pack_cache[ents[kb]][0] == ver
+        torch.testing.assert_close(ya.float(), T.conv2d_nhwc(x, wa.clone(), 1, 1, 1).float(), rtol=0, atol=0)
+        torch.testing.assert_close(yb.float(), T.conv2d_nhwc(x, wb.clone(), 1, 1, 1).float(), rtol=0, atol=0)
+    finally:
+        T.unregister_param_storage(ka)
+        T.unregister_param_storage(kb)
