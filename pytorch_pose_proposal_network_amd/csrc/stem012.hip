@@ -32,8 +32,12 @@
 // ds_read_u16 the same change cost +15 us).  Phase by phase (timing-only builds, -DPPN_S012_SKIP): convert 25,
 // layer 0 47, layer 1 43, layer 2 31, input requests 21 us -- additive, no unit saturated (SQ counters of the 159 us
 // kernel: MFMA pipe 25 %, VALU issue 39 %, LDS 45 % of which a fifth bank conflicts, 36 % of the wave cycles in s_waitcnt):
-// with two waves per SIMD (223 VGPRs: the three weight sets) the kernel is latency-bound; the step change needs
-// wave-specialised producers / consumers under 128 VGPRs each.
+// round 4 read this as "latency-bound at two waves per SIMD (223 VGPRs: the three weight sets); the step change needs wave-specialised
+// producers / consumers under 128 VGPRs each".  Round 5 built exactly that (8 waves = front role: requests, conversion, layer 0 | back
+// role: layer 1, layer 2; 128 VGPRs, two workgroups = 16 waves per CU; bit-identical): 170 us against 168 -- and at equal wave count the
+// role split is SLOWER than two independent workgroups (186 vs 168).  The phases are additive because the launch is bound by the
+// throughput of the shared pipes (12.2 M LDS instructions = ~60 % of the LDS cycles, VALU 39 %, MFMA 25 %), not by waiting: what would
+// shorten it is fewer LDS instructions per pixel, not another wave schedule (profiles/r05/stem_role_split.txt).
 #include <hip/hip_bf16.h>
 
 #include <cstdlib>
