@@ -60,7 +60,9 @@ def normalized_frames(frames_u8: np.ndarray) -> np.ndarray:
     x = frames_u8.astype(np.float32).transpose(0, 3, 1, 2)
     mean = np.array(cfg.MEAN, np.float32).reshape(1, 3, 1, 1)
     std = np.array(cfg.STD, np.float32).reshape(1, 3, 1, 1)
-    return ((x - mean) / std).astype(np.float32)
+    # C-contiguous NCHW, as a DataLoader hands batches over (the arithmetic on the transposed view keeps the NHWC memory order, and
+    # PPNTrainer.forward would then re-lay the batch out on the device in every step: 26 us at batch 32)
+    return np.ascontiguousarray(((x - mean) / std).astype(np.float32))
 
 
 def planted_crowd_head(seed: int, n_people: int = 16, n_decoys: int = 4, out_hw=(24, 24),
