@@ -183,3 +183,56 @@ def test_backward_apply_pass_folds_the_next_batchnorm_sums_bit_for_bit(dtype, ac
     dxb, dgb, dbb = T.bn_train_backward(x2, dxr, g2, b2, s2, act=act2)
     assert torch.equal(dx, dxr) and torch.equal(dg, dgr) and torch.equal(db, dbr)
     assert torch.equal(dga, dgb) and torch.equal(dba, dbb) and torch.equal(dxa, dxb)
+
+
+def test_bad_statistics_requests_are_refused():
+    """error behaviour of the new descriptor fields (include/ppn.h): a request the library cannot honour in form is PPN_E_INVALID,
+    one it cannot honour in substance (no such epilogue) is a normal launch that reports 0 tiles"""
+    import ctypes as C
+    from pytorch_pose_proposal_network_amd import lib as L
+    T = _mods()
+    lib = L.load()
+    dev = torch.device("cuda")
+    x = torch.randn(1, 16, 16, 128, device=dev).to(torch.bfloat16)
+    w = torch.randn(128, 128, 3, 3, device=dev) * 0.03
+    g, b = torch.ones(128, device=dev), torch.zeros(128, device=dev)
+    _, saved = T.bn_train_forward(x, g, b, act="relu")
+    # mode 2 without the BatchNorm's input / a wrong mode
+    orig = lib.ppn_conv2d_fused
+    seen = {}
+
+    def spy(dref, st):
+        d = dref._obj
+        if "mode3" in seen:
+            d.stats_mode = 3
+        elif "nox" in seen:
+            d.stats_x = None
+        return orig(dref, st)
+
+    lib.ppn_conv2d_fused = spy
+    try:
+        seen["nox"] = True
+        with pytest.raises(L.PPNError):
+            T.conv2d_nhwc(x, w, 1, 1, 1, stats=(x, g, b, saved, "relu"))
+        seen.pop("nox"); seen["mode3"] = True
+        with pytest.raises(L.PPNError):
+            T.conv2d_nhwc(x, w, 1, 1, 1, stats="fwd")
+    finally:
+        lib.ppn_conv2d_fused = orig
+    # BatchNorm: more partial blocks than a workspace holds; next_bn / stats with several gradient streams
+    d = L.BnDesc()
+    y = torch.empty_like(x)
+    sv = T.BnSaved(128, dev)
+    d.dtype, d.channels, d.pixels, d.act = L.PPN_BF16, 128, 256, 1
+    d.eps, d.momentum = 1e-5, 0.1
+    d.x, d.gamma, d.beta, d.y = x.data_ptr(), g.data_ptr(), b.data_ptr(), y.data_ptr()
+    d.save_mean, d.save_rstd = sv.mean.data_ptr(), sv.rstd.data_ptr()
+    d.workspace = T._workspace(128, dev).data_ptr()
+    d.stats_blocks = 1025
+    assert lib.ppn_bn_train_fwd(C.byref(d), L.current_stream_ptr()) == -1          # PPN_E_INVALID
+    d.stats_blocks = -1
+    assert lib.ppn_bn_train_fwd(C.byref(d), L.current_stream_ptr()) == -1
+    dy2 = torch.randn(2, 16, 16, 128, device=dev).to(torch.bfloat16)
+    with pytest.raises(ValueError):
+        T.bn_train_backward(x, dy2, g, b, saved, act="relu", nstreams=2, next_bn=(x, g, b, saved, "none"))
+    torch.cuda.synchronize()
