@@ -473,6 +473,9 @@ __global__ void __launch_bounds__(256, 2) stem012_kernel(Stem012Args a) {
                 for (int kk = 0; kk < 5; ++kk) {
                     lo[st][kk] = lds_read64<sg * 128>(rd[kk]);
                     hi[st][kk] = lds_read64<sg * 128 + W0 * 8>(rd[kk]);
+#ifdef PPN_S012_DUP_L1      // diagnostic: half of layer 1's operand reads issued twice (is the launch bound by LDS traffic?)
+                    lo[st][kk] = lds_read64<sg * 128>(rd[kk]);
+#endif
                 }
             };
             fetch(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
@@ -480,7 +483,11 @@ __global__ void __launch_bounds__(256, 2) stem012_kernel(Stem012Args a) {
                 constexpr int sg = decltype(sgc)::value, cur = sg & 1;
                 if constexpr (sg + 1 < NS) {
                     fetch(std::integral_constant<int, sg + 1>{}, std::integral_constant<int, cur ^ 1>{});
+#ifdef PPN_S012_DUP_L1
+                    asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");
+#else
                     asm volatile("s_waitcnt lgkmcnt(10)" ::: "memory");
+#endif
                 } else {
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 }
