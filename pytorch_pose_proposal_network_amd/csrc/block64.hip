@@ -147,34 +147,46 @@ __global__ void __launch_bounds__(512, 2) block64_kernel(BlkArgs a, unsigned ten
     };
 
     // ---- role 0: the 12 x 20 input patch of a tile by LDS-DMA (30 instructions of 8 rows over the role's 4 waves) ----------
+    // A wave's instructions g = rw, rw + 4, .. cover patch rows row0 + 32 i: the lane's (patch y, patch x) of instruction 0 is a
+    // constant of the kernel and moves by (+1, +12) or (+2, -8) per instruction, its XOR chunk ((row >> 1) & 7) does not move at all,
+    // so an instruction is a handful of adds and compares.  (The straightforward form -- row / 20, two 32-bit multiplies and the
+    // swizzle per instruction, 227 cycles each by the stamps -- made role 0 the longer role: 2.7 k of its 11.3 k cycles per tile.)
+    const int prow0 = rw * 8 + (lane >> 3);
+    const int ppy0 = prow0 / PW, ppx0 = prow0 - ppy0 * PW;
+    const int pchunk = ((lane & 7) ^ ((prow0 >> 1) & 7)) * 16;
+    static_assert(PW == 20, "issue_patch steps 32 rows = one patch line + 12 pixels");
     auto issue_patch = [&](int tile, int buf) {
         int img, ty, tx;
         tile_pos(tile, img, ty, tx);
         const int y0 = ty * TH - 2, x0 = tx * TW - 2;
+        const int base = ((img * a.H + y0) * a.W + x0) * 128;          // wave-uniform; the sum with `rel` is only used where in range
+        const int step = (a.W + 12) * 128, wrap = (a.W - PW) * 128;
+        int py = ppy0, px = ppx0;
+        int rel = (ppy0 * a.W + ppx0) * 128 + pchunk;
         for (int g = rw; g < IN_DMA; g += 4) {
-            const int row = g * 8 + (lane >> 3);
-            const int py = row / PW, px = row - py * PW;
             const int y = y0 + py, x = x0 + px;
-            const int chunk = (lane & 7) ^ ((row >> 1) & 7);
             const bool ok = (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
-            const unsigned off = ok ? (unsigned)(((img * a.H + y) * a.W + x) * 128 + chunk * 16) : kOOB;
-            bufload_lds16(xrs, smem + buf * IN_BYTES + g * 1024, off);
+            bufload_lds16(xrs, smem + buf * IN_BYTES + g * 1024, ok ? (unsigned)(base + rel) : kOOB);
+            px += 12; py += 1; rel += step;
+            if (px >= PW) { px -= PW; py += 1; rel += wrap; }
         }
     };
 
     // ---- role 0 also fetches the RESIDUAL rows of a tile (8 x 16 pixels, 16 instructions) for role 1, one phase ahead: role 1
     // then needs neither registers nor a memory wait for them (row r keeps its chunks XORed with r & 7)
     const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.res ? a.res : a.src), 0, a.res ? tensor_bytes : 0u, 0x00020000);
-    auto issue_res = [&](int tile, int buf) {
+    auto issue_res = [&](int tile, int buf) {                          // rows row0 + 32 i: two tile lines down, same column, same chunk
         int img, ty, tx;
         tile_pos(tile, img, ty, tx);
+        static_assert(TW == 16, "issue_res steps 32 rows = two tile lines");
+        const int x = tx * TW + (prow0 & 15);
+        int y = ty * TH + (prow0 >> 4);
+        int off = ((img * a.H + y) * a.W + x) * 128 + ((lane & 7) ^ (prow0 & 7)) * 16;
+        const int step = 2 * a.W * 128;
+        const bool xok = x < a.W;
         for (int g = rw; g < TH * TW / 8; g += 4) {
-            const int row = g * 8 + (lane >> 3);
-            const int y = ty * TH + (row >> 4), x = tx * TW + (row & 15);
-            const int chunk = (lane & 7) ^ (row & 7);
-            const bool ok = y < a.H && x < a.W;
-            const unsigned off = ok ? (unsigned)(((img * a.H + y) * a.W + x) * 128 + chunk * 16) : kOOB;
-            bufload_lds16(rrs, smem + OFF_RES + buf * RES_BYTES + g * 1024, off);
+            bufload_lds16(rrs, smem + OFF_RES + buf * RES_BYTES + g * 1024, (xok && y < a.H) ? (unsigned)off : kOOB);
+            y += 2; off += step;
         }
     };
 
